@@ -1,0 +1,215 @@
+/*
+ * mars5_hip.h  --  C ABI of libmars5_hip.so: hand-written HIP kernels (gfx950 / MI355X)
+ * for the MARS5-TTS hot path (AR decode loop + multinomial-DDPM NAR refinement).
+ *
+ * Conventions: plain pointers + explicit sizes/strides, no C++ or torch types;
+ * every function returns an int status (M5_OK = 0, negative = error, never throws);
+ * the CALLER owns every buffer (weights, KV cache, workspaces); all pointers are DEVICE
+ * pointers unless stated; `stream` is a hipStream_t passed as void*; nothing here
+ * synchronises the host.  Strides are in ELEMENTS unless stated.  The reference is pure
+ * Python/PyTorch (no FFI of its own), so each entry point cites the reference Python
+ * function whose device arithmetic it replaces (paths relative to the reference root).
+ *
+ * dtype codes select the GEMM/attention OPERAND type; accumulation is always fp32 and the
+ * residual stream is always fp32:  M5_F32 = exact-fp32 parity mode (reference CPU/NAR
+ * numerics), M5_F16 = reference GPU autocast numerics (ar_generate.py:67), M5_BF16 =
+ * BASELINE.json config.
+ */
+#ifndef MARS5_HIP_H
+#define MARS5_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define M5_OK 0
+#define M5_ERR_ARG (-1)
+#define M5_ERR_LAUNCH (-2)
+#define M5_ERR_UNSUPPORTED (-3)
+
+#define M5_F32 0
+#define M5_F16 1
+#define M5_BF16 2
+
+int m5_version(void);                 /* ABI version, currently 1 */
+const char* m5_build_info(void);      /* "gfx950 ..." */
+
+/* ------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = A[M,K] . W[N,K]^T (+bias)   -- both operands K-contiguous (nn.Linear
+ * layout), MFMA 16x16x32 (f16/bf16) or 16x16x4 (f32).  Replaces every nn.Linear on the
+ * path at M > 1: nn_future.py:241,274,298,398 (AR prefill), model.py:61-65,179-203,339,342
+ * (speaker encoders, NAR encoder/decoder, heads).  K must be a multiple of 64.
+ * ------------------------------------------------------------------------------------ */
+#define M5_EPI_F32 0          /* C fp32 = acc + bias                                      */
+#define M5_EPI_DT 1           /* C dtype = acc + bias                                     */
+#define M5_EPI_RESIDUAL 2     /* C fp32 += acc + bias   (x = x + linear(...))             */
+#define M5_EPI_SWIGLU 3       /* W rows interleaved (W_i, V_i): C dtype[M, N/2] = silu(c_2i) * c_2i+1
+                                 (nn_future.py:21-29, :297-298)                           */
+#define M5_EPI_QKV 4          /* scatter columns into head-major Q / K / V^T (M5QkvScatter) */
+#define M5_EPI_SILU_DT 5      /* C dtype = silu(acc + bias)   (timestep MLP, model.py:206-215) */
+
+typedef struct {
+    void* q;                  /* [b][h][s][hd]  or NULL when the columns hold no Q section */
+    void* k;                  /* [b][h][s][hd]  or NULL                                    */
+    void* vt;                 /* [b][h][hd][s]  (V transposed: s contiguous) or NULL       */
+    int32_t rows_per_batch;   /* row m -> b = m / rows_per_batch, s = m % rows_per_batch  */
+    int32_t n_heads, head_dim;
+    int64_t q_bs, q_hs, q_rs; /* element strides: batch, head, row                        */
+    int64_t k_bs, k_hs, k_rs;
+    int64_t vt_bs, vt_hs, vt_ds; /* batch, head, d-row (s contiguous)                     */
+} M5QkvScatter;               /* columns are laid out [present sections in q,k,v order] x (n_heads*head_dim) */
+
+int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+            void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
+            int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, void* stream);
+
+/* LayerNorm rows (fp32 in): y = (x-mean)*rsqrt(var+eps)*gamma+beta, out fp32 or dtype.
+ * n_affine > 1 applies several (gamma,beta) sets to the same normalised row (the 8 NAR
+ * heads, model.py:236-242,342).  D % 64 == 0, D <= 2048.  nn.LayerNorm on the path. */
+int m5_layernorm(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                 void* y, int64_t ldy, int M, int D, int n_affine, int64_t affine_stride, int64_t y_affine_stride,
+                 void* stream);
+
+/* RMSNorm rows (nn_future.py:301-312): y = dtype((x * rsqrt(mean(x^2)+eps)) * w). */
+int m5_rmsnorm(int out_dtype, const float* x, int64_t ldx, const float* w, float eps, void* y, int64_t ldy,
+               int M, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Flash attention over head-major Q/K and transposed V, head_dim 64, online softmax,
+ * never materialises scores.  F.scaled_dot_product_attention at nn_future.py:272 (AR
+ * prefill, causal) and inside nn.MultiheadAttention (model.py:61-67,179-203: key-padding
+ * masks).  O is row-major [b][s][h*64+d] (ready to be the next GEMM's A operand).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* q; int64_t q_bs, q_hs, q_rs;
+    const void* k; int64_t k_bs, k_hs, k_rs;
+    const void* vt; int64_t vt_bs, vt_hs, vt_ds;
+    void* o; int64_t o_bs, o_rs;
+    int32_t B, H, Sq, Sk;
+    const int32_t* key_len;     /* per-batch valid key count (device) or NULL = Sk          */
+    int32_t causal;             /* 1: key j visible to query i iff j <= i                    */
+    float scale;                /* 1/sqrt(head_dim)                                          */
+    const int32_t* kv_index;    /* optional device int: K base += (*kv_index) * kv_index_stride_k,   */
+    int64_t kv_index_stride_k;  /* V^T base += (*kv_index) * kv_index_stride_v (selects the          */
+    int64_t kv_index_stride_v;  /* pre-computed cross-attention memory of the current DDPM step)     */
+} M5AttnArgs;
+int m5_attention(int dtype, const M5AttnArgs* a, void* stream);
+
+/* out[r][:] = table[idx[r]][:] * 1 + alpha * pe[pos[r]][:] + add[add_idx[r]][:]
+ * (pe / add optional).  nn.Embedding + SinePositionalEmbedding (nn_future.py:78-83) +
+ * timestep-embedding add (model.py:329,337); also the AR prefill embedding (model.py:106,129). */
+int m5_gather_rows(float* out, int64_t ldo, int R, int D, const float* table, const int64_t* idx,
+                   const float* alpha, const float* pe, const int32_t* pos,
+                   const float* add, const int32_t* add_idx, void* stream);
+
+/* ChunkedEmbedding (model.py:147-159) + optional leading identity row + sine positional
+ * embedding + optional add row selected by a DEVICE index (the DDPM step):
+ * out[rep][r][:] = concat_q tables[q][codes[r-lead][q]] + alpha*pe[r] + add[*add_index]. */
+int m5_chunked_embed(float* out, int64_t ld_rep, int n_rep, int R, int D, int n_q, int n_codes,
+                     const float* tables, const int64_t* codes, const float* lead_row,
+                     const float* alpha, const float* pe, const float* add, const int32_t* add_index,
+                     void* stream);
+
+/* AR prefill: rotate q,k (interleaved-pair RoPE, nn_future.py:181-191) of a row-major
+ * [M][3D] qkv buffer at positions pos0..pos0+M-1; write Q head-major, K and V into the KV
+ * cache ([h][slot][hd], slot = pos % window, nn_future.py:249-252) and V^T scratch. */
+int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos0, const float* rope,
+                  void* q_out, void* kcache, void* vcache, int64_t cache_hs, int window,
+                  void* vt_out, int64_t vt_hs, int64_t vt_ds, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * AR decode step (one token, batch 1): weight-streaming GEMV with fused prologue/epilogue.
+ * Device-resident state lets one hipGraph replay serve every step.
+ * ------------------------------------------------------------------------------------ */
+#define M5_ST_POS 0        /* RoPE position of the current query (= prefix length)          */
+#define M5_ST_NGEN 1       /* tokens generated so far                                       */
+#define M5_ST_DONE 2       /* 1 after EOS or when max_len is reached: later steps no-op     */
+#define M5_ST_NTOK 3       /* total tokens stored (prompt + generated)                      */
+#define M5_ST_LAST 4       /* last sampled token id                                         */
+#define M5_ST_WORDS 8
+
+#define M5_PRO_RMS 0       /* xs = dtype((x*rsqrt(mean(x^2)+eps))*w)  (nn_future.py:307-312) */
+#define M5_PRO_DT 1        /* xs = x (dtype vector)                                         */
+#define M5_PRO_ATTN 2      /* xs = combine of split-KV attention partials                   */
+
+#define M5_GEPI_QKV_ROPE 0 /* rows q|k|v: RoPE q,k at state.pos, q -> qbuf, k,v -> cache slot */
+#define M5_GEPI_RESIDUAL 1 /* xres[n] += acc                                                */
+#define M5_GEPI_SWIGLU 2   /* rows interleaved (w1_i, w3_i): y[i] = silu(a)*b               */
+#define M5_GEPI_F32 3      /* y_f32[n] = acc  (logits)                                      */
+
+#define M5_ATTN_PART 66    /* floats per (head, split) partial: o[64], m, l                 */
+
+typedef struct {
+    const void* W; int64_t ldw; int32_t N, K;
+    const float* x_f32; const float* norm_w; float eps;   /* PRO_RMS                        */
+    const void* x_dt;                                      /* PRO_DT                         */
+    const float* part; int32_t nsplit, n_heads;            /* PRO_ATTN                       */
+    void* y_dt; float* y_f32; float* xres;
+    const float* rope; const int32_t* state;
+    void* kcache; void* vcache; void* qbuf;                /* this layer's cache [h][W][64]  */
+    int32_t w_alloc, window, dim;
+} M5GemvArgs;
+int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void* stream);
+
+typedef struct {
+    const void* qbuf; const void* kcache; const void* vcache;
+    float* part; const int32_t* state;
+    int32_t n_heads, w_alloc, window, nsplit;
+    float scale;
+} M5AttnDecodeArgs;
+/* nn_future.py:257-272 decode branch: q . K[:min(pos+1,W)] softmax . V, split over keys. */
+int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream);
+
+/* Sampler chain of ar_generate.py:74-115 + samplers.py:20-93 on device, then the
+ * multinomial draw argmax(p / q) with caller-supplied Exp(1) noise, EOS / max_len
+ * handling (ar_generate.py:62,121) and the next token's embedding load (model.py:106). */
+typedef struct {
+    const float* logits; int32_t V;
+    int32_t* state; int64_t* tokens; int32_t max_len;
+    float alpha_frequency, alpha_presence; int32_t penalty_window;
+    int32_t n_text; int32_t eos_idx;
+    int32_t n_est; const float* eos_table;      /* eos_table[n], n = 0..n_est, or NULL       */
+    float temperature; int32_t div_mode;         /* 0: z / T (CPU reference), 1: z * (1/T)    */
+    int32_t top_k; float top_p;
+    const float* noise; int64_t noise_stride;    /* Exp(1) draws [step][V]                    */
+    const float* embed; int32_t dim; float* xres;
+} M5SampleArgs;
+int m5_ar_sample(const M5SampleArgs* a, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * NAR reverse-diffusion step tail (diffuser.py:364-393 + :467-468): CFG mix, temperature,
+ * log_softmax, multinomial posterior, Gumbel-argmax with caller-supplied uniforms, known
+ * branch q_sample, inpaint merge and L0 override, for every (frame, codebook).
+ * ------------------------------------------------------------------------------------ */
+#define M5_NAR_CONSTS 8   /* per step: lca[t-1], l1mca[t-1]-lnK, la[t], l1ma[t]-lnK, lca[t], l1mca[t]-lnK, t, unused */
+typedef struct {
+    const float* logits_c; const float* logits_u;   /* [S-row_offset][n_q-1][ldk] (codebooks 1..)  */
+    int64_t ld_row, ld_q;
+    int32_t S, n_q, K, row_offset;
+    int64_t* x; const int64_t* x_known; const uint8_t* m;
+    const float* u1; const float* u2;               /* [S][n_q][K] uniforms                   */
+    const float* consts; const int32_t* step;       /* consts[*step][M5_NAR_CONSTS]            */
+    float guidance_w, temperature, log_eps;         /* log_eps = log(1e-7f)                    */
+    int32_t div_mode, q0_override_steps;
+} M5NarSampleArgs;
+int m5_nar_sample(const M5NarSampleArgs* a, void* stream);
+
+int m5_add_int(int32_t* p, int32_t delta, void* stream);
+
+/* hipGraph helpers (capture the launches issued between begin/end on `stream`). */
+int m5_graph_begin(void* stream);
+int m5_graph_end(void* stream, void** graph_exec);
+int m5_graph_launch(void* graph_exec, void* stream);
+int m5_graph_destroy(void* graph_exec);
+
+/* HIP-event timing on an arbitrary stream (bench roofline measurements). */
+int m5_event_create(void** ev);
+int m5_event_record(void* ev, void* stream);
+int m5_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+int m5_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARS5_HIP_H */

@@ -1,0 +1,496 @@
+// AR decode step, batch 1: HBM-bound weight streaming.
+//
+// One token = 5 launches per Mistral layer + head + sampler, all reading the position /
+// token state from DEVICE memory so a single captured hipGraph serves every step:
+//   K1 gemv<RMS, QKV_ROPE>   RMSNorm -> Wqkv stream -> RoPE(q,k) -> q buffer + KV-cache slot
+//   K2 attn_decode           q . K[0:n] softmax . V, split over keys, partial (o, m, l)
+//   K3 gemv<ATTN, RESIDUAL>  combine partials -> Wo stream -> x += .
+//   K4 gemv<RMS, SWIGLU>     RMSNorm -> interleaved (W1,W3) stream -> silu(a)*b
+//   K5 gemv<DT, RESIDUAL>    W2 stream -> x += .
+// GEMV: the activation vector lives in LDS as fp32 (<= 18 KB); every wave streams R weight
+// rows with 16-byte loads per lane (1 KiB per wave instruction, fully coalesced, no LDS
+// round trip for the streamed operand), fp32 accumulate, xor-shuffle reduction.
+#include "common.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- GEMV
+template <typename T, int PRO, int EPI, int R>
+__global__ __launch_bounds__(256) void gemv_kernel(M5GemvArgs a) {
+    using st = typename T::storage;
+    constexpr int EPL = T::EPL;
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (a.state && a.state[M5_ST_DONE]) return;
+    const int K = a.K;
+
+    // ---- prologue: activation vector -> LDS (fp32 values already rounded to dtype)
+    if constexpr (PRO == M5_PRO_RMS) {
+        float ss = 0.f;
+        for (int i = tid; i < K; i += 256) { const float v = a.x_f32[i]; ss += v * v; }
+        const float tot = block_sum<4>(ss, red);
+        const float rstd = rsqrtf(tot / (float)K + a.eps);
+        for (int i = tid; i < K; i += 256) {
+            const float n = a.x_f32[i] * rstd;
+            xs[i] = round_dt<T>(n * a.norm_w[i]);
+        }
+    } else if constexpr (PRO == M5_PRO_DT) {
+        const st* x = reinterpret_cast<const st*>(a.x_dt);
+        for (int i = tid; i < K; i += 256) xs[i] = T::to_f32(x[i]);
+    } else {   // M5_PRO_ATTN: merge the split-KV partials of every head
+        for (int i = tid; i < K; i += 256) {
+            const int h = i >> 6, d = i & 63;
+            const float* pp = a.part + (int64_t)h * a.nsplit * M5_ATTN_PART;
+            float mx = -INFINITY;
+            for (int s = 0; s < a.nsplit; ++s) mx = fmaxf(mx, pp[s * M5_ATTN_PART + 64]);
+            float o = 0.f, l = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) {
+                const float w = expf(pp[s * M5_ATTN_PART + 64] - mx);
+                o += w * pp[s * M5_ATTN_PART + d];
+                l += w * pp[s * M5_ATTN_PART + 65];
+            }
+            xs[i] = round_dt<T>(o / l);
+        }
+    }
+    __syncthreads();
+
+    const int row0 = (blockIdx.x * 4 + wave) * R;
+    if (row0 >= a.N) return;
+    const unsigned char* wrow[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        wrow[r] = (const unsigned char*)a.W + (int64_t)min(row0 + r, a.N - 1) * a.ldw * sizeof(st);
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+
+#pragma unroll 2
+    for (int k0 = lane * EPL; k0 < K; k0 += 64 * EPL) {
+        Vec16<T> wv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) wv[r].load(wrow[r] + (int64_t)k0 * sizeof(st));
+        float xv[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(xs + k0 + e);
+            xv[e] = t.x; xv[e + 1] = t.y; xv[e + 2] = t.z; xv[e + 3] = t.w;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float wf[EPL];
+            wv[r].to_float(wf);
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) acc[r] = fmaf(wf[e], xv[e], acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+
+    // ---- epilogue (lane r2 handles the pair / row r2)
+    if constexpr (EPI == M5_GEPI_RESIDUAL) {
+        if (lane < R && row0 + lane < a.N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (lane == r) v = acc[r];
+            a.xres[row0 + lane] += v;
+        }
+    } else if constexpr (EPI == M5_GEPI_F32) {
+        if (lane < R && row0 + lane < a.N) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (lane == r) v = acc[r];
+            a.y_f32[row0 + lane] = v;
+        }
+    } else if constexpr (EPI == M5_GEPI_SWIGLU) {
+        static_assert(R % 2 == 0, "pairs");
+        if (lane < R / 2 && row0 + 2 * lane + 1 < a.N) {
+            float va = 0.f, vb = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; r += 2) if (lane == r / 2) { va = acc[r]; vb = acc[r + 1]; }
+            const float x1 = round_dt<T>(va), x3 = round_dt<T>(vb);
+            const float sl = round_dt<T>(silu_f(x1));
+            reinterpret_cast<st*>(a.y_dt)[(row0 >> 1) + lane] = T::from_f32(sl * x3);
+        }
+    } else {   // M5_GEPI_QKV_ROPE
+        static_assert(R % 2 == 0, "pairs");
+        if (lane < R / 2 && row0 + 2 * lane + 1 < a.N) {
+            float va = 0.f, vb = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; r += 2) if (lane == r / 2) { va = acc[r]; vb = acc[r + 1]; }
+            const int n = row0 + 2 * lane;
+            const int D = a.dim;
+            const int sec = n / D, c = n - sec * D, h = c >> 6, d = c & 63;
+            const int pos = a.state[M5_ST_POS];
+            const float x0 = round_dt<T>(va), x1 = round_dt<T>(vb);
+            float o0 = x0, o1 = x1;
+            if (sec < 2) {
+                const float cs = a.rope[((int64_t)pos * 32 + (d >> 1)) * 2];
+                const float sn = a.rope[((int64_t)pos * 32 + (d >> 1)) * 2 + 1];
+                o0 = x0 * cs - x1 * sn;
+                o1 = x0 * sn + x1 * cs;
+            }
+            st* dst;
+            if (sec == 0) {
+                dst = reinterpret_cast<st*>(a.qbuf) + c;
+            } else {
+                const int slot = pos % a.window;
+                st* base = reinterpret_cast<st*>(sec == 1 ? a.kcache : a.vcache);
+                dst = base + ((int64_t)h * a.w_alloc + slot) * 64 + d;
+            }
+            dst[0] = T::from_f32(o0);
+            dst[1] = T::from_f32(o1);
+        }
+    }
+}
+
+template <typename T, int PRO, int EPI, int R>
+int launch_gemv(const M5GemvArgs& a, hipStream_t s) {
+    const int rows_per_block = 4 * R;
+    dim3 grid((a.N + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL((gemv_kernel<T, PRO, EPI, R>), grid, dim3(256), (size_t)a.K * sizeof(float), s, a);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+template <typename T>
+int dispatch_gemv(int pro, int epi, const M5GemvArgs& a, hipStream_t s) {
+    if (pro == M5_PRO_RMS && epi == M5_GEPI_QKV_ROPE) return launch_gemv<T, M5_PRO_RMS, M5_GEPI_QKV_ROPE, 4>(a, s);
+    if (pro == M5_PRO_ATTN && epi == M5_GEPI_RESIDUAL) return launch_gemv<T, M5_PRO_ATTN, M5_GEPI_RESIDUAL, 2>(a, s);
+    if (pro == M5_PRO_RMS && epi == M5_GEPI_SWIGLU) return launch_gemv<T, M5_PRO_RMS, M5_GEPI_SWIGLU, 4>(a, s);
+    if (pro == M5_PRO_DT && epi == M5_GEPI_RESIDUAL) return launch_gemv<T, M5_PRO_DT, M5_GEPI_RESIDUAL, 2>(a, s);
+    if (pro == M5_PRO_RMS && epi == M5_GEPI_F32) return launch_gemv<T, M5_PRO_RMS, M5_GEPI_F32, 4>(a, s);
+    if (pro == M5_PRO_DT && epi == M5_GEPI_F32) return launch_gemv<T, M5_PRO_DT, M5_GEPI_F32, 4>(a, s);
+    return M5_ERR_UNSUPPORTED;
+}
+
+// ------------------------------------------------------------------- decode attention
+// grid (H, nsplit); 4 waves; LPP lanes cover one cached position (16 B each), so a wave
+// instruction reads 64/LPP consecutive positions = 1 KiB contiguous of this head's K (or V).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
+    using st = typename T::storage;
+    constexpr int EPL = T::EPL;
+    constexpr int LPP = 64 / EPL;          // lanes per position: 8 (16-bit) or 16 (f32)
+    constexpr int PPW = 64 / LPP;          // positions per wave instruction
+    __shared__ float sm[4][LPP][EPL + 2];
+    if (a.state[M5_ST_DONE]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = blockIdx.x, split = blockIdx.y;
+    const int pos = a.state[M5_ST_POS];
+    const int n_valid = min(pos + 1, a.window);
+    int chunk = (n_valid + a.nsplit - 1) / a.nsplit;
+    chunk = (chunk + PPW * 4 - 1) / (PPW * 4) * (PPW * 4);
+    const int start = split * chunk, end = min(n_valid, start + chunk);
+    const int sub = lane % LPP, grp = lane / LPP;
+
+    float qv[EPL];
+    {
+        Vec16<T> q;
+        q.load(reinterpret_cast<const st*>(a.qbuf) + h * 64 + sub * EPL);
+        q.to_float(qv);
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) qv[e] *= a.scale;
+    }
+    const st* Kh = reinterpret_cast<const st*>(a.kcache) + (int64_t)h * a.w_alloc * 64;
+    const st* Vh = reinterpret_cast<const st*>(a.vcache) + (int64_t)h * a.w_alloc * 64;
+
+    float m = -INFINITY, l = 0.f, o[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.f;
+
+    for (int base = start + wave * PPW; base < end; base += 4 * PPW) {
+        const int p = base + grp;
+        const bool ok = p < end;
+        Vec16<T> kv, vv;
+        if (ok) {
+            kv.load(Kh + (int64_t)p * 64 + sub * EPL);
+            vv.load(Vh + (int64_t)p * 64 + sub * EPL);
+        } else {
+            kv.zero();
+            vv.zero();
+        }
+        float kf[EPL], vf[EPL];
+        kv.to_float(kf);
+        vv.to_float(vf);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) s = fmaf(qv[e], kf[e], s);
+#pragma unroll
+        for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off);
+        if (ok) {
+            const float mn = fmaxf(m, s);
+            const float al = expf(m - mn), pe = expf(s - mn);
+            l = l * al + pe;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) o[e] = o[e] * al + pe * vf[e];
+            m = mn;
+        }
+    }
+    // merge the PPW position groups of the wave
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        const float mn = fmaxf(m, m2);
+        const float w1 = (m == -INFINITY) ? 0.f : expf(m - mn);
+        const float w2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+        l = l * w1 + l2 * w2;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float o2 = __shfl_xor(o[e], off);
+            o[e] = o[e] * w1 + o2 * w2;
+        }
+        m = mn;
+    }
+    if (grp == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sm[wave][sub][e] = o[e];
+        sm[wave][sub][EPL] = m;
+        sm[wave][sub][EPL + 1] = l;
+    }
+    __syncthreads();
+    if (tid < LPP) {
+        float mm = -INFINITY;
+        for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm[w][tid][EPL]);
+        float ll = 0.f, oo[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) oo[e] = 0.f;
+        for (int w = 0; w < 4; ++w) {
+            const float mw = sm[w][tid][EPL];
+            const float wt = (mw == -INFINITY) ? 0.f : expf(mw - mm);
+            ll += wt * sm[w][tid][EPL + 1];
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) oo[e] += wt * sm[w][tid][e];
+        }
+        float* dst = a.part + ((int64_t)h * a.nsplit + split) * M5_ATTN_PART;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) dst[tid * EPL + e] = oo[e];
+        if (tid == 0) { dst[64] = mm; dst[65] = ll; }
+    }
+}
+
+// ----------------------------------------------------------------------------- sampler
+__device__ inline uint32_t desc_key(float f) {
+    // monotone map: larger float -> SMALLER key (so ascending key order = descending value)
+    uint32_t u = __float_as_uint(f);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending-order key
+    return ~u;
+}
+__device__ inline float key_to_float(uint32_t k) {
+    uint32_t u = ~k;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* sk = reinterpret_cast<unsigned long long*>(smem);            // V2 sort keys
+    float* fs = reinterpret_cast<float*>(smem + (size_t)V2 * 8);                     // V2 floats scratch
+    int* cnt = reinterpret_cast<int*>(fs);                                           // alias (used before fs)
+    __shared__ float red[16];
+    __shared__ int sh_i[4];
+    __shared__ float sh_f[2];
+    int32_t* st = a.state;
+    if (st[M5_ST_DONE]) return;
+    const int tid = threadIdx.x;
+    const int V = a.V;
+    const int n_gen = st[M5_ST_NGEN];
+    const int n_tok = st[M5_ST_NTOK];
+
+    // ---- 1. frequency / presence penalty over the last `window` generated ids (samplers.py:20-36)
+    const bool pen = n_gen > 1;
+    if (pen) {
+        for (int i = tid; i < V; i += 1024) cnt[i] = 0;
+        __syncthreads();
+        const int w = min(n_gen, a.penalty_window);
+        for (int j = tid; j < w; j += 1024) atomicAdd(&cnt[(int)a.tokens[n_tok - 1 - j]], 1);
+        __syncthreads();
+    }
+    // ---- 2-5. mask, EOS penalty, temperature; build sort keys
+    const float invT = 1.0f / a.temperature;
+    for (int i = tid; i < V2; i += 1024) {
+        unsigned long long key = 0xffffffffffffffffull;
+        if (i < V) {
+            float z = a.logits[i];
+            if (pen) {
+                const int c = cnt[i];
+                z = (z - (float)c * a.alpha_frequency) - (c > 0 ? 1.0f : 0.0f) * a.alpha_presence;
+            }
+            if (i < a.n_text - 1) z = -INFINITY;
+            if (a.eos_table && i == a.eos_idx && n_gen <= a.n_est) z = z - a.eos_table[n_gen];
+            z = a.div_mode ? z * invT : z / a.temperature;
+            key = ((unsigned long long)desc_key(z) << 32) | (unsigned)i;
+        }
+        sk[i] = key;
+    }
+    __syncthreads();
+    // ---- bitonic sort ascending on (desc_key, index): value descending, index ascending
+    for (int k = 2; k <= V2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (V2 >> 1); t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long x = sk[i], y = sk[l];
+                const bool asc = (i & k) == 0;
+                if ((x > y) == asc) { sk[i] = y; sk[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 6. top-k: threshold = k-th largest, keep everything >= it (samplers.py:70-74)
+    if (tid == 0) {
+        int nk = V;
+        sh_i[0] = nk;
+    }
+    __syncthreads();
+    if (a.top_k > 0) {
+        const int k = min(max(a.top_k, 1), V);
+        const uint32_t thr = (uint32_t)(sk[k - 1] >> 32);
+        for (int j = tid; j < V; j += 1024) {
+            const uint32_t hj = (uint32_t)(sk[j] >> 32);
+            const uint32_t hn = (j + 1 < V2) ? (uint32_t)(sk[j + 1] >> 32) : 0xffffffffu;
+            if (hj == thr && hn != thr) sh_i[0] = j + 1;     // last entry equal to the threshold
+        }
+        __syncthreads();
+    }
+    int n_keep = sh_i[0];
+    const float v0 = key_to_float((uint32_t)(sk[0] >> 32));
+    // ---- 7. top-p over the sorted list (samplers.py:76-91)
+    if (a.top_p < 1.0f) {
+        float part = 0.f;
+        for (int j = tid; j < V2; j += 1024) {
+            float e = 0.f;
+            if (j < n_keep) e = expf(key_to_float((uint32_t)(sk[j] >> 32)) - v0);
+            fs[j] = e;
+            part += e;
+        }
+        const float S = block_sum<16>(part, red);
+        // inclusive scan of p_j = e_j / S : contiguous chunk per thread + scan of thread totals
+        const int per = V2 >> 10 ? V2 >> 10 : 1;
+        const int j0 = tid * per;
+        float loc = 0.f;
+        if (j0 < V2)
+            for (int q = 0; q < per; ++q) { const float pj = fs[j0 + q] / S; loc += pj; fs[j0 + q] = loc; }
+        // scan thread totals: wave inclusive scan + wave offsets
+        float inc = loc;
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float n = __shfl_up(inc, off);
+            if (lane >= off) inc += n;
+        }
+        __syncthreads();
+        if (lane == 63) red[wv] = inc;
+        __syncthreads();
+        float woff = 0.f;
+        for (int w = 0; w < wv; ++w) woff += red[w];
+        const float excl = woff + inc - loc;
+        if (j0 < V2)
+            for (int q = 0; q < per; ++q) fs[j0 + q] += excl;
+        __syncthreads();
+        // keep j iff j == 0 or cum[j-1] <= top_p ; cum is non-decreasing -> count
+        int mycnt = 0;
+        for (int j = tid; j < n_keep; j += 1024) mycnt += (j == 0 || !(fs[j - 1] > a.top_p)) ? 1 : 0;
+        const int nk2 = (int)(block_sum<16>((float)mycnt, red) + 0.5f);
+        n_keep = min(n_keep, nk2);
+    }
+    __syncthreads();
+    // ---- 9. log_softmax over the kept set, p / q, argmax (ar_generate.py:102,115)
+    float part = 0.f;
+    for (int j = tid; j < n_keep; j += 1024) part += expf(key_to_float((uint32_t)(sk[j] >> 32)) - v0);
+    const float S2 = block_sum<16>(part, red);
+    const float logS = logf(S2);
+    const float* q = a.noise + (int64_t)n_gen * a.noise_stride;
+    float best = -1.f;
+    int besti = 0x7fffffff;
+    for (int j = tid; j < n_keep; j += 1024) {
+        const float v = key_to_float((uint32_t)(sk[j] >> 32));
+        const int id = (int)(sk[j] & 0xffffffffu);
+        const float pz = expf((v - v0) - logS);
+        const float sc = pz / q[id];
+        if (sc > best || (sc == best && id < besti)) { best = sc; besti = id; }
+    }
+    // block argmax (value desc, index asc)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(besti, off);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    }
+    __shared__ float wb[16];
+    __shared__ int wi[16];
+    if ((tid & 63) == 0) { wb[tid >> 6] = best; wi[tid >> 6] = besti; }
+    __syncthreads();
+    if (tid == 0) {
+        float b = wb[0];
+        int bi = wi[0];
+        for (int w = 1; w < 16; ++w)
+            if (wb[w] > b || (wb[w] == b && wi[w] < bi)) { b = wb[w]; bi = wi[w]; }
+        sh_i[1] = bi;
+    }
+    __syncthreads();
+    const int tok = sh_i[1];
+    // ---- 10. EOS / append / max_len (ar_generate.py:62,121-157) and next-step embedding
+    if (tok == a.eos_idx) {
+        if (tid == 0) { st[M5_ST_DONE] = 1; st[M5_ST_LAST] = tok; }
+        return;
+    }
+    for (int i = tid; i < a.dim; i += 1024) a.xres[i] = a.embed[(int64_t)tok * a.dim + i];
+    if (tid == 0) {
+        a.tokens[n_tok] = tok;
+        st[M5_ST_NTOK] = n_tok + 1;
+        st[M5_ST_NGEN] = n_gen + 1;
+        st[M5_ST_POS] = st[M5_ST_POS] + 1;
+        st[M5_ST_LAST] = tok;
+        if (n_tok + 1 >= a.max_len) st[M5_ST_DONE] = 1;
+    }
+}
+
+}  // namespace
+
+extern "C" int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void* stream) {
+    if (!a || !a->W || a->N <= 0 || a->K <= 0) return M5_ERR_ARG;
+    const int es = (dtype == M5_F32) ? 4 : 2, al = 16 / es;
+    if (a->K % al || a->ldw % al || ((uintptr_t)a->W & 15)) return M5_ERR_ARG;
+    if ((size_t)a->K * 4 > 64 * 1024) return M5_ERR_UNSUPPORTED;
+    if (pro == M5_PRO_ATTN && (a->K != a->n_heads * 64 || !a->part || a->nsplit <= 0)) return M5_ERR_ARG;
+    if (epi == M5_GEPI_QKV_ROPE && (!a->rope || !a->state || !a->kcache || !a->vcache || !a->qbuf || a->N != 3 * a->dim || a->dim % 64)) return M5_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case M5_F32: return dispatch_gemv<F32T>(pro, epi, *a, s);
+        case M5_F16: return dispatch_gemv<F16T>(pro, epi, *a, s);
+        case M5_BF16: return dispatch_gemv<BF16T>(pro, epi, *a, s);
+        default: return M5_ERR_ARG;
+    }
+}
+
+extern "C" int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream) {
+    if (!a || !a->qbuf || !a->kcache || !a->vcache || !a->part || !a->state || a->n_heads <= 0 || a->nsplit <= 0) return M5_ERR_ARG;
+    dim3 grid(a->n_heads, a->nsplit);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case M5_F32: hipLaunchKernelGGL(attn_decode_kernel<F32T>, grid, dim3(256), 0, s, *a); break;
+        case M5_F16: hipLaunchKernelGGL(attn_decode_kernel<F16T>, grid, dim3(256), 0, s, *a); break;
+        case M5_BF16: hipLaunchKernelGGL(attn_decode_kernel<BF16T>, grid, dim3(256), 0, s, *a); break;
+        default: return M5_ERR_ARG;
+    }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_ar_sample(const M5SampleArgs* a, void* stream) {
+    if (!a || !a->logits || !a->state || !a->tokens || !a->noise || !a->embed || !a->xres || a->V <= 1) return M5_ERR_ARG;
+    if (a->V > 8192) return M5_ERR_UNSUPPORTED;
+    if (!(a->temperature > 0.f)) return M5_ERR_ARG;
+    int V2 = 1024;
+    while (V2 < a->V) V2 <<= 1;
+    const size_t sm = (size_t)V2 * 12;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), sm, (hipStream_t)stream, *a, V2);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}

@@ -1,0 +1,98 @@
+// Shared device helpers for the MARS5 gfx950 kernels (wave64, CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mars5_hip.h"
+
+#define M5_WAVE 64
+
+// ---- element types ----------------------------------------------------------------
+// F32T: exact fp32 operands (parity mode; MFMA 16x16x4 f32).  F16T / BF16T: 16-bit
+// operands, fp32 accumulate (MFMA 16x16x32).
+struct F32T {
+    using storage = float;
+    static constexpr int id = M5_F32;
+    static constexpr int EPL = 4;  // elements per 16-byte load
+    __device__ static inline float to_f32(storage v) { return v; }
+    __device__ static inline storage from_f32(float f) { return f; }
+};
+struct F16T {
+    using storage = _Float16;
+    static constexpr int id = M5_F16;
+    static constexpr int EPL = 8;
+    __device__ static inline float to_f32(storage v) { return (float)v; }
+    __device__ static inline storage from_f32(float f) { return (_Float16)f; }
+};
+struct BF16T {
+    using storage = uint16_t;
+    static constexpr int id = M5_BF16;
+    static constexpr int EPL = 8;
+    __device__ static inline float to_f32(storage v) { return __uint_as_float(((uint32_t)v) << 16); }
+    __device__ static inline storage from_f32(float f) {
+        uint32_t u = __float_as_uint(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)0x7fc0;  // NaN
+        u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
+        return (uint16_t)(u >> 16);
+    }
+};
+
+template <typename T>
+__device__ inline float round_dt(float f) { return T::to_f32(T::from_f32(f)); }
+
+// 16-byte vector of T::EPL elements, converted to fp32
+template <typename T>
+struct Vec16 {
+    uint4 raw;
+    __device__ inline void load(const void* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ inline void zero() { raw = make_uint4(0, 0, 0, 0); }
+    __device__ inline void to_float(float* out) const {
+        const typename T::storage* e = reinterpret_cast<const typename T::storage*>(&raw);
+#pragma unroll
+        for (int i = 0; i < T::EPL; ++i) out[i] = T::to_f32(e[i]);
+    }
+};
+
+// ---- wave / block reductions ---------------------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+// block reductions over blockDim.x = NW*64 threads; `red` is NW floats of LDS scratch.
+template <int NW>
+__device__ inline float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += red[i];
+    return t;
+}
+template <int NW>
+__device__ inline float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+    return t;
+}
+
+__device__ inline float silu_f(float a) { return a / (1.0f + expf(-a)); }
+
+#define M5_CHECK_LAUNCH()                                   \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return M5_ERR_LAUNCH;        \
+    } while (0)

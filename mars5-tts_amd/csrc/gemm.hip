@@ -1,0 +1,259 @@
+// MFMA GEMM  C[M,N] = A[M,K] . W[N,K]^T  for gfx950 (wave64).
+//
+// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA 16x16
+// tiles, 64 fp32 accumulators per lane).  Both operands are K-contiguous, so a 128-byte
+// K-slab of every row (BK = 64 halves or 32 floats = one full cache line) is staged
+// through LDS in rows padded to 144 B (conflict-light ds_read_b128 fragment reads), with
+// the next slab prefetched into registers while the current one feeds the matrix cores
+// (global -> reg -> LDS split staging).  f16/bf16: v_mfma_f32_16x16x32;  f32 (parity
+// mode): v_mfma_f32_16x16x4_f32, bitwise an fmaf chain.
+// Fused epilogues: bias, in-place residual, SwiGLU on interleaved rows, head-major
+// Q/K/V^T scatter (feeds attention.hip with no transpose pass), bias+SiLU.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
+typedef __attribute__((ext_vector_type(4))) float f4_t;
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 144;   // LDS row stride in bytes: 128 data + 16 pad
+
+struct GemmParams {
+    const unsigned char* A; const unsigned char* W; const float* bias; unsigned char* C;
+    int64_t lda, ldw, ldc;           // elements
+    int64_t sA, sW, sC, sBias;       // batch strides, elements
+    int M, N, K;
+    M5QkvScatter sc;
+    int sec_kind[3];                 // column section -> 0 q, 1 k, 2 v
+};
+
+template <typename T>
+__device__ inline f4_t mfma16(const uint4& a, const uint4& b, f4_t c);
+template <>
+__device__ inline f4_t mfma16<F16T>(const uint4& a, const uint4& b, f4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8_t*>(&a),
+                                                  *reinterpret_cast<const h8_t*>(&b), c, 0, 0, 0);
+}
+template <>
+__device__ inline f4_t mfma16<BF16T>(const uint4& a, const uint4& b, f4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const b8_t*>(&a),
+                                                   *reinterpret_cast<const b8_t*>(&b), c, 0, 0, 0);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    using st = typename T::storage;
+    constexpr int ES = sizeof(st);
+    constexpr int BK = 128 / ES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * ROWB];
+    unsigned char* As = lds;
+    unsigned char* Ws = lds + 128 * ROWB;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int64_t bz = blockIdx.z;
+    const unsigned char* A = p.A + bz * p.sA * ES;
+    const unsigned char* W = p.W + bz * p.sW * ES;
+
+    // staging assignment: 8 threads cover one 128-byte row slab, 32 rows per pass, 4 passes
+    const int chunk = tid & 7, r0 = tid >> 3;
+    const unsigned char* ga[4];
+    const unsigned char* gw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int ra = min(m0 + r0 + 32 * j, p.M - 1);
+        int rw = min(n0 + r0 + 32 * j, p.N - 1);
+        ga[j] = A + (int64_t)ra * p.lda * ES + chunk * 16;
+        gw[j] = W + (int64_t)rw * p.ldw * ES + chunk * 16;
+    }
+    const int lds_st = r0 * ROWB + chunk * 16;
+
+    f4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rw[4];
+    const int nk = p.K / BK;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ra[j] = *reinterpret_cast<const uint4*>(ga[j]);
+        rw[j] = *reinterpret_cast<const uint4*>(gw[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint4*>(As + lds_st + 32 * j * ROWB) = ra[j];
+        *reinterpret_cast<uint4*>(Ws + lds_st + 32 * j * ROWB) = rw[j];
+    }
+    __syncthreads();
+
+    const unsigned char* a_base = As + (wm * 64 + l15) * ROWB;
+    const unsigned char* w_base = Ws + (wn * 64 + l15) * ROWB;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const int64_t koff = (int64_t)(kt + 1) * 128;   // bytes
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ra[j] = *reinterpret_cast<const uint4*>(ga[j] + koff);
+                rw[j] = *reinterpret_cast<const uint4*>(gw[j] + koff);
+            }
+        }
+        if constexpr (ES == 2) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 af[4], bf[4];
+                const int ko = (ks * 32 + lg * 8) * 2;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * ROWB + ko);
+                    bf[i] = *reinterpret_cast<const uint4*>(w_base + i * 16 * ROWB + ko);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(af[i], bf[j], acc[i][j]);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float af[4], bf[4];
+                const int ko = (kk * 4 + lg) * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    af[i] = *reinterpret_cast<const float*>(a_base + i * 16 * ROWB + ko);
+                    bf[i] = *reinterpret_cast<const float*>(w_base + i * 16 * ROWB + ko);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<uint4*>(As + lds_st + 32 * j * ROWB) = ra[j];
+                *reinterpret_cast<uint4*>(Ws + lds_st + 32 * j * ROWB) = rw[j];
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: acc[i][j][r] is C[row = m0+wm*64+i*16+lg*4+r][col = n0+wn*64+j*16+l15]
+    const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
+    unsigned char* Cb = p.C + bz * p.sC * ((EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL) ? 4 : ES);
+    const int Dm = p.sc.n_heads * p.sc.head_dim;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + l15;
+        const bool cok = col < p.N;
+        const float bv = (bias && cok) ? bias[col] : 0.f;
+        // QKV scatter: per-column decomposition hoisted out of the row loops
+        int kind = 0, hh = 0, dd = 0;
+        if constexpr (EPI == M5_EPI_QKV) {
+            const int cc = cok ? col : 0;
+            kind = p.sec_kind[cc / Dm];
+            const int c = cc % Dm;
+            hh = c / p.sc.head_dim;
+            dd = c % p.sc.head_dim;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
+                const bool ok = cok && row < p.M;
+                const float v = acc[i][j][r] + bv;
+                if constexpr (EPI == M5_EPI_F32) {
+                    if (ok) reinterpret_cast<float*>(Cb)[(int64_t)row * p.ldc + col] = v;
+                } else if constexpr (EPI == M5_EPI_RESIDUAL) {
+                    if (ok) reinterpret_cast<float*>(Cb)[(int64_t)row * p.ldc + col] += v;
+                } else if constexpr (EPI == M5_EPI_DT) {
+                    if (ok) reinterpret_cast<st*>(Cb)[(int64_t)row * p.ldc + col] = T::from_f32(v);
+                } else if constexpr (EPI == M5_EPI_SILU_DT) {
+                    if (ok) reinterpret_cast<st*>(Cb)[(int64_t)row * p.ldc + col] = T::from_f32(silu_f(v));
+                } else if constexpr (EPI == M5_EPI_SWIGLU) {
+                    const float other = __shfl_xor(v, 1);     // odd column (V_i) of the pair
+                    if (ok && !(col & 1)) {
+                        const float a = round_dt<T>(v), b = round_dt<T>(other);
+                        const float s = round_dt<T>(silu_f(a));
+                        reinterpret_cast<st*>(Cb)[(int64_t)row * p.ldc + (col >> 1)] = T::from_f32(s * b);
+                    }
+                } else if constexpr (EPI == M5_EPI_QKV) {
+                    if (ok) {
+                        const int b = row / p.sc.rows_per_batch, s = row - b * p.sc.rows_per_batch;
+                        const st o = T::from_f32(v);
+                        if (kind == 0)
+                            reinterpret_cast<st*>(p.sc.q)[b * p.sc.q_bs + hh * p.sc.q_hs + (int64_t)s * p.sc.q_rs + dd] = o;
+                        else if (kind == 1)
+                            reinterpret_cast<st*>(p.sc.k)[b * p.sc.k_bs + hh * p.sc.k_hs + (int64_t)s * p.sc.k_rs + dd] = o;
+                        else
+                            reinterpret_cast<st*>(p.sc.vt)[b * p.sc.vt_bs + hh * p.sc.vt_hs + (int64_t)dd * p.sc.vt_ds + s] = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_gemm(int epi, const GemmParams& p, dim3 grid, hipStream_t s) {
+    switch (epi) {
+        case M5_EPI_F32: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_F32>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_DT>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_RESIDUAL>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_SWIGLU: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SWIGLU>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_QKV>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_SILU_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SILU_DT>), grid, dim3(256), 0, s, p); break;
+        default: return M5_ERR_ARG;
+    }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+}  // namespace
+
+extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                       void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
+                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, void* stream) {
+    if (!A || !W || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return M5_ERR_ARG;
+    if (K % 64 != 0) return M5_ERR_UNSUPPORTED;
+    const int es = (dtype == M5_F32) ? 4 : 2;
+    const int al = 16 / es;
+    if (lda % al || ldw % al || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return M5_ERR_ARG;
+    if ((sA % al) || (sW % al)) return M5_ERR_ARG;
+    if (epi != M5_EPI_QKV && !C) return M5_ERR_ARG;
+    if (epi == M5_EPI_SWIGLU && (N & 1)) return M5_ERR_ARG;
+    GemmParams p{};
+    p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
+    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = sA; p.sW = sW; p.sC = sC; p.sBias = sBias;
+    p.M = M; p.N = N; p.K = K;
+    if (epi == M5_EPI_QKV) {
+        if (!sc || sc->head_dim <= 0 || sc->n_heads <= 0 || sc->rows_per_batch <= 0) return M5_ERR_ARG;
+        p.sc = *sc;
+        int n = 0;
+        if (sc->q) p.sec_kind[n++] = 0;
+        if (sc->k) p.sec_kind[n++] = 1;
+        if (sc->vt) p.sec_kind[n++] = 2;
+        if (n == 0 || N != n * sc->n_heads * sc->head_dim) return M5_ERR_ARG;
+    } else {
+        p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case M5_F32: return launch_gemm<F32T>(epi, p, grid, s);
+        case M5_F16: return launch_gemm<F16T>(epi, p, grid, s);
+        case M5_BF16: return launch_gemm<BF16T>(epi, p, grid, s);
+        default: return M5_ERR_ARG;
+    }
+}

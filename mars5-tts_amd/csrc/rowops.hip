@@ -1,0 +1,223 @@
+// Row-wise HBM-bound kernels: LayerNorm / RMSNorm (fp32 rows -> GEMM operand dtype),
+// embedding gathers with fused sine positional + timestep add, and the AR-prefill
+// RoPE + KV-cache write.  One wave per row, lanes stride the row (coalesced 256 B per
+// wave instruction); row statistics by wave shuffles only.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXI = 32;   // D <= 64*32 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                                        float eps, typename T::storage* y, int64_t ldy, int M, int D,
+                                                        int n_affine, int64_t affine_stride, int64_t y_affine_stride) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int ni = D >> 6;
+    const float* xr = x + (int64_t)row * ldx;
+    float v[MAXI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+        if (i < ni) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+        if (i < ni) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    for (int a = 0; a < n_affine; ++a) {
+        const float* g = gamma + a * affine_stride;
+        const float* bt = beta + a * affine_stride;
+        typename T::storage* yr = y + a * y_affine_stride + (int64_t)row * ldy;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+            if (i < ni) {
+                const int c = lane + 64 * i;
+                yr[c] = T::from_f32((v[i] - mean) * rstd * g[c] + bt[c]);
+            }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ldx, const float* w, float eps,
+                                                      typename T::storage* y, int64_t ldy, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int ni = D >> 6;
+    const float* xr = x + (int64_t)row * ldx;
+    float v[MAXI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+        if (i < ni) { v[i] = xr[lane + 64 * i]; s += v[i] * v[i]; }
+    const float rstd = rsqrtf(wave_sum(s) / (float)D + eps);
+    typename T::storage* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+        if (i < ni) {
+            const int c = lane + 64 * i;
+            const float n = v[i] * rstd;          // (x * rsqrt(...)).type_as(x)
+            yr[c] = T::from_f32(n * w[c]);        // ... * weight, then cast to the GEMM dtype
+        }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(float* out, int64_t ldo, int R, int D, const float* table,
+                                                          const int64_t* idx, const float* alpha, const float* pe,
+                                                          const int32_t* pos, const float* add, const int32_t* add_idx) {
+    const int r = blockIdx.x;
+    const float* src = table + idx[r] * (int64_t)D;
+    const float al = alpha ? alpha[0] : 0.f;
+    const float* per = pe ? pe + (int64_t)(pos ? pos[r] : r) * D : nullptr;
+    const float* ar = add ? add + (int64_t)(add_idx ? add_idx[r] : 0) * D : nullptr;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float v = src[c];
+        if (per) v = v * 1.0f + al * per[c];
+        if (ar) v = v + ar[c];
+        out[(int64_t)r * ldo + c] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void chunked_embed_kernel(float* out, int64_t ld_rep, int n_rep, int R, int D, int n_q,
+                                                            int n_codes, const float* tables, const int64_t* codes,
+                                                            const float* lead_row, const float* alpha, const float* pe,
+                                                            const float* add, const int32_t* add_index) {
+    const int r = blockIdx.x;
+    const int lead = lead_row ? 1 : 0;
+    const int dq = D / n_q;
+    const float al = alpha ? alpha[0] : 0.f;
+    const float* ar = add ? add + (int64_t)(add_index ? add_index[0] : 0) * D : nullptr;
+    for (int c = threadIdx.x; c < D; c += 256) {
+        float v;
+        if (r < lead) {
+            v = lead_row[c];
+        } else {
+            const int q = c / dq;
+            const int64_t code = codes[(int64_t)(r - lead) * n_q + q];
+            v = tables[((int64_t)q * n_codes + code) * dq + (c - q * dq)];
+        }
+        if (pe) v = v * 1.0f + al * pe[(int64_t)r * D + c];
+        if (ar) v = v + ar[c];
+        for (int rep = 0; rep < n_rep; ++rep) out[rep * ld_rep + (int64_t)r * D + c] = v;
+    }
+}
+
+// one block per row m; thread t handles the (even, odd) pair t of each of q / k, and v.
+template <typename T>
+__global__ __launch_bounds__(256) void rope_cache_kernel(const typename T::storage* qkv, int M, int H, int pos0,
+                                                         const float* rope, typename T::storage* q_out,
+                                                         typename T::storage* kc, typename T::storage* vc,
+                                                         int64_t cache_hs, int window, typename T::storage* vt,
+                                                         int64_t vt_hs, int64_t vt_ds) {
+    const int m = blockIdx.x;
+    const int D = H * 64;
+    const int pos = pos0 + m;
+    const int slot = pos % window;
+    const typename T::storage* row = qkv + (int64_t)m * 3 * D;
+    for (int pr = threadIdx.x; pr < D / 2; pr += 256) {
+        const int c = 2 * pr, h = c >> 6, d = c & 63;
+        const float cs = rope[((int64_t)pos * 32 + (d >> 1)) * 2], sn = rope[((int64_t)pos * 32 + (d >> 1)) * 2 + 1];
+        {
+            const float a = T::to_f32(row[c]), b = T::to_f32(row[c + 1]);
+            typename T::storage* dst = q_out + ((int64_t)h * M + m) * 64 + d;
+            dst[0] = T::from_f32(a * cs - b * sn);
+            dst[1] = T::from_f32(a * sn + b * cs);
+        }
+        {
+            const float a = T::to_f32(row[D + c]), b = T::to_f32(row[D + c + 1]);
+            typename T::storage* dst = kc + h * cache_hs + (int64_t)slot * 64 + d;
+            dst[0] = T::from_f32(a * cs - b * sn);
+            dst[1] = T::from_f32(a * sn + b * cs);
+        }
+        {
+            const typename T::storage a = row[2 * D + c], b = row[2 * D + c + 1];
+            typename T::storage* dst = vc + h * cache_hs + (int64_t)slot * 64 + d;
+            dst[0] = a;
+            dst[1] = b;
+            vt[h * vt_hs + (int64_t)d * vt_ds + m] = a;
+            vt[h * vt_hs + (int64_t)(d + 1) * vt_ds + m] = b;
+        }
+    }
+}
+
+__global__ void add_int_kernel(int32_t* p, int32_t delta) { *p += delta; }
+
+}  // namespace
+
+extern "C" int m5_layernorm(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                            void* y, int64_t ldy, int M, int D, int n_affine, int64_t affine_stride,
+                            int64_t y_affine_stride, void* stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || D <= 0 || n_affine <= 0) return M5_ERR_ARG;
+    if (D % 64 || D > 64 * MAXI) return M5_ERR_UNSUPPORTED;
+    dim3 grid((M + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    switch (out_dtype) {
+        case M5_F32: hipLaunchKernelGGL(layernorm_kernel<F32T>, grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (float*)y, ldy, M, D, n_affine, affine_stride, y_affine_stride); break;
+        case M5_F16: hipLaunchKernelGGL(layernorm_kernel<F16T>, grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (_Float16*)y, ldy, M, D, n_affine, affine_stride, y_affine_stride); break;
+        case M5_BF16: hipLaunchKernelGGL(layernorm_kernel<BF16T>, grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (uint16_t*)y, ldy, M, D, n_affine, affine_stride, y_affine_stride); break;
+        default: return M5_ERR_ARG;
+    }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_rmsnorm(int out_dtype, const float* x, int64_t ldx, const float* w, float eps, void* y, int64_t ldy,
+                          int M, int D, void* stream) {
+    if (!x || !w || !y || M <= 0 || D <= 0) return M5_ERR_ARG;
+    if (D % 64 || D > 64 * MAXI) return M5_ERR_UNSUPPORTED;
+    dim3 grid((M + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    switch (out_dtype) {
+        case M5_F32: hipLaunchKernelGGL(rmsnorm_kernel<F32T>, grid, dim3(256), 0, s, x, ldx, w, eps, (float*)y, ldy, M, D); break;
+        case M5_F16: hipLaunchKernelGGL(rmsnorm_kernel<F16T>, grid, dim3(256), 0, s, x, ldx, w, eps, (_Float16*)y, ldy, M, D); break;
+        case M5_BF16: hipLaunchKernelGGL(rmsnorm_kernel<BF16T>, grid, dim3(256), 0, s, x, ldx, w, eps, (uint16_t*)y, ldy, M, D); break;
+        default: return M5_ERR_ARG;
+    }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_gather_rows(float* out, int64_t ldo, int R, int D, const float* table, const int64_t* idx,
+                              const float* alpha, const float* pe, const int32_t* pos, const float* add,
+                              const int32_t* add_idx, void* stream) {
+    if (!out || !table || !idx || R <= 0 || D <= 0) return M5_ERR_ARG;
+    if (pe && !alpha) return M5_ERR_ARG;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, out, ldo, R, D, table, idx, alpha, pe, pos, add, add_idx);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_chunked_embed(float* out, int64_t ld_rep, int n_rep, int R, int D, int n_q, int n_codes,
+                                const float* tables, const int64_t* codes, const float* lead_row, const float* alpha,
+                                const float* pe, const float* add, const int32_t* add_index, void* stream) {
+    if (!out || !tables || R <= 0 || D <= 0 || n_q <= 0 || D % n_q || n_rep <= 0) return M5_ERR_ARG;
+    if (!codes && !(lead_row && R == 1)) return M5_ERR_ARG;
+    if (pe && !alpha) return M5_ERR_ARG;
+    hipLaunchKernelGGL(chunked_embed_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, out, ld_rep, n_rep, R, D, n_q,
+                       n_codes, tables, codes, lead_row, alpha, pe, add, add_index);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos0, const float* rope, void* q_out,
+                             void* kcache, void* vcache, int64_t cache_hs, int window, void* vt_out, int64_t vt_hs,
+                             int64_t vt_ds, void* stream) {
+    if (!qkv || !rope || !q_out || !kcache || !vcache || !vt_out || M <= 0 || n_heads <= 0 || window <= 0) return M5_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    switch (dtype) {
+        case M5_F32: hipLaunchKernelGGL(rope_cache_kernel<F32T>, dim3(M), dim3(256), 0, s, (const float*)qkv, M, n_heads, pos0, rope, (float*)q_out, (float*)kcache, (float*)vcache, cache_hs, window, (float*)vt_out, vt_hs, vt_ds); break;
+        case M5_F16: hipLaunchKernelGGL(rope_cache_kernel<F16T>, dim3(M), dim3(256), 0, s, (const _Float16*)qkv, M, n_heads, pos0, rope, (_Float16*)q_out, (_Float16*)kcache, (_Float16*)vcache, cache_hs, window, (_Float16*)vt_out, vt_hs, vt_ds); break;
+        case M5_BF16: hipLaunchKernelGGL(rope_cache_kernel<BF16T>, dim3(M), dim3(256), 0, s, (const uint16_t*)qkv, M, n_heads, pos0, rope, (uint16_t*)q_out, (uint16_t*)kcache, (uint16_t*)vcache, cache_hs, window, (uint16_t*)vt_out, vt_hs, vt_ds); break;
+        default: return M5_ERR_ARG;
+    }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_add_int(int32_t* p, int32_t delta, void* stream) {
+    if (!p) return M5_ERR_ARG;
+    hipLaunchKernelGGL(add_int_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p, delta);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
