@@ -1,0 +1,138 @@
+"""ctypes binding of ``libmars5_hip.so`` (C ABI declared in ``include/mars5_hip.h``).
+
+The product path has NO CPU fallback: if the library is missing this module raises at
+import (build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``mars5-tts_amd/csrc/build.sh``).  Every call returns an int status; ``check`` turns a
+non-zero status into a Python exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmars5_hip.so")
+
+M5_OK, M5_ERR_ARG, M5_ERR_LAUNCH, M5_ERR_UNSUPPORTED = 0, -1, -2, -3
+F32, F16, BF16 = 0, 1, 2
+EPI_F32, EPI_DT, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV, EPI_SILU_DT = 0, 1, 2, 3, 4, 5
+ST_POS, ST_NGEN, ST_DONE, ST_NTOK, ST_LAST, ST_WORDS = 0, 1, 2, 3, 4, 8
+PRO_RMS, PRO_DT, PRO_ATTN = 0, 1, 2
+GEPI_QKV_ROPE, GEPI_RESIDUAL, GEPI_SWIGLU, GEPI_F32 = 0, 1, 2, 3
+ATTN_PART = 66
+NAR_CONSTS = 8
+
+_ERR = {M5_ERR_ARG: "invalid argument", M5_ERR_LAUNCH: "HIP launch / runtime error",
+        M5_ERR_UNSUPPORTED: "unsupported shape or option"}
+
+
+class Mars5HipError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str = "") -> None:
+    if status != M5_OK:
+        raise Mars5HipError(f"libmars5_hip {what}: status {status} ({_ERR.get(status, 'unknown')})")
+
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class QkvScatter(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("rows_per_batch", i32), ("n_heads", i32), ("head_dim", i32),
+                ("q_bs", i64), ("q_hs", i64), ("q_rs", i64), ("k_bs", i64), ("k_hs", i64), ("k_rs", i64),
+                ("vt_bs", i64), ("vt_hs", i64), ("vt_ds", i64)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("q_bs", i64), ("q_hs", i64), ("q_rs", i64),
+                ("k", vp), ("k_bs", i64), ("k_hs", i64), ("k_rs", i64),
+                ("vt", vp), ("vt_bs", i64), ("vt_hs", i64), ("vt_ds", i64),
+                ("o", vp), ("o_bs", i64), ("o_rs", i64),
+                ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32),
+                ("key_len", vp), ("causal", i32), ("scale", f32),
+                ("kv_index", vp), ("kv_index_stride_k", i64), ("kv_index_stride_v", i64)]
+
+
+class GemvArgs(C.Structure):
+    _fields_ = [("W", vp), ("ldw", i64), ("N", i32), ("K", i32),
+                ("x_f32", vp), ("norm_w", vp), ("eps", f32),
+                ("x_dt", vp),
+                ("part", vp), ("nsplit", i32), ("n_heads", i32),
+                ("y_dt", vp), ("y_f32", vp), ("xres", vp),
+                ("rope", vp), ("state", vp),
+                ("kcache", vp), ("vcache", vp), ("qbuf", vp),
+                ("w_alloc", i32), ("window", i32), ("dim", i32)]
+
+
+class AttnDecodeArgs(C.Structure):
+    _fields_ = [("qbuf", vp), ("kcache", vp), ("vcache", vp), ("part", vp), ("state", vp),
+                ("n_heads", i32), ("w_alloc", i32), ("window", i32), ("nsplit", i32), ("scale", f32)]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("logits", vp), ("V", i32),
+                ("state", vp), ("tokens", vp), ("max_len", i32),
+                ("alpha_frequency", f32), ("alpha_presence", f32), ("penalty_window", i32),
+                ("n_text", i32), ("eos_idx", i32),
+                ("n_est", i32), ("eos_table", vp),
+                ("temperature", f32), ("div_mode", i32),
+                ("top_k", i32), ("top_p", f32),
+                ("noise", vp), ("noise_stride", i64),
+                ("embed", vp), ("dim", i32), ("xres", vp)]
+
+
+class NarSampleArgs(C.Structure):
+    _fields_ = [("logits_c", vp), ("logits_u", vp), ("ld_row", i64), ("ld_q", i64),
+                ("S", i32), ("n_q", i32), ("K", i32), ("row_offset", i32),
+                ("x", vp), ("x_known", vp), ("m", vp),
+                ("u1", vp), ("u2", vp),
+                ("consts", vp), ("step", vp),
+                ("guidance_w", f32), ("temperature", f32), ("log_eps", f32),
+                ("div_mode", i32), ("q0_override_steps", i32)]
+
+
+# name -> (restype, argtypes); also the list the symbol-export test checks against the header
+PROTOTYPES = {
+    "m5_version": (C.c_int, []),
+    "m5_build_info": (C.c_char_p, []),
+    "m5_gemm": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int,
+                          C.POINTER(QkvScatter), C.c_int, i64, i64, i64, i64, vp]),
+    "m5_layernorm": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
+    "m5_rmsnorm": (C.c_int, [C.c_int, vp, i64, vp, f32, vp, i64, C.c_int, C.c_int, vp]),
+    "m5_attention": (C.c_int, [C.c_int, C.POINTER(AttnArgs), vp]),
+    "m5_gather_rows": (C.c_int, [vp, i64, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "m5_chunked_embed": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "m5_rope_cache": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, C.c_int, vp, i64, i64, vp]),
+    "m5_ar_gemv": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(GemvArgs), vp]),
+    "m5_ar_attn_decode": (C.c_int, [C.c_int, C.POINTER(AttnDecodeArgs), vp]),
+    "m5_ar_sample": (C.c_int, [C.POINTER(SampleArgs), vp]),
+    "m5_nar_sample": (C.c_int, [C.POINTER(NarSampleArgs), vp]),
+    "m5_add_int": (C.c_int, [vp, i32, vp]),
+    "m5_graph_begin": (C.c_int, [vp]),
+    "m5_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
+    "m5_graph_launch": (C.c_int, [vp, vp]),
+    "m5_graph_destroy": (C.c_int, [vp]),
+    "m5_event_create": (C.c_int, [C.POINTER(vp)]),
+    "m5_event_record": (C.c_int, [vp, vp]),
+    "m5_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
+    "m5_event_destroy": (C.c_int, [vp]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the MARS5 HIP library is not built. There is no CPU fallback. "
+            "Build it with mars5-tts_amd/csrc/build.sh (needs hipcc, cross-compiles gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    if lib.m5_version() != 1:
+        raise ImportError(f"libmars5_hip ABI version {lib.m5_version()} != 1")
+    return lib
+
+
+lib = _load()

@@ -1,0 +1,247 @@
+"""AR stage on MI355X: CodecLM prefill + hipGraph-captured decode loop.
+
+Replaces the device work of reference ``mars5/ar_generate.py:62-157`` +
+``mars5/model.py:95-141`` + ``mars5/nn_future.py:235-398`` + ``mars5/samplers.py``.
+
+What is different from the reference by design (all exact):
+  * the speaker vector is computed once per utterance, not once per token;
+  * only the new token is embedded per step;
+  * sampling, EOS/max_len handling and the next-token embedding happen on device, with the
+    position / counters in device memory, so ONE captured graph (5 launches per layer +
+    head + sampler) is replayed per token with no host sync; the host polls the done flag
+    every ``poll`` steps;
+  * KV cache is [layer][head][slot][64] (head-major: a head's keys are contiguous, so decode
+    attention streams them with fully coalesced 1 KiB wave loads), slot = pos % 3000.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .blocks import SpeakerEncoder, interleave_rows, round_up
+from .synth import ARShape
+from .tables import eos_penalty_table, rope_table
+
+NSPLIT = 8
+
+
+@dataclass
+class ARSamplingConfig:
+    """Arguments of reference ``ar_generate`` (ar_generate.py:15-22) that steer sampling."""
+    temperature: float = 1.0
+    topk: Optional[int] = None
+    top_p: float = 1.0
+    alpha_frequency: float = 0.0
+    alpha_presence: float = 0.0
+    penalty_window: int = 100
+    typical_p: float = 1.0
+    eos_penalty_factor: float = 1.0
+    eos_penalty_decay: float = 0.0
+    n_phones_gen: Optional[int] = None
+    div_mode: int = 0            # 0: logits / T (reference CPU kernel), 1: logits * (1/T) (reference GPU kernel)
+
+
+class ARModel:
+    """Packed CodecLM weights on one GPU.  dtype: GEMM operand type ('f32' | 'f16' | 'bf16')."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], shape: ARShape, dtype: torch.dtype, device, max_pos: int = 8192):
+        self.shape, self.dt, self.dev = shape, dtype, torch.device(device)
+        dev, dt = self.dev, dtype
+        Lr, D, F, V = shape.n_layers, shape.dim, shape.hidden_dim, shape.n_vocab
+        assert shape.head_dim == 64 and D % 64 == 0 and F % 8 == 0
+
+        def stack(fmt, f=lambda t: t):
+            return torch.stack([f(sd[fmt.format(l)].float()) for l in range(Lr)]).to(device=dev, dtype=dt).contiguous()
+
+        self.wqkv = torch.stack([torch.cat([sd[f"ar.layers.{l}.attention.wq.weight"], sd[f"ar.layers.{l}.attention.wk.weight"],
+                                            sd[f"ar.layers.{l}.attention.wv.weight"]]).float() for l in range(Lr)]
+                                ).to(device=dev, dtype=dt).contiguous()                      # (L, 3D, D)
+        self.wo = stack("ar.layers.{}.attention.wo.weight")                                   # (L, D, D)
+        self.w13 = torch.stack([interleave_rows(sd[f"ar.layers.{l}.feed_forward.w1.weight"].float(),
+                                                sd[f"ar.layers.{l}.feed_forward.w3.weight"].float()) for l in range(Lr)]
+                               ).to(device=dev, dtype=dt).contiguous()                        # (L, 2F, D)
+        self.w2 = stack("ar.layers.{}.feed_forward.w2.weight")                                # (L, D, F)
+        self.attn_norm = torch.stack([sd[f"ar.layers.{l}.attention_norm.weight"].float() for l in range(Lr)]).to(dev).contiguous()
+        self.ffn_norm = torch.stack([sd[f"ar.layers.{l}.ffn_norm.weight"].float() for l in range(Lr)]).to(dev).contiguous()
+        self.final_norm = sd["ar.norm.weight"].float().to(dev).contiguous()
+        self.w_out = sd["ar.output.weight"].to(device=dev, dtype=dt).contiguous()             # (V, D)
+        self.embed = sd["embed.weight"].float().to(dev).contiguous()                          # (V, D) fp32
+        self.rope = rope_table(64, max_pos).to(dev)
+        self.max_pos = max_pos
+        self.spk = SpeakerEncoder(sd, "ref_chunked_emb", "pos_embedding.alpha", shape.n_spk_layers, dt, dev)
+
+    def weight_bytes_per_token(self) -> int:
+        """Algorithmic HBM bytes one decode step must stream."""
+        es = torch.tensor([], dtype=self.dt).element_size()
+        n = self.wqkv.numel() + self.wo.numel() + self.w13.numel() + self.w2.numel() + self.w_out.numel()
+        return n * es + (self.attn_norm.numel() + self.ffn_norm.numel() + self.final_norm.numel()) * 4
+
+
+class ARSession:
+    """One utterance: prefill + decode.  Owns KV cache and step buffers (caller = this host code)."""
+
+    def __init__(self, model: ARModel, max_len: int, stream: Optional[torch.cuda.Stream] = None):
+        self.m = model
+        s, dev, dt = model.shape, model.dev, model.dt
+        self.max_len = max_len
+        self.window = s.sliding_window
+        self.w_alloc = min(s.sliding_window, max_len + 1)
+        assert max_len + 1 <= model.max_pos
+        H, D, F, V = s.nhead, s.dim, s.hidden_dim, s.n_vocab
+        self.kc = torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
+        self.vc = torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
+        self.xdec = torch.zeros(D, dtype=torch.float32, device=dev)
+        self.qbuf = torch.zeros(D, dtype=dt, device=dev)
+        self.hbuf = torch.zeros(F, dtype=dt, device=dev)
+        self.part = torch.zeros(H, NSPLIT, L.ATTN_PART, dtype=torch.float32, device=dev)
+        self.logits = torch.zeros(V, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(L.ST_WORDS, dtype=torch.int32, device=dev)
+        self.tokens = torch.zeros(max_len + 1, dtype=torch.int64, device=dev)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.graph: Optional[ops.Graph] = None
+        self._sample_args: Optional[L.SampleArgs] = None
+        self._keep: List[torch.Tensor] = []
+
+    # ------------------------------------------------------------------ prefill
+    def prefill(self, prompt: torch.Tensor, ref_codes: torch.Tensor) -> None:
+        """prompt (P,) int64 global ids; ref_codes (Lc, 8) int64.  Runs the speaker encoder and
+        the 26-layer stack over [spk_vec, tok_0..tok_{P-1}] (positions 0..P), filling the cache
+        and leaving the last row's residual in ``xdec``."""
+        m, s = self.m, self.m.shape
+        dev, dt = m.dev, m.dt
+        st = self.stream.cuda_stream
+        P = int(prompt.shape[0])
+        M = P + 1
+        assert M <= self.window, "prefill longer than the sliding window is not supported"
+        H, D, F = s.nhead, s.dim, s.hidden_dim
+        with torch.cuda.stream(self.stream):
+            prompt = prompt.to(dev)
+            ref_codes = ref_codes.to(dev).contiguous()
+            spk = m.spk(ref_codes, stream=st)                                    # (D,) fp32
+            table = torch.cat([m.embed, spk[None]], dim=0)                       # plumbing: one extra row
+            idx = torch.cat([torch.tensor([s.n_vocab], device=dev, dtype=torch.int64), prompt])
+            x = torch.empty(M, D, dtype=torch.float32, device=dev)
+            ops.gather_rows(x, table, idx, stream=st)
+            Mp = round_up(M, 64)
+            xn = torch.empty(M, D, dtype=dt, device=dev)
+            qkv = torch.empty(M, 3 * D, dtype=dt, device=dev)
+            q = torch.empty(H, M, 64, dtype=dt, device=dev)
+            vt = torch.zeros(H, 64, Mp, dtype=dt, device=dev)
+            att = torch.empty(M, D, dtype=dt, device=dev)
+            hb = torch.empty(M, F, dtype=dt, device=dev)
+            for l in range(s.n_layers):
+                ops.rmsnorm(x, m.attn_norm[l], s.norm_eps, xn, stream=st)
+                ops.gemm(xn, m.wqkv[l], qkv, L.EPI_DT, stream=st)
+                ops.rope_cache(qkv, H, 0, m.rope, q, self.kc[l], self.vc[l], self.w_alloc * 64, self.window, vt, 64 * Mp, Mp, stream=st)
+                a = L.AttnArgs(q=q.data_ptr(), q_bs=0, q_hs=M * 64, q_rs=64,
+                               k=self.kc[l].data_ptr(), k_bs=0, k_hs=self.w_alloc * 64, k_rs=64,
+                               vt=vt.data_ptr(), vt_bs=0, vt_hs=64 * Mp, vt_ds=Mp,
+                               o=att.data_ptr(), o_bs=0, o_rs=D, B=1, H=H, Sq=M, Sk=M, key_len=None, causal=1,
+                               scale=64 ** -0.5, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0)
+                ops.attention(dt, a, stream=st)
+                ops.gemm(att, m.wo[l], x, L.EPI_RESIDUAL, stream=st)
+                ops.rmsnorm(x, m.ffn_norm[l], s.norm_eps, xn, stream=st)
+                ops.gemm(xn, m.w13[l], hb, L.EPI_SWIGLU, stream=st)
+                ops.gemm(hb, m.w2[l], x, L.EPI_RESIDUAL, stream=st)
+            self.xdec.copy_(x[M - 1])
+            self.tokens[:P].copy_(prompt)
+            self.state.copy_(torch.tensor([P, 0, 0, P, -1, 0, 0, 0], dtype=torch.int32), non_blocking=False)
+            self._keep = [table, x]
+        self.P = P
+
+    # ------------------------------------------------------------------ decode
+    def _gemv_args(self, **kw) -> L.GemvArgs:
+        a = L.GemvArgs()
+        for k, v in kw.items():
+            setattr(a, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+        return a
+
+    def enqueue_head_and_sample(self, st: int) -> None:
+        m, s = self.m, self.m.shape
+        a = self._gemv_args(W=m.w_out, ldw=s.dim, N=s.n_vocab, K=s.dim, x_f32=self.xdec, norm_w=m.final_norm, eps=s.norm_eps,
+                            y_f32=self.logits, state=self.state)
+        ops.ar_gemv(m.dt, L.PRO_RMS, L.GEPI_F32, a, stream=st)
+        ops.ar_sample(self._sample_args, stream=st)
+
+    def enqueue_layers(self, st: int) -> None:
+        m, s = self.m, self.m.shape
+        D, F, H = s.dim, s.hidden_dim, s.nhead
+        for l in range(s.n_layers):
+            a = self._gemv_args(W=m.wqkv[l], ldw=D, N=3 * D, K=D, x_f32=self.xdec, norm_w=m.attn_norm[l], eps=s.norm_eps,
+                                rope=m.rope, state=self.state, kcache=self.kc[l], vcache=self.vc[l], qbuf=self.qbuf,
+                                w_alloc=self.w_alloc, window=self.window, dim=D)
+            ops.ar_gemv(m.dt, L.PRO_RMS, L.GEPI_QKV_ROPE, a, stream=st)
+            d = L.AttnDecodeArgs(qbuf=self.qbuf.data_ptr(), kcache=self.kc[l].data_ptr(), vcache=self.vc[l].data_ptr(),
+                                 part=self.part.data_ptr(), state=self.state.data_ptr(), n_heads=H, w_alloc=self.w_alloc,
+                                 window=self.window, nsplit=NSPLIT, scale=64 ** -0.5)
+            ops.ar_attn_decode(m.dt, d, stream=st)
+            a = self._gemv_args(W=m.wo[l], ldw=D, N=D, K=D, part=self.part, nsplit=NSPLIT, n_heads=H, xres=self.xdec, state=self.state)
+            ops.ar_gemv(m.dt, L.PRO_ATTN, L.GEPI_RESIDUAL, a, stream=st)
+            a = self._gemv_args(W=m.w13[l], ldw=D, N=2 * F, K=D, x_f32=self.xdec, norm_w=m.ffn_norm[l], eps=s.norm_eps,
+                                y_dt=self.hbuf, state=self.state)
+            ops.ar_gemv(m.dt, L.PRO_RMS, L.GEPI_SWIGLU, a, stream=st)
+            a = self._gemv_args(W=m.w2[l], ldw=F, N=D, K=F, x_dt=self.hbuf, xres=self.xdec, state=self.state)
+            ops.ar_gemv(m.dt, L.PRO_DT, L.GEPI_RESIDUAL, a, stream=st)
+
+    def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: torch.Tensor) -> None:
+        """noise: (n_steps, V) fp32 device tensor of Exp(1) draws (one row per sampler call)."""
+        m, s = self.m, self.m.shape
+        if not cfg.typical_p > 0.999:
+            raise NotImplementedError("typical_p <= 0.999 (samplers.py:96-122) is not on the device path yet; "
+                                      "the reference default 1.0 is a no-op")
+        eos_tab = None
+        n_est = 0
+        if cfg.n_phones_gen is not None:
+            n_est = int(cfg.n_phones_gen)
+            eos_tab = eos_penalty_table(n_est, cfg.eos_penalty_decay, cfg.eos_penalty_factor).to(m.dev)
+        self._eos_tab, self._noise = eos_tab, noise
+        assert noise.dtype == torch.float32 and noise.shape[1] == s.n_vocab and noise.is_contiguous()
+        a = L.SampleArgs(logits=self.logits.data_ptr(), V=s.n_vocab, state=self.state.data_ptr(), tokens=self.tokens.data_ptr(),
+                         max_len=self.max_len, alpha_frequency=cfg.alpha_frequency, alpha_presence=cfg.alpha_presence,
+                         penalty_window=cfg.penalty_window, n_text=n_text, eos_idx=eos_idx, n_est=n_est,
+                         eos_table=eos_tab.data_ptr() if eos_tab is not None else None, temperature=cfg.temperature,
+                         div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, noise=noise.data_ptr(),
+                         noise_stride=s.n_vocab, embed=m.embed.data_ptr(), dim=s.dim, xres=self.xdec.data_ptr())
+        self._sample_args = a
+        self.n_noise = noise.shape[0]
+
+    def capture(self) -> None:
+        """Capture one decode step (layers + head + sampler) as a hipGraph."""
+        st = self.stream.cuda_stream
+        self.stream.synchronize()
+        ops.Graph.begin(st)
+        self.enqueue_layers(st)
+        self.enqueue_head_and_sample(st)
+        self.graph = ops.Graph().end(st)
+
+    def decode(self, use_graph: bool = True, poll: int = 32) -> torch.Tensor:
+        """Run sampler for the prefill logits, then decode steps until EOS / max_len.
+        Returns the token sequence (prompt + generated) like ``ar_generate`` (EOS not appended)."""
+        st = self.stream.cuda_stream
+        if self.P >= self.max_len:
+            return self.tokens[: self.P].clone()
+        self.enqueue_head_and_sample(st)                       # token P from the prefill's last row
+        budget = min(self.max_len - self.P - 1, self.n_noise - 1)
+        if use_graph and self.graph is None and budget > 0:
+            self.capture()
+        done = 0
+        while done < budget:
+            n = min(poll, budget - done)
+            for _ in range(n):
+                if use_graph:
+                    self.graph.launch(st)
+                else:
+                    self.enqueue_layers(st)
+                    self.enqueue_head_and_sample(st)
+            done += n
+            with torch.cuda.stream(self.stream):
+                flag = self.state.cpu()                        # syncs this stream only
+            if int(flag[L.ST_DONE]):
+                break
+        self.stream.synchronize()
+        n_tok = int(self.state[L.ST_NTOK].item())
+        return self.tokens[:n_tok].clone()

@@ -1,0 +1,192 @@
+"""Pre-LN transformer encoder / decoder layers of the reference (``nn.TransformerEncoderLayer``
+/ ``nn.TransformerDecoderLayer`` with ``linear1 = Identity`` and ``activation = FNNSwiGLU``,
+reference model.py:61-67,179-203) as launch sequences over libmars5_hip kernels.
+
+Host code only sequences kernels and owns buffers; weight repacking (dtype cast, W/V row
+interleave for the fused SwiGLU epilogue) happens once at load.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+LAYERNORM_EPS = 4e-5        # reference model.py:13
+
+
+def interleave_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """rows (a_0, b_0, a_1, b_1, ...): lets one GEMM produce silu(a_i x) * (b_i x) in its epilogue."""
+    return torch.stack([a, b], dim=1).reshape(a.shape[0] * 2, a.shape[1]).contiguous()
+
+
+@dataclass
+class EncLayerW:
+    in_w: torch.Tensor; in_b: torch.Tensor
+    out_w: torch.Tensor; out_b: torch.Tensor
+    act_w: torch.Tensor                      # (2*FF, D) interleaved (W_i, V_i)
+    l2_w: torch.Tensor; l2_b: torch.Tensor
+    n1_w: torch.Tensor; n1_b: torch.Tensor
+    n2_w: torch.Tensor; n2_b: torch.Tensor
+    # decoder only
+    ca_q_w: Optional[torch.Tensor] = None; ca_q_b: Optional[torch.Tensor] = None
+    ca_kv_w: Optional[torch.Tensor] = None; ca_kv_b: Optional[torch.Tensor] = None
+    ca_out_w: Optional[torch.Tensor] = None; ca_out_b: Optional[torch.Tensor] = None
+    n3_w: Optional[torch.Tensor] = None; n3_b: Optional[torch.Tensor] = None
+
+
+def pack_layer(sd: Dict[str, torch.Tensor], p: str, dt: torch.dtype, dev, cross: bool = False) -> EncLayerW:
+    def W(name):
+        return sd[name].to(device=dev, dtype=dt).contiguous()
+
+    def Fv(name):
+        return sd[name].to(device=dev, dtype=torch.float32).contiguous()
+
+    act = interleave_rows(sd[f"{p}.activation.W.weight"].float(), sd[f"{p}.activation.V.weight"].float())
+    lw = EncLayerW(
+        in_w=W(f"{p}.self_attn.in_proj_weight"), in_b=Fv(f"{p}.self_attn.in_proj_bias"),
+        out_w=W(f"{p}.self_attn.out_proj.weight"), out_b=Fv(f"{p}.self_attn.out_proj.bias"),
+        act_w=act.to(device=dev, dtype=dt).contiguous(),
+        l2_w=W(f"{p}.linear2.weight"), l2_b=Fv(f"{p}.linear2.bias"),
+        n1_w=Fv(f"{p}.norm1.weight"), n1_b=Fv(f"{p}.norm1.bias"),
+        n2_w=Fv(f"{p}.norm2.weight"), n2_b=Fv(f"{p}.norm2.bias"))
+    if cross:
+        D = lw.out_w.shape[0]
+        cw, cb = sd[f"{p}.multihead_attn.in_proj_weight"], sd[f"{p}.multihead_attn.in_proj_bias"]
+        lw.ca_q_w = cw[:D].to(device=dev, dtype=dt).contiguous()
+        lw.ca_q_b = cb[:D].to(device=dev, dtype=torch.float32).contiguous()
+        lw.ca_kv_w = cw[D:].to(device=dev, dtype=dt).contiguous()
+        lw.ca_kv_b = cb[D:].to(device=dev, dtype=torch.float32).contiguous()
+        lw.ca_out_w = W(f"{p}.multihead_attn.out_proj.weight")
+        lw.ca_out_b = Fv(f"{p}.multihead_attn.out_proj.bias")
+        lw.n3_w, lw.n3_b = Fv(f"{p}.norm3.weight"), Fv(f"{p}.norm3.bias")
+    return lw
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class SeqWorkspace:
+    """Buffers for running encoder/decoder layers over B sequences of S rows (dim D, H heads
+    of 64).  V^T rows are padded to whole 64-key tiles and zero-filled once."""
+
+    def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev):
+        self.B, self.S, self.D, self.FF, self.dt = B, S, D, FF, dt
+        self.H = D // 64
+        self.Sp = round_up(S, 64)
+        M = B * S
+        self.M = M
+        self.xn = torch.empty(M, D, dtype=dt, device=dev)
+        self.q = torch.empty(B, self.H, S, 64, dtype=dt, device=dev)
+        self.k = torch.empty(B, self.H, S, 64, dtype=dt, device=dev)
+        self.vt = torch.zeros(B, self.H, 64, self.Sp, dtype=dt, device=dev)
+        self.att = torch.empty(M, D, dtype=dt, device=dev)
+        self.hff = torch.empty(M, FF, dtype=dt, device=dev)
+
+    def scatter(self, q=True, k=True, v=True) -> L.QkvScatter:
+        H, S, Sp = self.H, self.S, self.Sp
+        return L.QkvScatter(q=self.q.data_ptr() if q else None, k=self.k.data_ptr() if k else None,
+                            vt=self.vt.data_ptr() if v else None, rows_per_batch=S, n_heads=H, head_dim=64,
+                            q_bs=H * S * 64, q_hs=S * 64, q_rs=64, k_bs=H * S * 64, k_hs=S * 64, k_rs=64,
+                            vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp)
+
+    def self_attn_args(self, key_len: Optional[torch.Tensor], causal: bool = False) -> L.AttnArgs:
+        H, S, Sp, D = self.H, self.S, self.Sp, self.D
+        return L.AttnArgs(q=self.q.data_ptr(), q_bs=H * S * 64, q_hs=S * 64, q_rs=64,
+                          k=self.k.data_ptr(), k_bs=H * S * 64, k_hs=S * 64, k_rs=64,
+                          vt=self.vt.data_ptr(), vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp,
+                          o=self.att.data_ptr(), o_bs=S * D, o_rs=D, B=self.B, H=H, Sq=S, Sk=S,
+                          key_len=key_len.data_ptr() if key_len is not None else None, causal=1 if causal else 0,
+                          scale=64 ** -0.5, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0)
+
+
+def self_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, key_len: Optional[torch.Tensor], stream=None) -> None:
+    """x = x + out_proj(SDPA(in_proj(LN1(x))))   (x fp32 [B*S, D], updated in place)."""
+    ops.layernorm(x, lw.n1_w, lw.n1_b, LAYERNORM_EPS, ws.xn, stream=stream)
+    ops.gemm(ws.xn, lw.in_w, None, L.EPI_QKV, bias=lw.in_b, scatter=ws.scatter(), stream=stream)
+    ops.attention(ws.dt, ws.self_attn_args(key_len), stream=stream)
+    ops.gemm(ws.att, lw.out_w, x, L.EPI_RESIDUAL, bias=lw.out_b, stream=stream)
+
+
+def ff_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, norm_w: torch.Tensor, norm_b: torch.Tensor, stream=None) -> None:
+    """x = x + linear2(silu(W LN(x)) * (V LN(x)))."""
+    ops.layernorm(x, norm_w, norm_b, LAYERNORM_EPS, ws.xn, stream=stream)
+    ops.gemm(ws.xn, lw.act_w, ws.hff, L.EPI_SWIGLU, stream=stream)
+    ops.gemm(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, bias=lw.l2_b, stream=stream)
+
+
+def encoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, key_len: Optional[torch.Tensor], stream=None) -> None:
+    self_attn_block(x, lw, ws, key_len, stream)
+    ff_block(x, lw, ws, lw.n2_w, lw.n2_b, stream)
+
+
+@dataclass
+class CrossMemory:
+    """Pre-projected cross-attention memory of one decoder layer for every reverse step:
+    k (T*Bm, H, Le, 64), vt (T*Bm, H, 64, Lep)."""
+    k: torch.Tensor
+    vt: torch.Tensor
+    Le: int
+    Lep: int
+    Bm: int          # memory batch entries per step (2 = cond, uncond)
+
+
+def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mem: CrossMemory, step_ptr: torch.Tensor, stream=None) -> None:
+    """x = x + out_proj(SDPA(q_proj(LN2(x)), memory K/V of step *step_ptr))."""
+    H, S, D = ws.H, ws.S, ws.D
+    ops.layernorm(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, stream=stream)
+    ops.gemm(ws.xn, lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=ws.scatter(True, False, False), stream=stream)
+    a = L.AttnArgs(q=ws.q.data_ptr(), q_bs=H * S * 64, q_hs=S * 64, q_rs=64,
+                   k=mem.k.data_ptr(), k_bs=H * mem.Le * 64, k_hs=mem.Le * 64, k_rs=64,
+                   vt=mem.vt.data_ptr(), vt_bs=H * 64 * mem.Lep, vt_hs=64 * mem.Lep, vt_ds=mem.Lep,
+                   o=ws.att.data_ptr(), o_bs=S * D, o_rs=D, B=ws.B, H=H, Sq=S, Sk=mem.Le, key_len=None, causal=0,
+                   scale=64 ** -0.5, kv_index=step_ptr.data_ptr(),
+                   kv_index_stride_k=mem.Bm * H * mem.Le * 64, kv_index_stride_v=mem.Bm * H * 64 * mem.Lep)
+    ops.attention(ws.dt, a, stream=stream)
+    ops.gemm(ws.att, lw.ca_out_w, x, L.EPI_RESIDUAL, bias=lw.ca_out_b, stream=stream)
+
+
+def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mem: CrossMemory, step_ptr: torch.Tensor, stream=None) -> None:
+    self_attn_block(x, lw, ws, None, stream)
+    cross_attn_block(x, lw, ws, mem, step_ptr, stream)
+    ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream)
+
+
+class SpeakerEncoder:
+    """The reference's speaker-reference encoder (CodecLM: model.py:109-127, ResidualTransformer:
+    model.py:298-310): [identity row, chunked-embedding(codes)] + sine positions -> pre-LN
+    encoder layers -> final LayerNorm -> row 0."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], emb_prefix: str, alpha_name: str, n_layers: int, dt: torch.dtype, dev,
+                 max_frames: int = 4000):
+        self.dt, self.dev = dt, dev
+        self.layers = [pack_layer(sd, f"spk_encoder.layers.{l}", dt, dev) for l in range(n_layers)]
+        self.norm_w = sd["spk_encoder.norm.weight"].to(dev, torch.float32).contiguous()
+        self.norm_b = sd["spk_encoder.norm.bias"].to(dev, torch.float32).contiguous()
+        self.tables = torch.stack([sd[f"{emb_prefix}.embs.{q}.weight"].float() for q in range(8)]).to(dev).contiguous()
+        self.identity = sd["spk_identity_emb.weight"].to(dev, torch.float32).contiguous()
+        self.alpha = sd[alpha_name].to(dev, torch.float32).contiguous()
+        self.D = self.identity.shape[1]
+        self.FF = self.layers[0].l2_w.shape[1]
+        from .tables import sine_pe
+        self.pe = sine_pe(max_frames + 1, self.D).to(dev)
+
+    def __call__(self, codes: Optional[torch.Tensor], stream=None) -> torch.Tensor:
+        """codes (Lc, 8) int64 device, or None for the unconditional vector (all-pad codes,
+        length 0: only position 0 is attended, so the sequence collapses to the identity
+        row -- a per-model constant).  Returns (D,) fp32."""
+        R = 1 if codes is None else 1 + codes.shape[0]
+        assert R <= self.pe.shape[0]
+        x = torch.empty(1, R, self.D, dtype=torch.float32, device=self.dev)
+        ops.chunked_embed(x, self.tables, codes, self.identity, self.alpha, self.pe, stream=stream)
+        x = x[0]
+        ws = SeqWorkspace(1, R, self.D, self.FF, self.dt, self.dev)
+        for lw in self.layers:
+            encoder_layer(x, lw, ws, None, stream)
+        out = torch.empty(1, self.D, dtype=torch.float32, device=self.dev)
+        ops.layernorm(x, self.norm_w, self.norm_b, LAYERNORM_EPS, out, M=1, stream=stream)
+        return out[0]

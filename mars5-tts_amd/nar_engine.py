@@ -1,0 +1,238 @@
+"""NAR stage on MI355X: multinomial-DDPM refinement of the 7 remaining Encodec codebooks.
+
+Replaces the device work of reference ``mars5/diffuser.py:345-472`` +
+``mars5/model.py:264-343`` (``ResidualTransformer.forward``).
+
+MI355X-first restructuring (all exact re-orderings of the reference computation):
+  * everything that does not depend on x_t is hoisted out of the 200-step loop and batched
+    over ALL reverse steps at once: the two speaker vectors (t-independent; the
+    unconditional one is a model constant), both timestep MLPs, the whole 8-layer text
+    encoder for (step, cond/uncond) pairs, and the cross-attention K / V^T projections of all
+    16 decoder layers (~1 GB bf16 per utterance, resident in HBM; 288 GB makes this free).
+    The loop body is then only the 16-layer decoder + heads;
+  * cond / uncond (classifier-free guidance) run as one batch of 2;
+  * codebook 0 and the prompt frames are never sampled from the model (m = 1 there), so the
+    heads skip them;
+  * one step = one captured hipGraph (chunked embedding -> 16 decoder layers -> LayerNorms ->
+    7-head batched GEMM) + torch RNG draws + the fused posterior/sample kernel.  The step
+    index lives in device memory so the same graph serves all steps.
+RNG: the uniforms come from ``torch.rand`` in the reference's order and shapes
+((1,S,8,K) twice per step, once at t = 0) so a seeded run consumes the generator exactly
+like the reference on the same device.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .blocks import (LAYERNORM_EPS, CrossMemory, SeqWorkspace, SpeakerEncoder, decoder_layer, encoder_layer,
+                     pack_layer, round_up)
+from .synth import NARShape
+from .tables import log_eps, nar_step_consts, reverse_schedule, sine_pe, timestep_inputs
+
+
+class NARModel:
+    def __init__(self, sd: Dict[str, torch.Tensor], shape: NARShape, dtype: torch.dtype, device, max_frames: int = 6000):
+        self.shape, self.dt, self.dev = shape, dtype, torch.device(device)
+        dev, dt = self.dev, dtype
+        D, Q, K = shape.dim, shape.n_codebooks, shape.n_quant
+        f32 = lambda n: sd[n].to(dev, torch.float32).contiguous()
+        wdt = lambda n: sd[n].to(device=dev, dtype=dt).contiguous()
+        self.enc = [pack_layer(sd, f"tfm.encoder.layers.{l}", dt, dev) for l in range(shape.enc_layers)]
+        self.dec = [pack_layer(sd, f"tfm.decoder.layers.{l}", dt, dev, cross=True) for l in range(shape.dec_layers)]
+        self.enc_norm = (f32("tfm.encoder.norm.weight"), f32("tfm.encoder.norm.bias"))
+        self.dec_norm = (f32("tfm.decoder.norm.weight"), f32("tfm.decoder.norm.bias"))
+        self.te = [(wdt(f"timestep_{w}_emb.0.weight"), f32(f"timestep_{w}_emb.0.bias"),
+                    wdt(f"timestep_{w}_emb.2.weight"), f32(f"timestep_{w}_emb.2.bias")) for w in ("encoder", "decoder")]
+        self.text_embed = f32("text_embed.weight")
+        self.res_tables = torch.stack([sd[f"residual_encoder.embs.{q}.weight"].float() for q in range(Q)]).to(dev).contiguous()
+        self.cond_alpha, self.pos_alpha = f32("cond_pos_embedding.alpha"), f32("pos_embedding.alpha")
+        # heads 1..Q-1 only: codebook 0 is always taken from the known branch (m[...,0] = 1)
+        self.head_g = torch.stack([sd[f"residual_decoder.{q}.0.weight"].float() for q in range(1, Q)]).to(dev).contiguous()
+        self.head_b = torch.stack([sd[f"residual_decoder.{q}.0.bias"].float() for q in range(1, Q)]).to(dev).contiguous()
+        self.head_w = torch.stack([sd[f"residual_decoder.{q}.1.weight"].float() for q in range(1, Q)]).to(device=dev, dtype=dt).contiguous()
+        self.head_bias = torch.stack([sd[f"residual_decoder.{q}.1.bias"].float() for q in range(1, Q)]).to(dev).contiguous()
+        self.spk = SpeakerEncoder(sd, "ref_embedder", "ref_pos_embedding.alpha", shape.n_spk_layers, dt, dev)
+        self.pe = sine_pe(max_frames, D).to(dev)
+        self.spk_uncond: Optional[torch.Tensor] = None      # model constant, computed on first use
+
+    def uncond_speaker(self, stream=None) -> torch.Tensor:
+        if self.spk_uncond is None:
+            self.spk_uncond = self.spk(None, stream=stream)
+        return self.spk_uncond
+
+    def flops_per_step(self, S: int, Le: int, s_out: int, guidance: bool = True) -> float:
+        """Algorithmic MFMA flops of one reverse step's loop body (decoder + heads), SURVEY §8d."""
+        s = self.shape
+        D, FF = s.dim, s.dim_ff
+        nb = 2 if guidance else 1
+        per_row = 2 * (4 * D * D + 2 * D * D + 3 * D * FF)          # self in/out, cross q/out, SwiGLU + linear2
+        att = 4 * (S + Le) * D                                        # QK^T + PV, self + cross
+        dec = s.dec_layers * S * (per_row + att)
+        heads = s_out * (s.n_codebooks - 1) * 2 * D * s.n_quant
+        return float(nb * (dec + heads))
+
+
+@dataclass
+class NARConfig:
+    """The DSH fields that reach the shipped inference path (reference diffuser.py:302-315,
+    inference.py:289-294) plus T."""
+    T: int = 200
+    x_0_temp: float = 0.7
+    guidance_w: float = 3.0
+    deep_clone: bool = True
+    q0_override_steps: int = 20
+    div_mode: int = 0
+
+
+class NARSession:
+    """One utterance.  ``prepare`` = everything x_t-independent; ``step`` = one reverse step."""
+
+    def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None):
+        self.m, self.cfg = model, cfg
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=model.dev)
+        self.graph: Optional[ops.Graph] = None
+
+    # -------------------------------------------------------------------------- prepare
+    def prepare(self, c_text: torch.Tensor, c_codes: torch.Tensor, x: torch.Tensor, x_known: torch.Tensor, m_mask: torch.Tensor,
+                row_offset: int, times: Optional[List[int]] = None) -> None:
+        """c_text (Lt,), c_codes (Lc, 8): conditioning.  x / x_known (S, 8) int64, m_mask (S, 8)
+        uint8: the inpainting state built by ``perform_simple_inference`` (diffuser.py:405-436).
+        row_offset: prompt frames prepended in deep-clone mode (never sampled from the model)."""
+        mdl, s, cfg = self.m, self.m.shape, self.cfg
+        dev, dt = mdl.dev, mdl.dt
+        st = self.stream.cuda_stream
+        self.times = reverse_schedule(cfg.T) if times is None else list(times)
+        T = len(self.times)
+        D, H, FF, K, Q = s.dim, s.dim // 64, s.dim_ff, s.n_quant, s.n_codebooks
+        guided = cfg.guidance_w != 1
+        nb = 2 if guided else 1
+        with torch.cuda.stream(self.stream):
+            c_text = c_text.to(dev)
+            c_codes = c_codes.to(dev).contiguous()
+            self.x = x.to(dev).contiguous().clone()
+            self.x_known = x_known.to(dev).contiguous()
+            self.m_mask = m_mask.to(device=dev, dtype=torch.uint8).contiguous()
+            S = self.x.shape[0]
+            self.S, self.row_offset, self.nb = S, int(row_offset), nb
+            assert S <= mdl.pe.shape[0]
+            Lt = int(c_text.shape[0])
+            Le = Lt + 1
+            # -- speaker vectors (t-independent) and timestep MLPs for every scheduled t
+            spk_c = mdl.spk(c_codes, stream=st)
+            rows = [spk_c]
+            if guided:
+                rows.append(mdl.uncond_speaker(stream=st))
+            tin = timestep_inputs(self.times, s.t_emb_dim).to(device=dev, dtype=dt)
+            tvec = []
+            for (w0, b0, w2, b2) in mdl.te:
+                h = torch.empty(T, D, dtype=dt, device=dev)
+                o = torch.empty(T, D, dtype=torch.float32, device=dev)
+                ops.gemm(tin, w0, h, L.EPI_SILU_DT, bias=b0, stream=st)
+                ops.gemm(h, w2, o, L.EPI_F32, bias=b2, stream=st)
+                tvec.append(o)
+            t_enc, self.t_dec = tvec
+            # -- encoder input for every (step, cond/uncond): [spk, text] + pos + t_enc[step]
+            table = torch.cat([mdl.text_embed] + [r[None] for r in rows], dim=0)
+            nt = mdl.text_embed.shape[0]
+            one = torch.cat([torch.tensor([0], device=dev), c_text])                       # row 0 placeholder
+            idx = one[None, None, :].repeat(T, nb, 1)
+            for b in range(nb):
+                idx[:, b, 0] = nt + b
+            pos = torch.arange(Le, device=dev, dtype=torch.int32)[None, None].expand(T, nb, Le).contiguous()
+            aidx = torch.arange(T, device=dev, dtype=torch.int32)[:, None, None].expand(T, nb, Le).contiguous()
+            Me = T * nb * Le
+            c = torch.empty(Me, D, dtype=torch.float32, device=dev)
+            ops.gather_rows(c, table, idx.reshape(-1).contiguous(), mdl.cond_alpha, mdl.pe, pos.reshape(-1), t_enc,
+                            aidx.reshape(-1), stream=st)
+            wse = SeqWorkspace(T * nb, Le, D, FF, dt, dev)
+            for lw in mdl.enc:
+                encoder_layer(c, lw, wse, None, st)
+            mem = torch.empty(Me, D, dtype=dt, device=dev)
+            ops.layernorm(c, mdl.enc_norm[0], mdl.enc_norm[1], LAYERNORM_EPS, mem, stream=st)
+            # -- cross-attention K / V^T of every decoder layer for every step
+            Lep = round_up(Le, 64)
+            self.mems: List[CrossMemory] = []
+            for lw in mdl.dec:
+                k = torch.empty(T * nb, H, Le, 64, dtype=dt, device=dev)
+                vt = torch.zeros(T * nb, H, 64, Lep, dtype=dt, device=dev)
+                sc = L.QkvScatter(q=None, k=k.data_ptr(), vt=vt.data_ptr(), rows_per_batch=Le, n_heads=H, head_dim=64,
+                                  q_bs=0, q_hs=0, q_rs=0, k_bs=H * Le * 64, k_hs=Le * 64, k_rs=64,
+                                  vt_bs=H * 64 * Lep, vt_hs=64 * Lep, vt_ds=Lep)
+                ops.gemm(mem, lw.ca_kv_w, None, L.EPI_QKV, bias=lw.ca_kv_b, scatter=sc, stream=st)
+                self.mems.append(CrossMemory(k, vt, Le, Lep, nb))
+            # -- loop-body buffers
+            self.ws = SeqWorkspace(nb, S, D, FF, dt, dev)
+            self.h = torch.empty(nb, S, D, dtype=torch.float32, device=dev)
+            self.hf = torch.empty(nb * S, D, dtype=torch.float32, device=dev)
+            self.s_out = S - self.row_offset
+            self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
+            self.Kp = round_up(K, 4)
+            self.logits = torch.empty(nb * self.s_out, Q - 1, self.Kp, dtype=torch.float32, device=dev)
+            self.consts = nar_step_consts(self.times, K).to(dev)
+            self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.step_i = 0
+            self._keep = [table, t_enc, mem]
+        self.graph = None
+
+    # ----------------------------------------------------------------------------- step
+    def enqueue_forward(self, st: int) -> None:
+        """x_t -> logits for both guidance branches (the loop body's GEMM/attention work)."""
+        mdl, s = self.m, self.m.shape
+        S, nb, D, Q = self.S, self.nb, s.dim, s.n_codebooks
+        ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr, stream=st)
+        hx = self.h.view(nb * S, D)
+        for lw, mem in zip(mdl.dec, self.mems):
+            decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st)
+        ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
+        so = self.s_out
+        for b in range(nb):
+            ops.layernorm(self.hf[b * S + self.row_offset:], mdl.head_g, mdl.head_b, 1e-5, self.hn[:, b * so:], n_affine=Q - 1,
+                          affine_stride=D, y_affine_stride=nb * so * D, M=so, stream=st)
+        ops.gemm(self.hn[0], mdl.head_w[0], self.logits, L.EPI_F32, bias=mdl.head_bias, ldc=(Q - 1) * self.Kp, batch=Q - 1,
+                 sA=nb * so * D, sW=s.n_quant * D, sC=self.Kp, sBias=s.n_quant, stream=st)
+
+    def enqueue_sample(self, u1: torch.Tensor, u2: Optional[torch.Tensor], st: int) -> None:
+        s, cfg = self.m.shape, self.cfg
+        so, Q = self.s_out, s.n_codebooks
+        ld_row = (Q - 1) * self.Kp
+        lu = self.logits[so:] if self.nb == 2 else None
+        a = L.NarSampleArgs(logits_c=self.logits.data_ptr(), logits_u=lu.data_ptr() if lu is not None else None,
+                            ld_row=ld_row, ld_q=self.Kp, S=self.S, n_q=Q, K=s.n_quant, row_offset=self.row_offset,
+                            x=self.x.data_ptr(), x_known=self.x_known.data_ptr(), m=self.m_mask.data_ptr(),
+                            u1=u1.data_ptr(), u2=(u2 if u2 is not None else u1).data_ptr(), consts=self.consts.data_ptr(),
+                            step=self.step_ptr.data_ptr(), guidance_w=cfg.guidance_w, temperature=cfg.x_0_temp,
+                            log_eps=log_eps(), div_mode=cfg.div_mode, q0_override_steps=cfg.q0_override_steps)
+        ops.nar_sample(a, stream=st)
+        ops.add_int(self.step_ptr, 1, stream=st)
+
+    def step(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True) -> None:
+        """One reverse step t = times[step_i]: forward (graph), draw uniforms, sample."""
+        st = self.stream.cuda_stream
+        t = self.times[self.step_i]
+        if use_graph:
+            if self.graph is None:
+                self.stream.synchronize()
+                ops.Graph.begin(st)
+                self.enqueue_forward(st)
+                self.graph = ops.Graph().end(st)
+            self.graph.launch(st)
+        else:
+            self.enqueue_forward(st)
+        shape = (1, self.S, self.m.shape.n_codebooks, self.m.shape.n_quant)
+        with torch.cuda.stream(self.stream):
+            u1 = uniform(shape)
+            u2 = uniform(shape) if t > 0 else None
+            self.enqueue_sample(u1[0], u2[0] if u2 is not None else None, st)
+        self.step_i += 1
+
+    def run(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True, n_steps: Optional[int] = None) -> torch.Tensor:
+        n = len(self.times) if n_steps is None else n_steps
+        for _ in range(n):
+            self.step(uniform, use_graph)
+        self.stream.synchronize()
+        return self.x

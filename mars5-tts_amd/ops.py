@@ -1,0 +1,163 @@
+"""Tensor-level wrappers over the C ABI.  torch is plumbing here: device memory
+(``data_ptr``), streams and shapes.  No arithmetic happens in this file; every function
+enqueues exactly one HIP kernel on ``stream`` (default: torch's current stream)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from ._lib import check, lib
+
+DT_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
+CODE_DT = {v: k for k, v in DT_CODE.items()}
+DT_NAME = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_cuda, "libmars5_hip operates on device memory only"
+    return t.data_ptr()
+
+
+def cur_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _s(stream: Optional[int]) -> int:
+    return cur_stream() if stream is None else stream
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int, bias: Optional[torch.Tensor] = None,
+         scatter: Optional[L.QkvScatter] = None, M: Optional[int] = None, ldc: Optional[int] = None,
+         batch: int = 1, sA: int = 0, sW: int = 0, sC: int = 0, sBias: int = 0, stream: Optional[int] = None) -> None:
+    """out = a[M,K] @ w[N,K]^T (+bias) with fused epilogue `epi`.  a/w: 2-D, K contiguous."""
+    assert a.dtype == w.dtype and a.stride(-1) == 1 and w.stride(-1) == 1
+    Mv = a.shape[-2] if M is None else M
+    N, K = w.shape[-2], w.shape[-1]
+    assert a.shape[-1] == K
+    if bias is not None:
+        assert bias.dtype == torch.float32
+    ld = ldc if ldc is not None else (out.stride(-2) if out is not None else 0)
+    check(lib.m5_gemm(DT_CODE[a.dtype], _p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(out), ld, Mv, N, K, epi,
+                      C.byref(scatter) if scatter is not None else None, batch, sA, sW, sC, sBias, _s(stream)), "m5_gemm")
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor,
+              n_affine: int = 1, affine_stride: int = 0, y_affine_stride: int = 0, M: Optional[int] = None,
+              stream: Optional[int] = None) -> None:
+    assert x.dtype == torch.float32 and x.stride(-1) == 1 and out.stride(-1) == 1
+    Mv = x.shape[0] if M is None else M
+    ldy = out.stride(-2)
+    check(lib.m5_layernorm(DT_CODE[out.dtype], _p(x), x.stride(0), _p(gamma), _p(beta), eps, _p(out), ldy, Mv, x.shape[1],
+                           n_affine, affine_stride, y_affine_stride, _s(stream)), "m5_layernorm")
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: torch.Tensor, stream: Optional[int] = None) -> None:
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    check(lib.m5_rmsnorm(DT_CODE[out.dtype], _p(x), x.stride(0), _p(w), eps, _p(out), out.stride(0), x.shape[0], x.shape[1],
+                         _s(stream)), "m5_rmsnorm")
+
+
+def attention(dtype: torch.dtype, args: L.AttnArgs, stream: Optional[int] = None) -> None:
+    check(lib.m5_attention(DT_CODE[dtype], C.byref(args), _s(stream)), "m5_attention")
+
+
+def gather_rows(out: torch.Tensor, table: torch.Tensor, idx: torch.Tensor, alpha: Optional[torch.Tensor] = None,
+                pe: Optional[torch.Tensor] = None, pos: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None,
+                add_idx: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
+    assert out.dtype == torch.float32 and table.dtype == torch.float32 and idx.dtype == torch.int64
+    R, D = out.shape
+    assert table.shape[1] == D and table.is_contiguous()
+    check(lib.m5_gather_rows(_p(out), out.stride(0), R, D, _p(table), _p(idx), _p(alpha), _p(pe), _p(pos), _p(add),
+                             _p(add_idx), _s(stream)), "m5_gather_rows")
+
+
+def chunked_embed(out: torch.Tensor, tables: torch.Tensor, codes: Optional[torch.Tensor], lead_row: Optional[torch.Tensor],
+                  alpha: Optional[torch.Tensor], pe: Optional[torch.Tensor], add: Optional[torch.Tensor] = None,
+                  add_index: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
+    """out (n_rep, R, D) fp32; tables (n_q, n_codes, D/n_q); codes (R-lead, n_q) int64."""
+    assert out.dtype == torch.float32 and out.is_contiguous() and tables.is_contiguous()
+    n_rep, R, D = out.shape
+    n_q, n_codes, _ = tables.shape
+    if codes is not None:
+        assert codes.dtype == torch.int64 and codes.is_contiguous()
+    check(lib.m5_chunked_embed(_p(out), R * D, n_rep, R, D, n_q, n_codes, _p(tables), _p(codes), _p(lead_row), _p(alpha),
+                               _p(pe), _p(add), _p(add_index), _s(stream)), "m5_chunked_embed")
+
+
+def rope_cache(qkv: torch.Tensor, n_heads: int, pos0: int, rope: torch.Tensor, q_out: torch.Tensor, kcache: torch.Tensor,
+               vcache: torch.Tensor, cache_hs: int, window: int, vt_out: torch.Tensor, vt_hs: int, vt_ds: int,
+               stream: Optional[int] = None) -> None:
+    check(lib.m5_rope_cache(DT_CODE[qkv.dtype], _p(qkv), qkv.shape[0], n_heads, pos0, _p(rope), _p(q_out), _p(kcache),
+                            _p(vcache), cache_hs, window, _p(vt_out), vt_hs, vt_ds, _s(stream)), "m5_rope_cache")
+
+
+def ar_gemv(dtype: torch.dtype, pro: int, epi: int, args: L.GemvArgs, stream: Optional[int] = None) -> None:
+    check(lib.m5_ar_gemv(DT_CODE[dtype], pro, epi, C.byref(args), _s(stream)), "m5_ar_gemv")
+
+
+def ar_attn_decode(dtype: torch.dtype, args: L.AttnDecodeArgs, stream: Optional[int] = None) -> None:
+    check(lib.m5_ar_attn_decode(DT_CODE[dtype], C.byref(args), _s(stream)), "m5_ar_attn_decode")
+
+
+def ar_sample(args: L.SampleArgs, stream: Optional[int] = None) -> None:
+    check(lib.m5_ar_sample(C.byref(args), _s(stream)), "m5_ar_sample")
+
+
+def nar_sample(args: L.NarSampleArgs, stream: Optional[int] = None) -> None:
+    check(lib.m5_nar_sample(C.byref(args), _s(stream)), "m5_nar_sample")
+
+
+def add_int(p: torch.Tensor, delta: int, stream: Optional[int] = None) -> None:
+    assert p.dtype == torch.int32
+    check(lib.m5_add_int(_p(p), delta, _s(stream)), "m5_add_int")
+
+
+class Graph:
+    """A captured hipGraph of libmars5_hip launches (m5_graph_* helpers)."""
+
+    def __init__(self):
+        self.exec = C.c_void_p(None)
+
+    @staticmethod
+    def begin(stream: int) -> None:
+        check(lib.m5_graph_begin(stream), "m5_graph_begin")
+
+    def end(self, stream: int) -> "Graph":
+        check(lib.m5_graph_end(stream, C.byref(self.exec)), "m5_graph_end")
+        return self
+
+    def launch(self, stream: int) -> None:
+        check(lib.m5_graph_launch(self.exec, stream), "m5_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.exec and self.exec.value:
+                lib.m5_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self):
+        self.ev = C.c_void_p(None)
+        check(lib.m5_event_create(C.byref(self.ev)), "m5_event_create")
+
+    def record(self, stream: int) -> None:
+        check(lib.m5_event_record(self.ev, stream), "m5_event_record")
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = C.c_float(0)
+        check(lib.m5_event_elapsed_ms(self.ev, stop.ev, C.byref(ms)), "m5_event_elapsed_ms")
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.ev and self.ev.value:
+                lib.m5_event_destroy(self.ev)
+        except Exception:
+            pass

@@ -1,0 +1,280 @@
+"""End-to-end parity on a real MI355X through the reference-named seams
+(``ar_generate`` / ``perform_simple_inference``): HIP path vs golden fixtures produced by the
+unmodified reference, and vs the CPU oracle on the same seeded inputs."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TEXT = "The quick brown rat."
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _toks(b):
+    from mars5_tts_amd import minbpe
+    tt = minbpe.RegexTokenizer()
+    tt.load(io.BytesIO(b.ar_ckpt["vocab"]["texttok.model"].encode()))
+    st = minbpe.CodebookTokenizer()
+    st.load(io.BytesIO(b.ar_ckpt["vocab"]["speechtok.model"].encode()))
+    return tt, st
+
+
+def _lm(b, dt, dev):
+    from mars5_tts_amd import model
+    a = b.ar_shape
+    lm = model.CodecLM(a.n_vocab, dim=a.dim, nhead=a.nhead, n_layers=a.n_layers, n_spk_layers=a.n_spk_layers,
+                       dim_ff_scale=a.hidden_dim / a.dim + 1e-9)
+    lm.load_state_dict(b.ar_ckpt["model"])
+    return lm.to(dev).set_engine_dtype(dt)
+
+
+def _nar(b, dt, dev):
+    from mars5_tts_amd import model
+    n = b.nar_shape
+    nar = model.ResidualTransformer(n.n_text_vocab, n_quant=n.n_quant, dim=n.dim, nhead=n.nhead, enc_layers=n.enc_layers,
+                                    dec_layers=n.dec_layers, n_spk_layers=n.n_spk_layers, t_emb_dim=n.t_emb_dim, p_cond_drop=0, dropout=0)
+    nar.load_state_dict(b.nar_ckpt["model"])
+    return nar.to(dev).set_engine_dtype(dt)
+
+
+SAMPLERS = {
+    "ar_tiny_greedy_deep": dict(topk=1, top_p=0.2, penalty_window=80),
+    "ar_tiny_sampled_deep": dict(topk=100, top_p=0.9, penalty_window=100),
+    "ar_tiny_greedy_shallow": dict(topk=1, top_p=0.2, penalty_window=80),
+    "ar_full_greedy_deep": dict(topk=1, top_p=0.2, penalty_window=80),
+}
+
+
+def _run_ar(lm, tt, st, fx, kw, n_gen, use_graph, noise):
+    from mars5_tts_amd.ar_generate import ar_generate
+    prompt = torch.from_numpy(fx["prompt"])
+    ref = torch.from_numpy(fx["ref_codes"])[0].T.contiguous()
+    return ar_generate(tt, st, lm, prompt, ref, int(fx["first_codec_idx"]), max_len=prompt.shape[0] + n_gen, fp16=False,
+                       temperature=0.7, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4, eos_penalty_decay=0.5,
+                       eos_penalty_factor=1.0, n_phones_gen=round(len(TEXT)), vocode=False, noise=noise, use_graph=use_graph, **kw)
+
+
+@pytest.mark.parametrize("tag", ["ar_tiny_greedy_deep", "ar_tiny_sampled_deep", "ar_tiny_greedy_shallow"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ar_tiny_f32_matches_reference_tokens(dev, tiny_bundle, gold_dir, tag, use_graph):
+    """fp32 engine, same Exp(1) noise stream as the reference run (CPU mt19937, seed in the
+    fixture): token ids must equal the reference's, bit for bit."""
+    fx = np.load(os.path.join(gold_dir, f"{tag}.npz"))
+    tt, st = _toks(tiny_bundle)
+    lm = _lm(tiny_bundle, torch.float32, dev)
+    V = tiny_bundle.ar_shape.n_vocab
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    noise = torch.stack([torch.empty(V).exponential_(1, generator=g) for _ in range(24)])
+    out = _run_ar(lm, tt, st, fx, SAMPLERS[tag], 24, use_graph, noise)
+    assert out.cpu().tolist() == fx["tokens"].tolist()
+
+
+def test_ar_tiny_f32_logits_vs_reference(dev, tiny_bundle, gold_dir):
+    """Teacher-forced: prefill logits and the first decode steps' logits vs the reference's."""
+    from mars5_tts_amd import _lib as L
+    from mars5_tts_amd.ar_engine import ARSamplingConfig, ARSession
+    fx = np.load(os.path.join(gold_dir, "ar_tiny_greedy_deep.npz"))
+    tt, st = _toks(tiny_bundle)
+    eng = _lm(tiny_bundle, torch.float32, dev).engine()
+    V = eng.shape.n_vocab
+    prompt = torch.from_numpy(fx["prompt"])
+    sess = ARSession(eng, prompt.shape[0] + 24)
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    noise = torch.stack([torch.empty(V).exponential_(1, generator=g) for _ in range(24)]).to(dev)
+    cfg = ARSamplingConfig(temperature=0.7, topk=1, top_p=0.2, alpha_frequency=3, alpha_presence=0.4, penalty_window=80,
+                           eos_penalty_factor=1.0, eos_penalty_decay=0.5, n_phones_gen=round(len(TEXT)))
+    sess.configure_sampler(cfg, tiny_bundle.n_text, tiny_bundle.n_text + st.special_tokens["<|endofspeech|>"], noise)
+    sess.prefill(prompt, torch.from_numpy(fx["ref_codes"])[0].T.contiguous())
+    s = sess.stream.cuda_stream
+    sess.enqueue_head_and_sample(s)
+    sess.stream.synchronize()
+    errs = [float((sess.logits.cpu() - torch.from_numpy(fx["logits"][0])).abs().max())]
+    for i in range(1, 6):
+        sess.enqueue_layers(s)
+        sess.enqueue_head_and_sample(s)
+        sess.stream.synchronize()
+        errs.append(float((sess.logits.cpu() - torch.from_numpy(fx["logits"][i])).abs().max()))
+    print("AR f32 logits max|diff| per step:", errs)
+    assert max(errs) < 2e-4, errs     # |logits| ~ 5; fp32 accumulation-order noise only
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_ar_tiny_reduced_precision_vs_oracle(dev, dt):
+    """f16 / bf16 operands, weights pre-rounded so the oracle sees the same values: logits
+    within dtype tolerance of the fp32 oracle; greedy tokens agree except where the oracle's
+    own top-2 margin is inside that tolerance."""
+    import mars5_oracle as O
+    from mars5_tts_amd import synth
+    b = synth.make_bundle("tiny", seed=0, dtype_round="f16" if dt == torch.float16 else "bf16")
+    tt, st = _toks(b)
+    lm = _lm(b, dt, dev)
+    ref_codes = synth.make_ref_codes(40, seed=7, merge_friendly=True)
+    text = tt.encode("<|startoftext|>" + TEXT + "<|endoftext|>", allowed_special="all")
+    prompt = torch.tensor(text, dtype=torch.long)
+    p = O.ARSamplingParams(temperature=0.7, top_k=1, top_p=0.2, penalty_window=80, n_phones_gen=round(len(TEXT)))
+    n_gen = 16
+    V = b.ar_shape.n_vocab
+    noise = torch.ones(n_gen, V)
+    o_tok, o_logits = O.ar_generate_oracle(b.ar_ckpt["model"], b.ar_shape.nhead, b.n_text, b.n_speech, st.special_tokens["<|endofspeech|>"],
+                                           prompt, ref_codes[0].T.contiguous(), prompt.shape[0] + n_gen, p, noise=noise, return_logits=True)
+    from mars5_tts_amd.ar_generate import ar_generate
+    out = ar_generate(tt, st, lm, prompt, ref_codes[0].T.contiguous(), len(text) + 1, max_len=prompt.shape[0] + n_gen, fp16=True,
+                      temperature=0.7, topk=1, top_p=0.2, alpha_frequency=3, alpha_presence=0.4, penalty_window=80,
+                      eos_penalty_decay=0.5, eos_penalty_factor=1.0, n_phones_gen=round(len(TEXT)), vocode=False, noise=noise).cpu()
+    tol = 0.06 if dt == torch.float16 else 0.35
+    n = min(out.shape[0], o_tok.shape[0])
+    first_diff = next((i for i in range(n) if int(out[i]) != int(o_tok[i])), None)
+    if first_diff is not None:
+        step = first_diff - prompt.shape[0]
+        top2 = torch.topk(O.filter_logits(o_logits[step], o_tok[prompt.shape[0]:first_diff].tolist(), p, b.n_text,
+                                          b.n_text + st.special_tokens["<|endofspeech|>"]), 2)[0]
+        # a flip is only acceptable at a near-tie of the oracle's own logits (before top-k they differ by < tol)
+        lg = torch.topk(o_logits[step][b.n_text - 1:], 2)[0]
+        assert float(lg[0] - lg[1]) < tol, f"{dt}: token flip at step {step} with oracle margin {float(lg[0] - lg[1])}"
+    print(f"{dt}: first differing token index: {first_diff} of {n}")
+
+
+@pytest.mark.parametrize("tag", ["nar_tiny_deep", "nar_tiny_shallow"])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_nar_tiny_f32_matches_reference(dev, tiny_bundle, gold_dir, tag, use_graph):
+    """fp32 engine with the reference run's RNG stream (CPU generator, seed in the fixture).
+    Whole-trajectory equality is the headline statistic; the hard assertion is teacher-forced
+    (each step restarted from the reference's x_t) so one libm-ulp near-tie cannot cascade."""
+    from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_simple_inference
+    fx = np.load(os.path.join(gold_dir, f"{tag}.npz"))
+    nar = _nar(tiny_bundle, torch.float32, dev)
+    deep = bool(fx["deep_clone"])
+    T = int(fx["T_run"])
+    c_text = torch.from_numpy(fx["c_text"])[None]
+    c_codes = torch.from_numpy(fx["c_codes"])[None]
+    x_l0 = torch.from_numpy(fx["x_l0"])
+    _x = x_l0[None, :, None].repeat(1, 1, 8)
+    batch = (c_text, c_codes, torch.tensor([c_text.shape[1]]), torch.tensor([c_codes.shape[1]]), _x, torch.zeros(1, _x.shape[1], dtype=torch.bool))
+    diff = MultinomialDiffusion(1025, timesteps=200, device="cpu")
+    dsh = DSH(last_greedy=True, x_0_temp=0.7, guidance_w=3, deep_clone=deep, q0_override_steps=20)
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    out = perform_simple_inference(nar, batch, diff, T, torch.float16, dsh=dsh, retain_quant0=True,
+                                   uniform=lambda shp: torch.rand(shp, generator=g).to(dev),
+                                   randint=lambda shp: torch.randint(0, 1025, shp, dtype=torch.long, generator=g), use_graph=use_graph)
+    n_bad = int((out[0].cpu() != torch.from_numpy(fx["final"])).sum())
+    print(f"{tag} graph={use_graph}: free-running final mismatches {n_bad}/{fx['final'].size}")
+    # teacher-forced per step
+    from mars5_tts_amd.nar_engine import NARConfig, NARSession
+    eng = nar.engine()
+    off = c_codes.shape[1] if deep else 0
+    S = fx["steps_x_t"].shape[1]
+    x_known = torch.zeros(S, 8, dtype=torch.long)
+    m = torch.zeros(S, 8, dtype=torch.uint8)
+    m[:, 0] = 1
+    if deep:
+        x_known[:off] = c_codes[0]
+        m[:off] = 1
+        x_known[off:, 0] = x_l0
+    else:
+        x_known[:, 0] = x_l0
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    torch.randint(0, 1025, (1, x_l0.shape[0], 8), dtype=torch.long, generator=g)
+    sess = NARSession(eng, NARConfig(T=T, x_0_temp=0.7, guidance_w=3.0, deep_clone=deep, q0_override_steps=20))
+    sess.prepare(c_text[0], c_codes[0], torch.from_numpy(fx["steps_x_t"][0]), x_known, m, off, list(range(T - 1, -1, -1)))
+    worst = 0
+    for i in range(T):
+        sess.x.copy_(torch.from_numpy(fx["steps_x_t"][i]).to(dev))
+        sess.step(lambda shp: torch.rand(shp, generator=g).to(dev), use_graph=use_graph)
+        sess.stream.synchronize()
+        bad = int((sess.x.cpu() != torch.from_numpy(fx["steps_x_tm1"][i])).sum())
+        worst = max(worst, bad)
+    print(f"{tag}: worst teacher-forced step mismatch {worst}/{S * 8}")
+    assert worst <= 2
+    assert n_bad <= 0.02 * fx["final"].size
+
+
+def test_nar_tiny_logits_vs_reference(dev, tiny_bundle, gold_dir):
+    from mars5_tts_amd.nar_engine import NARConfig, NARSession
+    fx = np.load(os.path.join(gold_dir, "nar_tiny_deep.npz"))
+    eng = _nar(tiny_bundle, torch.float32, dev).engine()
+    c_text, c_codes = torch.from_numpy(fx["c_text"]), torch.from_numpy(fx["c_codes"])
+    S = fx["steps_x_t"].shape[1]
+    off = c_codes.shape[0]
+    T = int(fx["T_run"])
+    sess = NARSession(eng, NARConfig(T=T))
+    z = torch.zeros(S, 8, dtype=torch.long)
+    sess.prepare(c_text, c_codes, torch.from_numpy(fx["steps_x_t"][0]), z, z.to(torch.uint8), off, list(range(T - 1, -1, -1)))
+    sess.enqueue_forward(sess.stream.cuda_stream)
+    sess.stream.synchronize()
+    so = S - off
+    lg = sess.logits.cpu()[:, :, :1025]
+    ref_c = torch.from_numpy(fx["logits_c_sub"])[off:, 1:]
+    ref_u = torch.from_numpy(fx["logits_u_sub"])[off:, 1:]
+    ec = float((lg[:so, :, ::8] - ref_c).abs().max())
+    eu = float((lg[so:, :, ::8] - ref_u).abs().max())
+    print(f"NAR f32 logits max|diff| cond {ec:.3e} uncond {eu:.3e}")
+    assert ec < 3e-4 and eu < 3e-4
+    assert torch.equal(lg[:so].argmax(-1), torch.from_numpy(fx["logits_c_argmax"])[off:, 1:])
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_nar_tiny_reduced_precision_logits(dev, dt):
+    import mars5_oracle as O
+    from mars5_tts_amd import synth
+    from mars5_tts_amd.nar_engine import NARConfig, NARSession
+    b = synth.make_bundle("tiny", seed=0, dtype_round="f16" if dt == torch.float16 else "bf16")
+    eng = _nar(b, dt, dev).engine()
+    g = torch.Generator().manual_seed(3)
+    c_text = torch.randint(0, b.nar_shape.n_text_vocab, (19,), generator=g)
+    c_codes = synth.make_ref_codes(30)[0].T.contiguous()
+    S, off, t = 77, 30, 150
+    x = torch.randint(0, 1025, (S, 8), generator=g)
+    lc = O.nar_forward(b.nar_ckpt["model"], b.nar_shape.nhead, c_text, c_codes, x, t, False)
+    lu = O.nar_forward(b.nar_ckpt["model"], b.nar_shape.nhead, c_text, c_codes, x, t, True)
+    sess = NARSession(eng, NARConfig(T=200))
+    z = torch.zeros(S, 8, dtype=torch.long)
+    sess.prepare(c_text, c_codes, x, z, z.to(torch.uint8), off, [t])
+    sess.enqueue_forward(sess.stream.cuda_stream)
+    sess.stream.synchronize()
+    lg = sess.logits.cpu()[:, :, :1025]
+    so = S - off
+    tol = 0.05 if dt == torch.float16 else 0.3
+    ec = float((lg[:so] - lc[off:, 1:]).abs().max())
+    eu = float((lg[so:] - lu[off:, 1:]).abs().max())
+    print(f"NAR {dt} logits max|diff| cond {ec:.3e} uncond {eu:.3e} (|logit| max {float(lc.abs().max()):.2f})")
+    assert ec < tol and eu < tol
+
+
+def test_full_size_goldens_f32(dev, gold_dir):
+    """The real MARS5 geometry (1536-d x 26 layers AR, 1024-d 8+16 layers NAR) with seeded
+    weights regenerated on this host: fp32 engine vs tokens produced by the reference."""
+    from mars5_tts_amd import synth
+    from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_simple_inference
+    b = synth.make_bundle("full", seed=0)
+    tt, st = _toks(b)
+    fx = np.load(os.path.join(gold_dir, "ar_full_greedy_deep.npz"))
+    lm = _lm(b, torch.float32, dev)
+    V = b.ar_shape.n_vocab
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    noise = torch.stack([torch.empty(V).exponential_(1, generator=g) for _ in range(16)])
+    out = _run_ar(lm, tt, st, fx, SAMPLERS["ar_full_greedy_deep"], 16, True, noise)
+    assert out.cpu().tolist() == fx["tokens"].tolist()
+    del lm
+    torch.cuda.empty_cache()
+    fx = np.load(os.path.join(gold_dir, "nar_full_deep.npz"))
+    nar = _nar(b, torch.float32, dev)
+    c_text, c_codes = torch.from_numpy(fx["c_text"])[None], torch.from_numpy(fx["c_codes"])[None]
+    _x = torch.from_numpy(fx["x_l0"])[None, :, None].repeat(1, 1, 8)
+    batch = (c_text, c_codes, torch.tensor([c_text.shape[1]]), torch.tensor([c_codes.shape[1]]), _x, torch.zeros(1, _x.shape[1], dtype=torch.bool))
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    outn = perform_simple_inference(nar, batch, MultinomialDiffusion(1025, timesteps=200), int(fx["T_run"]), torch.float16,
+                                    dsh=DSH(last_greedy=True, x_0_temp=0.7, guidance_w=3, deep_clone=True, q0_override_steps=20),
+                                    uniform=lambda shp: torch.rand(shp, generator=g).to(dev),
+                                    randint=lambda shp: torch.randint(0, 1025, shp, dtype=torch.long, generator=g))
+    n_bad = int((outn[0].cpu() != torch.from_numpy(fx["final"])).sum())
+    print(f"full-size NAR: {n_bad}/{fx['final'].size} ids differ from the reference")
+    assert n_bad <= 0.02 * fx["final"].size

@@ -1,0 +1,494 @@
+"""Kernel-level parity on a real MI355X: every HIP kernel (through the C ABI) against a
+plain torch-CPU fp32 computation of the same op / the CPU oracle.  Integer outputs are
+compared exactly; floating point within the tolerance written in each test."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTS = [torch.float32, torch.float16, torch.bfloat16]
+TOL = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}   # relative to max |ref|
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _rel(out, ref):
+    return float((out.double() - ref.double()).abs().max() / (ref.double().abs().max() + 1e-30))
+
+
+def _q(t, dt):
+    return t.to(dt).float()
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+# ------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("M,N,K", [(200, 300, 192), (130, 1025, 128), (70, 64, 448), (257, 129, 64)])
+def test_gemm_epilogues(dev, dt, M, N, K):
+    from mars5_tts_amd import _lib as L, ops
+    a, w, b = _q(_rand((M, K), 1), dt), _q(_rand((N, K), 2), dt), _rand((N,), 3)
+    ref = a @ w.T + b
+    ad, wd, bd = a.to(dev, dt), w.to(dev, dt), b.to(dev)
+    out = torch.zeros(M, N, device=dev)
+    ops.gemm(ad, wd, out, L.EPI_F32, bias=bd)
+    torch.cuda.synchronize()
+    r = _rel(out.cpu(), ref)
+    assert r < TOL[dt], f"EPI_F32 rel err {r}"
+    # transpose detection: an asymmetric case must not match the transposed product
+    out2 = torch.zeros(M, N, device=dev, dtype=dt)
+    ops.gemm(ad, wd, out2, L.EPI_DT, bias=bd)
+    res = _rand((M, N), 4).to(dev)
+    res0 = res.clone()
+    ops.gemm(ad, wd, res, L.EPI_RESIDUAL, bias=bd)
+    out3 = torch.zeros(M, N, device=dev, dtype=dt)
+    ops.gemm(ad, wd, out3, L.EPI_SILU_DT, bias=bd)
+    torch.cuda.synchronize()
+    assert _rel(out2.float().cpu(), ref) < max(TOL[dt], 8e-3 if dt != torch.float32 else 0)
+    assert _rel((res - res0).cpu(), ref) < TOL[dt] * 2
+    assert _rel(out3.float().cpu(), torch.nn.functional.silu(ref)) < max(TOL[dt], 8e-3 if dt != torch.float32 else 0)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_swiglu_and_qkv(dev, dt):
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.blocks import interleave_rows
+    M, K, F = 150, 192, 136
+    a = _q(_rand((M, K), 1), dt)
+    w1, w3 = _q(_rand((F, K), 2), dt), _q(_rand((F, K), 3), dt)
+    ref = torch.nn.functional.silu(a @ w1.T) * (a @ w3.T)
+    h = torch.zeros(M, F, device=dev, dtype=dt)
+    ops.gemm(a.to(dev, dt), interleave_rows(w1, w3).to(dev, dt), h, L.EPI_SWIGLU)
+    torch.cuda.synchronize()
+    assert _rel(h.float().cpu(), ref) < max(TOL[dt] * 2, 1e-2 if dt != torch.float32 else 0)
+    # QKV scatter: B=2 sequences of S rows, H heads
+    B, S, H = 2, 75, 3
+    D = H * 64
+    a = _q(_rand((B * S, D), 5), dt)
+    w = _q(_rand((3 * D, D), 6, 0.2), dt)
+    bias = _rand((3 * D,), 7)
+    ref = (a @ w.T + bias).view(B, S, 3, H, 64)
+    Sp = 128
+    q = torch.zeros(B, H, S, 64, device=dev, dtype=dt)
+    k = torch.zeros(B, H, S, 64, device=dev, dtype=dt)
+    vt = torch.zeros(B, H, 64, Sp, device=dev, dtype=dt)
+    sc = L.QkvScatter(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), rows_per_batch=S, n_heads=H, head_dim=64,
+                      q_bs=H * S * 64, q_hs=S * 64, q_rs=64, k_bs=H * S * 64, k_hs=S * 64, k_rs=64,
+                      vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp)
+    ops.gemm(a.to(dev, dt), w.to(dev, dt), None, L.EPI_QKV, bias=bias.to(dev), scatter=sc)
+    torch.cuda.synchronize()
+    tol = max(TOL[dt], 8e-3 if dt != torch.float32 else 0)
+    assert _rel(q.float().cpu(), ref[:, :, 0].permute(0, 2, 1, 3)) < tol
+    assert _rel(k.float().cpu(), ref[:, :, 1].permute(0, 2, 1, 3)) < tol
+    assert _rel(vt.float().cpu()[..., :S], ref[:, :, 2].permute(0, 2, 3, 1)) < tol
+    assert float(vt[..., S:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_gemm_batched_heads(dev, dt):
+    from mars5_tts_amd import _lib as L, ops
+    nb, M, K, N = 3, 90, 128, 1025
+    a = _q(_rand((nb, M, K), 1), dt)
+    w = _q(_rand((nb, N, K), 2), dt)
+    b = _rand((nb, N), 3)
+    Kp = 1028
+    out = torch.zeros(M, nb, Kp, device=dev)
+    ad, wd = a.to(dev, dt), w.to(dev, dt)
+    ops.gemm(ad[0], wd[0], out, L.EPI_F32, bias=b.to(dev), ldc=nb * Kp, batch=nb, sA=M * K, sW=N * K, sC=Kp, sBias=N)
+    torch.cuda.synchronize()
+    ref = torch.einsum("bmk,bnk->mbn", a, w) + b[None]
+    assert _rel(out.cpu()[..., :N], ref) < TOL[dt]
+
+
+# ------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dt", DTS)
+def test_norms(dev, dt):
+    from mars5_tts_amd import ops
+    M, D = 37, 192
+    x = _rand((M, D), 1, 3.0) + 0.5
+    g, b = 1 + _rand((4, D), 2, 0.2), _rand((4, D), 3, 0.2)
+    out = torch.zeros(4, M, D, device=dev, dtype=dt)
+    ops.layernorm(x.to(dev), g.to(dev), b.to(dev), 4e-5, out, n_affine=4, affine_stride=D, y_affine_stride=M * D)
+    o2 = torch.zeros(M, D, device=dev, dtype=dt)
+    ops.rmsnorm(x.to(dev), g[0].to(dev), 1e-5, o2)
+    torch.cuda.synchronize()
+    for i in range(4):
+        ref = torch.nn.functional.layer_norm(x, (D,), g[i], b[i], 4e-5)
+        assert _rel(out[i].float().cpu(), ref) < max(TOL[dt], 5e-3 if dt != torch.float32 else 0)
+    ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-5) * g[0]
+    assert _rel(o2.float().cpu(), ref) < max(TOL[dt], 5e-3 if dt != torch.float32 else 0)
+
+
+# ------------------------------------------------------------------------------ attention
+def _ref_attention(q, k, v, key_len, causal):
+    # q (B,H,Sq,64) k,v (B,H,Sk,64)
+    s = (q @ k.transpose(-1, -2)) / 8.0
+    Sq, Sk = q.shape[2], k.shape[2]
+    mask = torch.zeros(q.shape[0], 1, Sq, Sk, dtype=torch.bool)
+    for b, kl in enumerate(key_len):
+        mask[b, :, :, kl:] = True
+    if causal:
+        mask |= torch.triu(torch.ones(Sq, Sk, dtype=torch.bool), diagonal=1)[None, None]
+    s = s.masked_fill(mask, float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("B,H,Sq,Sk,kls,causal", [(2, 3, 150, 150, [150, 77], False), (1, 2, 130, 130, [130], True),
+                                                   (2, 2, 100, 41, [41, 41], False), (1, 1, 70, 300, [300], False)])
+def test_attention(dev, dt, B, H, Sq, Sk, kls, causal):
+    from mars5_tts_amd import _lib as L, ops
+    q, k, v = _q(_rand((B, H, Sq, 64), 1, 2.0), dt), _q(_rand((B, H, Sk, 64), 2, 2.0), dt), _q(_rand((B, H, Sk, 64), 3), dt)
+    ref = _ref_attention(q, k, v, kls, causal).permute(0, 2, 1, 3).reshape(B, Sq, H * 64)
+    Skp = (Sk + 63) // 64 * 64
+    vt = torch.zeros(B, H, 64, Skp, dtype=dt)
+    vt[..., :Sk] = v.transpose(-1, -2).to(dt)
+    qd, kd, vtd = q.to(dev, dt).contiguous(), k.to(dev, dt).contiguous(), vt.to(dev)
+    o = torch.zeros(B, Sq, H * 64, device=dev, dtype=dt)
+    kl = torch.tensor(kls, dtype=torch.int32, device=dev)
+    a = L.AttnArgs(q=qd.data_ptr(), q_bs=H * Sq * 64, q_hs=Sq * 64, q_rs=64, k=kd.data_ptr(), k_bs=H * Sk * 64, k_hs=Sk * 64, k_rs=64,
+                   vt=vtd.data_ptr(), vt_bs=H * 64 * Skp, vt_hs=64 * Skp, vt_ds=Skp, o=o.data_ptr(), o_bs=Sq * H * 64, o_rs=H * 64,
+                   B=B, H=H, Sq=Sq, Sk=Sk, key_len=kl.data_ptr(), causal=1 if causal else 0, scale=0.125, kv_index=None,
+                   kv_index_stride_k=0, kv_index_stride_v=0)
+    ops.attention(dt, a)
+    torch.cuda.synchronize()
+    r = _rel(o.float().cpu(), ref)
+    assert r < max(TOL[dt], 1e-2 if dt != torch.float32 else 1e-4), f"attention rel err {r}"
+
+
+def test_attention_kv_index(dev):
+    from mars5_tts_amd import _lib as L, ops
+    dt = torch.float32
+    T, B, H, Sq, Sk = 3, 2, 2, 50, 20
+    q = _rand((B, H, Sq, 64), 1)
+    k, v = _rand((T, B, H, Sk, 64), 2), _rand((T, B, H, Sk, 64), 3)
+    vt = torch.zeros(T, B, H, 64, 64)
+    vt[..., :Sk] = v.transpose(-1, -2)
+    qd, kd, vtd = q.to(dev), k.to(dev), vt.to(dev)
+    o = torch.zeros(B, Sq, H * 64, device=dev)
+    step = torch.tensor([2], dtype=torch.int32, device=dev)
+    a = L.AttnArgs(q=qd.data_ptr(), q_bs=H * Sq * 64, q_hs=Sq * 64, q_rs=64, k=kd.data_ptr(), k_bs=H * Sk * 64, k_hs=Sk * 64, k_rs=64,
+                   vt=vtd.data_ptr(), vt_bs=H * 64 * 64, vt_hs=64 * 64, vt_ds=64, o=o.data_ptr(), o_bs=Sq * H * 64, o_rs=H * 64,
+                   B=B, H=H, Sq=Sq, Sk=Sk, key_len=None, causal=0, scale=0.125, kv_index=step.data_ptr(),
+                   kv_index_stride_k=B * H * Sk * 64, kv_index_stride_v=B * H * 64 * 64)
+    ops.attention(dt, a)
+    torch.cuda.synchronize()
+    ref = _ref_attention(q, k[2], v[2], [Sk, Sk], False).permute(0, 2, 1, 3).reshape(B, Sq, H * 64)
+    assert _rel(o.cpu(), ref) < 1e-4
+
+
+# ------------------------------------------------------------------------------ gathers / rope
+def test_gather_and_chunked(dev):
+    from mars5_tts_amd import ops
+    from mars5_tts_amd.tables import sine_pe
+    D, R = 128, 9
+    table = _rand((50, D), 1)
+    idx = torch.tensor([3, 49, 0, 7, 7, 12, 1, 2, 30])
+    pe = sine_pe(40, D)
+    alpha = torch.tensor([0.7])
+    add = _rand((4, D), 2)
+    pos = torch.tensor([0, 1, 2, 0, 1, 2, 5, 6, 7], dtype=torch.int32)
+    aidx = torch.tensor([0, 0, 0, 1, 1, 1, 3, 3, 3], dtype=torch.int32)
+    out = torch.zeros(R, D, device=dev)
+    ops.gather_rows(out, table.to(dev), idx.to(dev), alpha.to(dev), pe.to(dev), pos.to(dev), add.to(dev), aidx.to(dev))
+    torch.cuda.synchronize()
+    ref = table[idx] * 1.0 + alpha * pe[pos.long()] + add[aidx.long()]
+    assert torch.equal(out.cpu(), ref), float((out.cpu() - ref).abs().max())
+    tables = _rand((8, 1025, D // 8), 3)
+    codes = torch.randint(0, 1025, (R - 1, 8), generator=torch.Generator().manual_seed(4))
+    lead = _rand((1, D), 5)
+    o2 = torch.zeros(2, R, D, device=dev)
+    si = torch.tensor([2], dtype=torch.int32, device=dev)
+    ops.chunked_embed(o2, tables.to(dev), codes.to(dev), lead.to(dev), alpha.to(dev), pe.to(dev), add.to(dev), si)
+    torch.cuda.synchronize()
+    body = torch.cat([tables[q][codes[:, q]] for q in range(8)], dim=-1)
+    ref2 = torch.cat([lead, body]) * 1.0 + alpha * pe[:R] + add[2]
+    assert torch.equal(o2[0].cpu(), ref2) and torch.equal(o2[1].cpu(), ref2)
+
+
+@pytest.mark.parametrize("dt", DTS)
+def test_rope_cache(dev, dt):
+    import mars5_oracle as O
+    from mars5_tts_amd import ops
+    from mars5_tts_amd.tables import rope_table
+    M, H, W = 21, 3, 32
+    D = H * 64
+    qkv = _q(_rand((M, 3 * D), 1), dt)
+    rope = rope_table(64, 64)
+    fc = O.precompute_freqs_cis(64, M)
+    qr = O.apply_rotary(qkv[:, :D].view(M, H, 64), fc)
+    kr = O.apply_rotary(qkv[:, D:2 * D].view(M, H, 64), fc)
+    q = torch.zeros(H, M, 64, device=dev, dtype=dt)
+    kc = torch.zeros(H, W, 64, device=dev, dtype=dt)
+    vc = torch.zeros(H, W, 64, device=dev, dtype=dt)
+    vt = torch.zeros(H, 64, 64, device=dev, dtype=dt)
+    ops.rope_cache(qkv.to(dev, dt), H, 0, rope.to(dev), q, kc, vc, W * 64, W, vt, 64 * 64, 64)
+    torch.cuda.synchronize()
+    tol = 1e-6 if dt == torch.float32 else 8e-3
+    assert _rel(q.float().cpu(), qr.permute(1, 0, 2)) < tol
+    assert _rel(kc.float().cpu()[:, :M], kr.permute(1, 0, 2)) < tol
+    assert torch.equal(vc.float().cpu()[:, :M], qkv[:, 2 * D:].view(M, H, 64).permute(1, 0, 2))
+    assert torch.equal(vt.float().cpu()[:, :, :M], qkv[:, 2 * D:].view(M, H, 64).permute(1, 2, 0))
+
+
+# ------------------------------------------------------------------------------ decode kernels
+@pytest.mark.parametrize("dt", DTS)
+def test_ar_gemv_variants(dev, dt):
+    import mars5_oracle as O
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.blocks import interleave_rows
+    from mars5_tts_amd.tables import rope_table
+    H, F = 3, 448
+    D = H * 64
+    tol = max(TOL[dt] * 2, 1e-2 if dt != torch.float32 else 0)
+    x = _rand((D,), 1, 2.0)
+    nw = 1 + _rand((D,), 2, 0.1)
+    xn = _q(O.rmsnorm(x[None], nw, 1e-5)[0], dt)
+    state = torch.tensor([5, 0, 0, 5, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+    # --- RMS + QKV + RoPE + cache write at pos 5
+    wqkv = _q(_rand((3 * D, D), 3, 0.1), dt)
+    rope = rope_table(64, 16)
+    W = 12
+    kc = torch.zeros(H, W, 64, device=dev, dtype=dt)
+    vc = torch.zeros(H, W, 64, device=dev, dtype=dt)
+    qb = torch.zeros(D, device=dev, dtype=dt)
+    keep = [x.to(dev), nw.to(dev), wqkv.to(dev, dt), rope.to(dev)]
+    a = L.GemvArgs(W=keep[2].data_ptr(), ldw=D, N=3 * D, K=D, x_f32=keep[0].data_ptr(), norm_w=keep[1].data_ptr(), eps=1e-5,
+                   rope=keep[3].data_ptr(), state=state.data_ptr(), kcache=kc.data_ptr(), vcache=vc.data_ptr(), qbuf=qb.data_ptr(),
+                   w_alloc=W, window=3000, dim=D)
+    ops.ar_gemv(dt, L.PRO_RMS, L.GEPI_QKV_ROPE, a)
+    torch.cuda.synchronize()
+    y = _q(wqkv @ xn, dt)
+    fc = O.precompute_freqs_cis(64, 6)[5:6]
+    qr = O.apply_rotary(y[:D].view(1, H, 64), fc)[0]
+    kr = O.apply_rotary(y[D:2 * D].view(1, H, 64), fc)[0]
+    assert _rel(qb.float().cpu().view(H, 64), qr) < tol
+    assert _rel(kc.float().cpu()[:, 5], kr) < tol
+    assert _rel(vc.float().cpu()[:, 5], y[2 * D:].view(H, 64)) < tol
+    assert float(kc[:, :5].abs().max()) == 0 and float(kc[:, 6:].abs().max()) == 0
+    # --- RMS + SwiGLU
+    w1, w3 = _q(_rand((F, D), 4, 0.1), dt), _q(_rand((F, D), 5, 0.1), dt)
+    hb = torch.zeros(F, device=dev, dtype=dt)
+    w13 = interleave_rows(w1, w3).to(dev, dt)
+    a = L.GemvArgs(W=w13.data_ptr(), ldw=D, N=2 * F, K=D, x_f32=keep[0].data_ptr(), norm_w=keep[1].data_ptr(), eps=1e-5,
+                   y_dt=hb.data_ptr(), state=state.data_ptr())
+    ops.ar_gemv(dt, L.PRO_RMS, L.GEPI_SWIGLU, a)
+    torch.cuda.synchronize()
+    href = torch.nn.functional.silu(w1 @ xn) * (w3 @ xn)
+    assert _rel(hb.float().cpu(), href) < tol
+    # --- DT + residual  (w2)
+    w2 = _q(_rand((D, F), 6, 0.1), dt)
+    hq = _q(href, dt)
+    xr = x.clone().to(dev)
+    w2d, hd = w2.to(dev, dt), hq.to(dev, dt)
+    a = L.GemvArgs(W=w2d.data_ptr(), ldw=F, N=D, K=F, x_dt=hd.data_ptr(), xres=xr.data_ptr(), state=state.data_ptr())
+    ops.ar_gemv(dt, L.PRO_DT, L.GEPI_RESIDUAL, a)
+    torch.cuda.synchronize()
+    assert _rel(xr.cpu() - x, w2 @ hq) < tol
+    # --- RMS + logits
+    V = 1376
+    wo = _q(_rand((V, D), 7, 0.2), dt)
+    lg = torch.zeros(V, device=dev)
+    wod = wo.to(dev, dt)
+    a = L.GemvArgs(W=wod.data_ptr(), ldw=D, N=V, K=D, x_f32=keep[0].data_ptr(), norm_w=keep[1].data_ptr(), eps=1e-5,
+                   y_f32=lg.data_ptr(), state=state.data_ptr())
+    ops.ar_gemv(dt, L.PRO_RMS, L.GEPI_F32, a)
+    torch.cuda.synchronize()
+    assert _rel(lg.cpu(), wo @ xn) < TOL[dt] * 2
+    # --- done flag makes every step kernel a no-op
+    state[L.ST_DONE] = 1
+    lg.zero_()
+    ops.ar_gemv(dt, L.PRO_RMS, L.GEPI_F32, a)
+    torch.cuda.synchronize()
+    assert float(lg.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTS)
+@pytest.mark.parametrize("pos,W,window", [(0, 40, 3000), (37, 64, 3000), (700, 800, 3000), (95, 32, 32)])
+def test_attn_decode_and_combine(dev, dt, pos, W, window):
+    from mars5_tts_amd import _lib as L, ops
+    H, NS = 3, 8
+    D = H * 64
+    n_valid = min(pos + 1, window)
+    q = _q(_rand((H, 64), 1, 2.0), dt)
+    k, v = _q(_rand((H, W, 64), 2, 2.0), dt), _q(_rand((H, W, 64), 3), dt)
+    s = torch.einsum("hd,hnd->hn", q, k[:, :n_valid]) / 8.0
+    ref = torch.einsum("hn,hnd->hd", torch.softmax(s, -1), v[:, :n_valid]).reshape(D)
+    state = torch.tensor([pos, 0, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+    qd, kd, vd = q.reshape(D).to(dev, dt), k.to(dev, dt), v.to(dev, dt)
+    part = torch.zeros(H, NS, L.ATTN_PART, device=dev)
+    a = L.AttnDecodeArgs(qbuf=qd.data_ptr(), kcache=kd.data_ptr(), vcache=vd.data_ptr(), part=part.data_ptr(), state=state.data_ptr(),
+                         n_heads=H, w_alloc=W, window=window, nsplit=NS, scale=0.125)
+    ops.ar_attn_decode(dt, a)
+    # combine through the wo-GEMV prologue with W = identity
+    eye = torch.eye(D).to(dev, dt)
+    xr = torch.zeros(D, device=dev)
+    g = L.GemvArgs(W=eye.data_ptr(), ldw=D, N=D, K=D, part=part.data_ptr(), nsplit=NS, n_heads=H, xres=xr.data_ptr(), state=state.data_ptr())
+    ops.ar_gemv(dt, L.PRO_ATTN, L.GEPI_RESIDUAL, g)
+    torch.cuda.synchronize()
+    r = _rel(xr.cpu(), ref)
+    assert r < max(TOL[dt], 5e-3 if dt != torch.float32 else 1e-5), f"decode attention rel err {r}"
+
+
+def test_ar_sampler_golden_cases(dev, gold_dir):
+    """Device sampler chain vs the reference function chain (fixtures from the reference)."""
+    import mars5_oracle as O
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.tables import eos_penalty_table
+    fx = np.load(os.path.join(gold_dir, "sampler_cases.npz"), allow_pickle=True)
+    n_text, eos = int(fx["n_text"]), int(fx["eos_idx"])
+    V = fx["logits"].shape[1]
+    D = 64
+    embed = _rand((V, D), 1).to(dev)
+    n_checked = 0
+    for i in range(fx["logits"].shape[0]):
+        c = json.loads(str(fx["cfg"][i]))
+        if c["typical_p"] <= 0.999:
+            continue
+        prev = [int(t) for t in fx["prev"][i]]
+        n_est = int(fx["n_est"][i])
+        P = 5
+        tokens = torch.zeros(P + len(prev) + 4, dtype=torch.int64)
+        tokens[P:P + len(prev)] = torch.tensor(prev, dtype=torch.int64)
+        tokens = tokens.to(dev)
+        state = torch.tensor([P + len(prev), len(prev), 0, P + len(prev), -1, 0, 0, 0], dtype=torch.int32, device=dev)
+        noise = torch.ones(len(prev) + 1, V)
+        noise[len(prev)] = torch.from_numpy(fx["q"][i])
+        noise = noise.to(dev)
+        tab = eos_penalty_table(n_est, c["dec"], c["fac"]).to(dev)
+        logits = torch.from_numpy(fx["logits"][i]).to(dev)
+        xres = torch.zeros(D, device=dev)
+        a = L.SampleArgs(logits=logits.data_ptr(), V=V, state=state.data_ptr(), tokens=tokens.data_ptr(), max_len=10 ** 6,
+                         alpha_frequency=c["af"], alpha_presence=c["ap"], penalty_window=c["win"], n_text=n_text, eos_idx=eos,
+                         n_est=n_est, eos_table=tab.data_ptr(), temperature=c["temperature"], div_mode=0, top_k=c["topk"],
+                         top_p=c["top_p"], noise=noise.data_ptr(), noise_stride=V, embed=embed.data_ptr(), dim=D, xres=xres.data_ptr())
+        ops.ar_sample(a)
+        torch.cuda.synchronize()
+        st = state.cpu()
+        tok = int(fx["tok"][i])
+        assert int(st[L.ST_LAST]) == tok, f"case {i}: device token {int(st[L.ST_LAST])} != reference {tok}"
+        if tok == eos:
+            assert int(st[L.ST_DONE]) == 1
+        else:
+            assert int(st[L.ST_NGEN]) == len(prev) + 1 and int(tokens[P + len(prev)]) == tok
+            assert torch.equal(xres.cpu(), embed[tok].cpu())
+        n_checked += 1
+    assert n_checked >= 9
+
+
+def test_ar_sampler_random_vs_oracle(dev):
+    """More sampler cases than the fixtures hold: random logits vs the CPU oracle, incl. V = 4096."""
+    import mars5_oracle as O
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.tables import eos_penalty_table
+    g = torch.Generator().manual_seed(5)
+    for V, n_text in [(4096, 3071), (1376, 288), (3000, 500)]:
+        eos = V - 1
+        embed = torch.zeros(V, 64, device=dev)
+        for trial in range(6):
+            cfg = [dict(t=0.7, k=100, p=0.2), dict(t=1.0, k=0, p=1.0), dict(t=0.7, k=100, p=1.0), dict(t=0.9, k=5, p=0.5),
+                   dict(t=0.7, k=1, p=0.2), dict(t=1.3, k=4000, p=0.97)][trial]
+            logits = torch.randn(V, generator=g) * 2.5
+            n_prev = [0, 3, 90, 120, 2, 40][trial]
+            prev = torch.randint(n_text - 1, V - 1, (n_prev,), generator=g).tolist()
+            q = torch.empty(V).exponential_(1, generator=g)
+            p = O.ARSamplingParams(cfg["t"], cfg["k"], cfg["p"], 1.0, 3.0, 0.4, 100, 0.5, 1.0, 30)
+            z = O.filter_logits(logits, prev, p, n_text, eos)
+            tok = O.draw_token(z, q)
+            P = 3
+            tokens = torch.zeros(P + n_prev + 2, dtype=torch.int64)
+            tokens[P:P + n_prev] = torch.tensor(prev, dtype=torch.int64)
+            tokens = tokens.to(dev)
+            state = torch.tensor([P + n_prev, n_prev, 0, P + n_prev, -1, 0, 0, 0], dtype=torch.int32, device=dev)
+            noise = torch.ones(n_prev + 1, V)
+            noise[n_prev] = q
+            noise = noise.to(dev)
+            tab = eos_penalty_table(30, 0.5, 1.0).to(dev)
+            ld = logits.to(dev)
+            xres = torch.zeros(64, device=dev)
+            a = L.SampleArgs(logits=ld.data_ptr(), V=V, state=state.data_ptr(), tokens=tokens.data_ptr(), max_len=10 ** 6,
+                             alpha_frequency=3.0, alpha_presence=0.4, penalty_window=100, n_text=n_text, eos_idx=eos, n_est=30,
+                             eos_table=tab.data_ptr(), temperature=cfg["t"], div_mode=0, top_k=cfg["k"], top_p=cfg["p"],
+                             noise=noise.data_ptr(), noise_stride=V, embed=embed.data_ptr(), dim=64, xres=xres.data_ptr())
+            ops.ar_sample(a)
+            torch.cuda.synchronize()
+            assert int(state[L.ST_LAST]) == tok, f"V={V} trial {trial}: {int(state[L.ST_LAST])} != {tok}"
+
+
+def test_nar_sample_vs_oracle(dev):
+    """Fused posterior/sample kernel vs the oracle's reverse_step on identical logits and
+    uniforms: integer outputs, exact up to libm-ulp near-ties (bound: <= 2 of ~5k rows)."""
+    import mars5_oracle as O
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.tables import log_eps, nar_step_consts
+    S, Q, K, off = 70, 8, 1025, 20
+    g = torch.Generator().manual_seed(11)
+    tb = O.diffusion_tables(K, 200)
+    times = [199, 150, 21, 20, 1, 0]
+    consts = nar_step_consts(times, K).to(dev)
+    total_bad = 0
+    for si, t in enumerate(times):
+        lc = torch.randn(S - off, Q - 1, K, generator=g) * 2
+        lu = torch.randn(S - off, Q - 1, K, generator=g) * 2
+        x_t = torch.randint(0, K, (S, Q), generator=g)
+        x_known = torch.randint(0, 1024, (S, Q), generator=g)
+        m = torch.zeros(S, Q, dtype=torch.bool)
+        m[:, 0] = True
+        m[:off] = True
+        u1, u2 = torch.rand(S, Q, K, generator=g), torch.rand(S, Q, K, generator=g)
+        # oracle wants full-shape logits; rows it never uses (m = 1) are filled with zeros
+        fc = torch.zeros(S, Q, K)
+        fu = torch.zeros(S, Q, K)
+        fc[off:, 1:], fu[off:, 1:] = lc, lu
+        ref = O.reverse_step(tb, fc, fu, x_t, x_known, m, t, u1, u2 if t > 0 else None, 3.0, 0.7)
+        if 20 < t:
+            ref[:, 0] = x_known[:, 0]
+        Kp = 1028
+        lgc = torch.zeros(S - off, Q - 1, Kp)
+        lgu = torch.zeros(S - off, Q - 1, Kp)
+        lgc[..., :K], lgu[..., :K] = lc, lu
+        xd = x_t.clone().to(dev)
+        keep = [lgc.to(dev), lgu.to(dev), x_known.to(dev), m.to(torch.uint8).to(dev), u1.to(dev), u2.to(dev)]
+        step = torch.tensor([si], dtype=torch.int32, device=dev)
+        a = L.NarSampleArgs(logits_c=keep[0].data_ptr(), logits_u=keep[1].data_ptr(), ld_row=(Q - 1) * Kp, ld_q=Kp, S=S, n_q=Q, K=K,
+                            row_offset=off, x=xd.data_ptr(), x_known=keep[2].data_ptr(), m=keep[3].data_ptr(), u1=keep[4].data_ptr(),
+                            u2=keep[5].data_ptr(), consts=consts.data_ptr(), step=step.data_ptr(), guidance_w=3.0, temperature=0.7,
+                            log_eps=log_eps(), div_mode=0, q0_override_steps=20)
+        ops.nar_sample(a)
+        torch.cuda.synchronize()
+        bad = int((xd.cpu() != ref).sum())
+        total_bad += bad
+        assert bad <= 2, f"t={t}: {bad} of {S * Q} ids differ from the oracle"
+    print(f"nar_sample: {total_bad} mismatching ids over {len(times) * S * Q}")
+
+
+def test_graph_capture_replay(dev):
+    from mars5_tts_amd import ops
+    st = torch.cuda.Stream(device=dev)
+    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ops.Graph.begin(st.cuda_stream)
+    ops.add_int(cnt, 1, stream=st.cuda_stream)
+    ops.add_int(cnt, 2, stream=st.cuda_stream)
+    gr = ops.Graph().end(st.cuda_stream)
+    for _ in range(5):
+        gr.launch(st.cuda_stream)
+    st.synchronize()
+    assert int(cnt.item()) == 15
+    e0, e1 = ops.Event(), ops.Event()
+    e0.record(st.cuda_stream)
+    gr.launch(st.cuda_stream)
+    e1.record(st.cuda_stream)
+    assert e0.elapsed_ms(e1) >= 0.0
