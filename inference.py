@@ -1,0 +1,239 @@
+"""Drop-in for the reference's top-level ``inference.py``: ``InferenceConfig`` (same 21 fields and
+defaults, reference inference.py:24-77) and ``Mars5TTS`` (same constructor, ``tts``, ``vocode``,
+``get_speaker_embedding``, attributes; reference inference.py:79-307).  The AR decode loop and
+the NAR diffusion run on the MI355X engine in ``mars5-tts_amd/``; Encodec analysis and Vocos
+synthesis stay third-party modules exactly as in the reference (lazy: only needed by the
+audio-in / audio-out methods, and injectable for hosts where they are not installed).
+"""
+from __future__ import annotations
+
+import io
+import logging
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Dict, Optional, Tuple, Type, Union
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+from mars5_tts_amd.ar_generate import ar_generate
+from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_simple_inference
+from mars5_tts_amd.minbpe import GPT4_SPLIT_PATTERN, CodebookTokenizer, RegexTokenizer
+from mars5_tts_amd.model import CodecLM, ResidualTransformer
+from mars5_tts_amd.trim import trim
+
+
+@dataclass
+class InferenceConfig():
+    """ The defaults configuration variables for TTS inference. """
+    ## >>>> AR CONFIG
+    temperature: float = 0.7
+    top_k: int = 200          # 0 disables it
+    top_p: float = 0.2        # 1.0 disables it
+    typical_p: float = 1.0
+    freq_penalty: float = 3
+    presence_penalty: float = 0.4
+    rep_penalty_window: int = 80
+    eos_penalty_decay: float = 0.5
+    eos_penalty_factor: float = 1
+    eos_estimated_gen_length_factor: float = 1.0
+    ## >>>> NAR CONFIG
+    timesteps: int = 200      # unused by the reference too: T is fixed at default_T (inference.py:113,286)
+    x_0_temp: float = 0.7
+    q0_override_steps: int = 20
+    nar_guidance_w: float = 3
+    max_prompt_dur: float = 12
+    generate_max_len_override: int = -1
+    deep_clone: bool = True
+    use_kv_cache: bool = True
+    trim_db: float = 27
+    beam_width: int = 1
+    ref_audio_pad: float = 0
+
+
+class Mars5TTS:
+    def __init__(self, ar_ckpt, nar_ckpt, device: str = None, codec=None, vocos=None) -> None:
+        if device is None:
+            device = 'cuda' if torch.cuda.is_available() else 'cpu'
+        self.device = torch.device(device)
+        self.codec = codec if codec is not None else _load_encodec(self.device)
+        self.texttok = RegexTokenizer(GPT4_SPLIT_PATTERN)
+        self.texttok.load(io.BytesIO(ar_ckpt['vocab']['texttok.model'].encode('utf-8')))
+        self.speechtok = CodebookTokenizer(GPT4_SPLIT_PATTERN)
+        self.speechtok.load(io.BytesIO(ar_ckpt['vocab']['speechtok.model'].encode('utf-8')))
+        self.n_vocab = len(self.texttok.vocab) + len(self.speechtok.vocab)
+        self.n_text_vocab = len(self.texttok.vocab) + 1
+        self.diffusion_n_classes: int = 1025
+        self.codeclm = CodecLM(n_vocab=self.n_vocab, dim=1536, dim_ff_scale=7/3)
+        self.codeclm.load_state_dict(ar_ckpt['model'])
+        self.codeclm = self.codeclm.to(self.device).eval()
+        self.codecnar = ResidualTransformer(n_text_vocab=self.n_text_vocab, n_quant=self.diffusion_n_classes,
+                                            p_cond_drop=0, dropout=0)
+        self.codecnar.load_state_dict(nar_ckpt['model'])
+        self.codecnar = self.codecnar.to(self.device).eval()
+        self.default_T = 200
+        self.sr = 24000
+        self.latent_sr = 75
+        self.vocos = vocos if vocos is not None else _load_vocos(self.device)
+        self._expansion = self.speechtok.expansion_table()
+
+    # ------------------------------------------------------------------ hub loading
+    @classmethod
+    def from_pretrained(cls, model_id: str, device: str = None, revision=None, cache_dir=None, force_download=False,
+                        proxies=None, local_files_only=False, token=None, **kw) -> "Mars5TTS":
+        return cls._from_pretrained(model_id=model_id, revision=revision, cache_dir=cache_dir, force_download=force_download,
+                                    proxies=proxies, local_files_only=local_files_only, token=token, device=device, **kw)
+
+    @classmethod
+    def _from_pretrained(cls: Type["Mars5TTS"], *, model_id: str, revision: Optional[str], cache_dir: Optional[Union[str, Path]],
+                         force_download: bool, proxies: Optional[Dict], local_files_only: bool, token: Optional[Union[str, bool]],
+                         device: str = None, **model_kwargs) -> "Mars5TTS":
+        from huggingface_hub import hf_hub_download
+        from safetensors import safe_open
+        ckpts = []
+        for fname in ("mars5_ar.safetensors", "mars5_nar.safetensors"):
+            path = hf_hub_download(repo_id=model_id, filename=fname, revision=revision, cache_dir=cache_dir,
+                                   force_download=force_download, proxies=proxies, local_files_only=local_files_only, token=token)
+            ck = {'model': {}}
+            with safe_open(path, framework='pt', device='cpu') as f:
+                md = f.metadata()
+                ck['vocab'] = {'texttok.model': md['texttok.model'], 'speechtok.model': md['speechtok.model']}
+                for k in f.keys():
+                    ck['model'][k] = f.get_tensor(k)
+            ckpts.append(ck)
+        return cls(ar_ckpt=ckpts[0], nar_ckpt=ckpts[1], device=device, **model_kwargs)
+
+    # ------------------------------------------------------------------ audio ends (third party)
+    @torch.inference_mode()
+    def vocode(self, tokens: Tensor) -> Tensor:
+        """ Vocodes tokens of shape (seq_len, n_q) """
+        _need(self.vocos, "vocos")
+        tokens = tokens.T.to(self.device)
+        features = self.vocos.codes_to_features(tokens)
+        bandwidth_id = torch.tensor([1], device=self.device)
+        return self.vocos.decode(features, bandwidth_id=bandwidth_id).cpu().squeeze()[None]
+
+    @torch.inference_mode()
+    def get_speaker_embedding(self, ref_audio: Tensor) -> Tensor:
+        """ Given `ref_audio` (bs, T) audio tensor, compute the implicit speaker embedding of shape (bs, dim). """
+        _need(self.codec, "encodec")
+        if ref_audio.dim() == 1:
+            ref_audio = ref_audio[None]
+        spk_reference = self.codec.encode(ref_audio[None].to(self.device))[0][0].permute(0, 2, 1)
+        return self.codeclm.get_spk_embedding(spk_reference)
+
+    # ------------------------------------------------------------------ the hot path
+    @torch.inference_mode()
+    def tts_from_codes(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str],
+                       cfg: InferenceConfig = InferenceConfig(), ar_noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+        """``tts`` between the codec and the vocoder (reference inference.py:222-301):
+        prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out."""
+        text_tokens = self.texttok.encode("<|startoftext|>" + text.strip() + "<|endoftext|>", allowed_special='all')
+        text_tokens_full = self.texttok.encode("<|startoftext|>" + ref_transcript + ' ' + str(text).strip() + "<|endoftext|>",
+                                               allowed_special='all')
+        prompt_codec = prompt_codec.to(self.device)
+        n_speech_inp = 0
+        q0_str = ' '.join([str(t) for t in prompt_codec[0, 0].tolist()])
+        speech_tokens = self.speechtok.encode(q0_str.strip())
+        spk_ref_codec = prompt_codec[0, :, :].T
+        raw_prompt_acoustic_len = prompt_codec.shape[-1]
+        n_text = len(self.texttok.vocab)
+        offset_speech_codes = [p + n_text for p in speech_tokens]
+        if not cfg.deep_clone:
+            offset_speech_codes = offset_speech_codes[:n_speech_inp]
+        else:
+            text_tokens = text_tokens_full
+            n_speech_inp = len(offset_speech_codes)
+        prompt = torch.tensor(text_tokens + offset_speech_codes, dtype=torch.long, device=self.device)
+        first_codec_idx = prompt.shape[-1] - n_speech_inp + 1
+
+        ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, prompt, spk_ref_codec, first_codec_idx,
+                               max_len=cfg.generate_max_len_override if cfg.generate_max_len_override > 1 else 2000,
+                               fp16=True if torch.cuda.is_available() else False,
+                               temperature=cfg.temperature, topk=cfg.top_k, top_p=cfg.top_p, typical_p=cfg.typical_p,
+                               alpha_frequency=cfg.freq_penalty, alpha_presence=cfg.presence_penalty,
+                               penalty_window=cfg.rep_penalty_window, eos_penalty_decay=cfg.eos_penalty_decay,
+                               eos_penalty_factor=cfg.eos_penalty_factor, beam_width=cfg.beam_width, beam_length_penalty=1,
+                               n_phones_gen=round(cfg.eos_estimated_gen_length_factor * len(text)), vocode=False,
+                               use_kv_cache=cfg.use_kv_cache, noise=ar_noise)
+
+        # AR -> NAR hand-off: token ids -> L0 frames through the BPE expansion table
+        # (same result as speechtok.decode_int on the id list, inference.py:272-275)
+        output_tokens = (ar_codes - n_text).clamp(min=0)[first_codec_idx:].cpu().tolist()
+        frames = [c for tk in output_tokens for c in self._expansion[tk]]
+        gen_codes_decoded = torch.tensor(frames, dtype=torch.long, device=self.device)
+
+        c_text = torch.tensor(text_tokens, dtype=torch.long, device=self.device)[None]
+        c_codes = prompt_codec.permute(0, 2, 1)
+        c_texts_lengths = torch.tensor([len(text_tokens)], dtype=torch.long, device=self.device)
+        c_codes_lengths = torch.tensor([c_codes.shape[1]], dtype=torch.long, device=self.device)
+        _x = gen_codes_decoded[None, :, None].repeat(1, 1, 8)
+        x_padding_mask = torch.zeros((1, _x.shape[1]), dtype=torch.bool, device=_x.device)
+
+        T = self.default_T
+        diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
+        dsh_cfg = DSH(last_greedy=True, x_0_temp=cfg.x_0_temp, guidance_w=cfg.nar_guidance_w, deep_clone=cfg.deep_clone,
+                      jump_len=1, jump_n_sample=1, q0_override_steps=cfg.q0_override_steps,
+                      enable_kevin_scaled_inference=True, progress=False)
+        final_output = perform_simple_inference(self.codecnar, (c_text, c_codes, c_texts_lengths, c_codes_lengths, _x, x_padding_mask),
+                                                diff, diff.num_timesteps, torch.float16, dsh=dsh_cfg, retain_quant0=True)
+        skip_front = raw_prompt_acoustic_len if cfg.deep_clone else 0
+        final_output = final_output[0, skip_front:].to(self.device)
+        return gen_codes_decoded, final_output
+
+    @torch.inference_mode()
+    def tts(self, text: str, ref_audio: Tensor, ref_transcript: Optional[str] = None,
+            cfg: Optional[InferenceConfig] = InferenceConfig()) -> Tuple[Tensor, Tensor]:
+        """ Perform TTS for `text`, given a reference audio `ref_audio` (of shape [sequence_length,], sampled at 24kHz)
+        which has an associated `ref_transcript`.  Returns `ar_codes` (seq_len,) and `out_wav` (T,) at 24kHz. """
+        if cfg.deep_clone and ref_transcript is None:
+            raise AssertionError(
+                ("Inference config deep clone is set to true, but reference transcript not specified! "
+                 "Please specify the transcript of the prompt, or set deep_clone=False in the inference `cfg` argument."))
+        ref_dur = ref_audio.shape[-1] / self.sr
+        if ref_dur > cfg.max_prompt_dur:
+            logging.warning((f"Reference audio duration is {ref_dur:.2f} > max suggested ref audio. "
+                             f"Expect quality degradations. We recommend you trim prompt to be shorter than max prompt length."))
+        _need(self.codec, "encodec")
+        if ref_audio.dim() == 1:
+            ref_audio = ref_audio[None]
+        if ref_audio.shape[0] != 1:
+            ref_audio = ref_audio.mean(dim=0, keepdim=True)
+        ref_audio = F.pad(ref_audio, (int(self.sr * cfg.ref_audio_pad), 0))
+        prompt_codec = self.codec.encode(ref_audio[None].to(self.device))[0][0]
+        gen_codes_decoded, final_output = self.tts_from_codes(text, prompt_codec, ref_transcript, cfg)
+        final_audio = self.vocode(final_output).squeeze()
+        final_audio, _ = trim(final_audio.cpu(), top_db=cfg.trim_db)
+        return gen_codes_decoded, final_audio
+
+
+def _need(obj, name):
+    if obj is None:
+        raise RuntimeError(f"the third-party '{name}' model is not available on this host; install it or pass an instance "
+                           f"to Mars5TTS(..., codec=..., vocos=...)")
+
+
+def _load_encodec(device):
+    try:
+        from encodec import EncodecModel
+    except ImportError:
+        logging.warning("encodec is not installed: Mars5TTS.tts()/get_speaker_embedding() need it (tts_from_codes does not)")
+        return None
+    from mars5_tts_amd.trim import nuke_weight_norm
+    codec = EncodecModel.encodec_model_24khz().to(device).eval()
+    codec.set_target_bandwidth(6.0)
+    nuke_weight_norm(codec)
+    return codec
+
+
+def _load_vocos(device):
+    try:
+        from vocos import Vocos
+    except ImportError:
+        logging.warning("vocos is not installed: Mars5TTS.tts()/vocode() need it (tts_from_codes does not)")
+        return None
+    from mars5_tts_amd.trim import nuke_weight_norm
+    vocos = Vocos.from_pretrained("charactr/vocos-encodec-24khz").to(device).eval()
+    nuke_weight_norm(vocos)
+    return vocos
