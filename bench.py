@@ -1,0 +1,294 @@
+#!/usr/bin/env python
+"""bench.py -- MARS5 hot-path throughput on MI355X.
+
+python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+
+A "step" is one utterance through the hot path ``Mars5TTS.tts_from_codes`` (= ``tts()`` between
+the Encodec encoder and the Vocos decoder): prompt tokens + reference codes in -> AR prefill +
+decode loop -> BPE expansion -> 200-step NAR diffusion -> final (S_out, 8) codec codes out.
+Workload = BASELINE.json configs[1]: single utterance, deep clone, temperature 0.7, top_k 100,
+bf16 operands, synthetic 6 s / 24 kHz reference (450 frames), ~20-token text + ~20-token
+transcript, 450 generated frames, seeded random weights of the real geometry (n_vocab 4096).
+Each rank processes its own utterances (replicas; no data-path collective), weak scaling.
+One JSON line on rank 0; ``value`` = generated audio seconds per wall second over all ranks.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+TEXT = "The quick brown rat jumped over the lazy dogs twice."
+TRANSCRIPT = "We actually haven't managed to meet demand this year."
+PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md dense peaks
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default=os.environ.get("MARS5_DTYPE", "bf16"), choices=["bf16", "f16", "f32"])
+    ap.add_argument("--ref-frames", type=int, default=450)
+    ap.add_argument("--n-gen", type=int, default=450)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    return ap.parse_args()
+
+
+def build_model(dtype_name: str, dev):
+    from inference import Mars5TTS
+    from mars5_tts_amd import synth
+    from mars5_tts_amd.ops import DT_NAME
+    bundle = synth.make_bundle("full", seed=0)
+    m = Mars5TTS(bundle.ar_ckpt, bundle.nar_ckpt, device=str(dev), codec=False, vocos=False)
+    m.codeclm.set_engine_dtype(DT_NAME[dtype_name])
+    m.codecnar.set_engine_dtype(DT_NAME[dtype_name])
+    m.codeclm.engine()
+    m.codecnar.engine()
+    return m, bundle
+
+
+def make_cfg(n_text_tokens_hint: int, p_len: int, n_gen: int):
+    from inference import InferenceConfig
+    # README sampling settings (reference README.md:122-123); output length is forced through
+    # generate_max_len_override and an EOS penalty that stays on for the whole utterance
+    # (random weights would otherwise emit <|endofspeech|> at random).
+    return InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
+                           generate_max_len_override=p_len + n_gen, eos_estimated_gen_length_factor=100.0,
+                           eos_penalty_factor=50.0, eos_penalty_decay=0.5)
+
+
+def prompt_len(m, ref_codes, deep=True):
+    tt = m.texttok.encode("<|startoftext|>" + TRANSCRIPT + ' ' + TEXT.strip() + "<|endoftext|>", allowed_special='all')
+    st = m.speechtok.encode(' '.join(str(t) for t in ref_codes[0, 0].tolist()))
+    return len(tt) + len(st), len(tt)
+
+
+def run_utterance(m, ref_codes, cfg, seed):
+    torch.manual_seed(seed)
+    t0 = time.perf_counter()
+    gen, final = m.tts_from_codes(TEXT, ref_codes, TRANSCRIPT, cfg)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, int(final.shape[0]), int(gen.shape[0])
+
+
+# ------------------------------------------------------------------------------------ roofline
+def roofline_leg(m, ref_codes, cfg, dtype_name):
+    """Per-kernel HIP-event timings on the engine's own stream, same shapes as the timed
+    region: an eager (un-captured) replay of NAR reverse steps with an event pair around every
+    GEMM / attention launch, plus the event-timed AR decode graph replays of the last utterance."""
+    from mars5_tts_amd import ar_engine, nar_engine, ops
+    from mars5_tts_amd import _lib as L
+    from mars5_tts_amd.nar_engine import NARConfig, NARSession
+    eng = m.codecnar.engine()
+    dev = eng.dev
+    ns = dict(nar_engine.LAST_STATS)
+    ars = dict(ar_engine.LAST_STATS)
+    S, s_out, Le = ns["S"], ns["s_out"], ns["Le"]
+    off = S - s_out
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 1025, (S, 8), generator=g)
+    c_text = torch.randint(0, eng.shape.n_text_vocab, (Le - 1,), generator=g)
+    sess = NARSession(eng, NARConfig(T=200))
+    z = torch.zeros(S, 8, dtype=torch.long)
+    mm = torch.zeros(S, 8, dtype=torch.uint8)
+    mm[:, 0] = 1
+    mm[:off] = 1
+    sess.prepare(c_text, ref_codes[0].T.contiguous(), x, z, mm, off, [199, 150, 100, 50])
+    st = sess.stream.cuda_stream
+    rec = []
+    orig_gemm, orig_attn = ops.gemm, ops.attention
+
+    def gemm_spy(a, w, out, epi, **kw):
+        e0, e1 = ops.Event(), ops.Event()
+        e0.record(st)
+        orig_gemm(a, w, out, epi, **kw)
+        e1.record(st)
+        Mv = kw.get("M") or a.shape[-2]
+        rec.append(("gemm", epi, 2.0 * Mv * w.shape[-2] * w.shape[-1] * kw.get("batch", 1), e0, e1, (Mv, w.shape[-2], w.shape[-1])))
+
+    def attn_spy(dt, args, **kw):
+        e0, e1 = ops.Event(), ops.Event()
+        e0.record(st)
+        orig_attn(dt, args, **kw)
+        e1.record(st)
+        rec.append(("attn", args.Sk, 4.0 * args.B * args.H * args.Sq * args.Sk * 64, e0, e1, (args.Sq, args.Sk)))
+
+    ops.gemm, ops.attention = gemm_spy, attn_spy
+    try:
+        for _ in range(3):
+            sess.enqueue_forward(st)
+            ops.add_int(sess.step_ptr, 1, stream=st)
+        sess.stream.synchronize()
+    finally:
+        ops.gemm, ops.attention = orig_gemm, orig_attn
+    names = {L.EPI_F32: "gemm_kernel<T,EPI_F32> (heads)", L.EPI_RESIDUAL: "gemm_kernel<T,EPI_RESIDUAL>",
+             L.EPI_SWIGLU: "gemm_kernel<T,EPI_SWIGLU>", L.EPI_QKV: "gemm_kernel<T,EPI_QKV>"}
+    agg = {}
+    for kind, key, flops, e0, e1, shp in rec:
+        nm = names.get(key, f"gemm epi {key}") if kind == "gemm" else ("attn_kernel<T> self" if key > 64 * 4 else "attn_kernel<T> cross")
+        a = agg.setdefault(nm, dict(ms=0.0, flops=0.0, n=0, shape=shp))
+        a["ms"] += e0.elapsed_ms(e1)
+        a["flops"] += flops
+        a["n"] += 1
+    kernels = {k: dict(launches=v["n"], avg_us=round(1e3 * v["ms"] / v["n"], 2), tflops=round(v["flops"] / v["ms"] / 1e9, 1),
+                       example_shape=list(v["shape"])) for k, v in agg.items()}
+    peak = PEAK_MFMA_TFLOPS[dtype_name]
+    dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
+    roof = dict(bound="mfma", kernel=dom[0], achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                traffic=None, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_timed=dom[1]["n"])
+    # NAR loop as a whole (graph replay + RNG + sample kernel), from the last timed utterance
+    step_ms = ns["loop_ms"] / ns["steps"]
+    nar = dict(ms_per_step=round(step_ms, 3), tflops=round(eng.flops_per_step(S, Le, s_out) / step_ms / 1e9, 1), S=S, Le=Le)
+    # AR decode: algorithmic bytes per token (weights once + KV read/write) / event-timed step
+    ae = m.codeclm.engine()
+    es = 2 if dtype_name != "f32" else 4
+    kv_per_pos = ae.shape.n_layers * ae.shape.nhead * 64 * 2 * es
+    avg_len = (ars["prefill_len"] + ars["final_len"]) / 2.0
+    bytes_tok = ae.weight_bytes_per_token() + kv_per_pos * (avg_len + 1)
+    tok_ms = ars["decode_ms"] / max(ars["n_generated"] - 1, 1)
+    gbs = bytes_tok / tok_ms / 1e6
+    ar = dict(bound="hbm", kernel="AR decode step (132 launches, hipGraph)", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+              frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_token=int(bytes_tok), us_per_token=round(1e3 * tok_ms, 1))
+    return roof, ar, nar, kernels
+
+
+# ------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen):
+    """The oracle (a torch-CPU restatement of the reference path, incl. the reference's
+    per-token speaker-encoder recompute and per-forward NAR speaker encoders so the COST is the
+    reference's) on a bounded sample, extrapolated linearly: prefill + 8 decode tokens of the
+    AR stage and 1 reverse step of the NAR stage at the bench shapes."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mars5_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    p_len, _ = prompt_len(m, ref_codes)
+    tt = m.texttok.encode("<|startoftext|>" + TRANSCRIPT + ' ' + TEXT.strip() + "<|endoftext|>", allowed_special='all')
+    sp = m.speechtok.encode(' '.join(str(t) for t in ref_codes[0, 0].tolist()))
+    n_text = len(m.texttok.vocab)
+    prompt = torch.tensor(tt + [s + n_text for s in sp], dtype=torch.long)
+    ref = ref_codes[0].T.contiguous().cpu()
+    sd_ar, sd_nar = bundle.ar_ckpt["model"], bundle.nar_ckpt["model"]
+    nh = bundle.ar_shape.nhead
+    p = O.ARSamplingParams(temperature=0.7, top_k=100, top_p=0.2, alpha_frequency=3, alpha_presence=0.4, penalty_window=100,
+                           eos_penalty_decay=0.5, eos_penalty_factor=50.0, n_phones_gen=round(100.0 * len(TEXT)))
+    n_tok = 8
+    with torch.inference_mode():
+        g = torch.Generator().manual_seed(0)
+        t0 = time.perf_counter()
+        O.ar_generate_oracle(sd_ar, nh, bundle.n_text, bundle.n_speech, m.speechtok.special_tokens['<|endofspeech|>'], prompt, ref,
+                             prompt.shape[0] + 1, p, generator=g, recompute_spk=True)
+        t_prefill = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        O.ar_generate_oracle(sd_ar, nh, bundle.n_text, bundle.n_speech, m.speechtok.special_tokens['<|endofspeech|>'], prompt, ref,
+                             prompt.shape[0] + 1 + n_tok, p, generator=g, recompute_spk=True)
+        t_tok = (time.perf_counter() - t0 - t_prefill) / n_tok
+        x_l0 = torch.randint(0, 1024, (ref.shape[0] - 1 + n_gen,), generator=g)
+        t0 = time.perf_counter()
+        O.perform_simple_inference_oracle(sd_nar, bundle.nar_shape.nhead, torch.tensor(tt), ref, x_l0,
+                                          O.NARParams(T=200, deep_clone=True), generator=g, n_steps=1, hoist=False)
+        t_step = time.perf_counter() - t0
+    total = t_prefill + n_gen * t_tok + 200 * t_step
+    audio_s = (n_gen - 1) / 75.0
+    return dict(value=round(audio_s / total, 5), unit="audio_s/s", cores=cores, kind="port",
+                sample=(f"oracle/mars5_oracle.py (torch-CPU fp32 port of the reference path, reference cost model) on this host: "
+                        f"AR prefill P={prompt.shape[0]} {t_prefill:.2f}s + {n_tok} decode tokens {t_tok:.3f}s/token, NAR 1 of 200 reverse steps "
+                        f"at S={ref.shape[0] + x_l0.shape[0]} {t_step:.2f}s; extrapolated to {n_gen} tokens + 200 steps = {total:.0f}s/utterance"))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+    from mars5_tts_amd import synth
+    m, bundle = build_model(args.dtype, dev)
+    ref_codes = synth.make_ref_codes(args.ref_frames, seed=7).to(dev)
+    p_len, n_text_tok = prompt_len(m, ref_codes)
+    cfg = make_cfg(n_text_tok, p_len, args.n_gen)
+    if args.no_graph:
+        import mars5_tts_amd.ar_engine as ae
+        import mars5_tts_amd.nar_engine as ne
+        _d, _r = ae.ARSession.decode, ne.NARSession.run
+        ae.ARSession.decode = lambda self, use_graph=True, poll=32: _d(self, False, poll)
+        ne.NARSession.run = lambda self, uniform, use_graph=True, n_steps=None: _r(self, uniform, False, n_steps)
+
+    for i in range(args.warmup):
+        run_utterance(m, ref_codes, cfg, 500 + i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    lat, frames = [], 0
+    for i in range(args.steps):
+        dt, n_out, _ = run_utterance(m, ref_codes, cfg, 1000 + rank * 10007 + i)
+        lat.append(dt)
+        frames += n_out
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, frames = float(tmax[0]), float(t[1])
+        lats = [None] * world
+        dist.all_gather_object(lats, lat)
+        lat = [x for l in lats for x in l]
+    audio_s = frames / 75.0
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    out = {
+        "metric": "generated audio seconds/sec (RTF), deep-clone", "value": round(audio_s / elapsed, 4), "unit": "audio_s/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "p50_latency_s": round(statistics.median(lat), 4),
+        "config": {"workload": "BASELINE configs[1]: single utterance deep-clone, temperature=0.7 top_k=100, 6 s / 450-frame synthetic "
+                               "reference, ~20-token text + transcript, 450 generated frames, 200 DDPM steps x CFG, seeded random weights "
+                               "(AR 1536d x 26L n_vocab 4096, NAR 1024d 8+16L)",
+                   "ar_prompt_tokens": p_len, "generated_frames_per_utterance": frames / (args.steps * world),
+                   "parallelism": f"replicas x{world} (one utterance stream per GPU, no data-path collective)",
+                   "hipgraph": not args.no_graph},
+    }
+    if not args.no_roofline:
+        roof, ar_roof, nar, kernels = roofline_leg(m, ref_codes, cfg, args.dtype)
+        from mars5_tts_amd import ar_engine
+        out["roofline"] = roof
+        out["roofline_ar_decode"] = ar_roof
+        out["nar_loop"] = nar
+        out["kernels"] = kernels
+        out["time_split_ms"] = {"ar_decode": round(ar_engine.LAST_STATS["decode_ms"], 1), "nar_loop": round(nar["ms_per_step"] * 200, 1)}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_leg(m, bundle, ref_codes, cfg, args.n_gen)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

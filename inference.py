@@ -57,7 +57,7 @@ class Mars5TTS:
         if device is None:
             device = 'cuda' if torch.cuda.is_available() else 'cpu'
         self.device = torch.device(device)
-        self.codec = codec if codec is not None else _load_encodec(self.device)
+        self.codec = codec if codec is not None else _load_encodec(self.device)   # pass False to skip loading
         self.texttok = RegexTokenizer(GPT4_SPLIT_PATTERN)
         self.texttok.load(io.BytesIO(ar_ckpt['vocab']['texttok.model'].encode('utf-8')))
         self.speechtok = CodebookTokenizer(GPT4_SPLIT_PATTERN)
@@ -209,7 +209,7 @@ class Mars5TTS:
 
 
 def _need(obj, name):
-    if obj is None:
+    if obj is None or obj is False:
         raise RuntimeError(f"the third-party '{name}' model is not available on this host; install it or pass an instance "
                            f"to Mars5TTS(..., codec=..., vocos=...)")
 

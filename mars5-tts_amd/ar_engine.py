@@ -27,6 +27,7 @@ from .synth import ARShape
 from .tables import eos_penalty_table, rope_table
 
 NSPLIT = 8
+LAST_STATS: dict = {}     # filled by ARSession.decode: HIP-event timings of the last utterance
 
 
 @dataclass
@@ -228,6 +229,8 @@ class ARSession:
         budget = min(self.max_len - self.P - 1, self.n_noise - 1)
         if use_graph and self.graph is None and budget > 0:
             self.capture()
+        ev0, ev1 = ops.Event(), ops.Event()
+        ev0.record(st)
         done = 0
         while done < budget:
             n = min(poll, budget - done)
@@ -242,6 +245,9 @@ class ARSession:
                 flag = self.state.cpu()                        # syncs this stream only
             if int(flag[L.ST_DONE]):
                 break
+        ev1.record(st)
         self.stream.synchronize()
         n_tok = int(self.state[L.ST_NTOK].item())
+        LAST_STATS.update(decode_ms=ev0.elapsed_ms(ev1), decode_steps_launched=done, n_generated=n_tok - self.P,
+                          prefill_len=self.P + 1, final_len=n_tok)
         return self.tokens[:n_tok].clone()

@@ -35,6 +35,9 @@ from .synth import NARShape
 from .tables import log_eps, nar_step_consts, reverse_schedule, sine_pe, timestep_inputs
 
 
+LAST_STATS: dict = {}     # filled by NARSession.run: HIP-event timings of the last utterance
+
+
 class NARModel:
     def __init__(self, sd: Dict[str, torch.Tensor], shape: NARShape, dtype: torch.dtype, device, max_frames: int = 6000):
         self.shape, self.dt, self.dev = shape, dtype, torch.device(device)
@@ -232,7 +235,12 @@ class NARSession:
 
     def run(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True, n_steps: Optional[int] = None) -> torch.Tensor:
         n = len(self.times) if n_steps is None else n_steps
+        st = self.stream.cuda_stream
+        ev0, ev1 = ops.Event(), ops.Event()
+        ev0.record(st)
         for _ in range(n):
             self.step(uniform, use_graph)
+        ev1.record(st)
         self.stream.synchronize()
+        LAST_STATS.update(loop_ms=ev0.elapsed_ms(ev1), steps=n, S=self.S, s_out=self.s_out, Le=self.mems[0].Le, nb=self.nb)
         return self.x
