@@ -166,16 +166,15 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen):
+def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=40.0):
     """The oracle (a torch-CPU restatement of the reference path, incl. the reference's
-    per-token speaker-encoder recompute and per-forward NAR speaker encoders so the COST is the
-    reference's) on a bounded sample, extrapolated linearly: prefill + 8 decode tokens of the
-    AR stage and 1 reverse step of the NAR stage at the bench shapes."""
+    per-token speaker-encoder recompute and per-forward NAR speaker encoder so the COST is the
+    reference's) on a bounded sample of the same workload, extrapolated linearly:
+    AR prefill + a few decode tokens, and one NAR forward (x2 for CFG) at the bench shapes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mars5_oracle as O
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)       # more threads than this slow torch-CPU down on these shapes
     torch.set_num_threads(cores)
-    p_len, _ = prompt_len(m, ref_codes)
     tt = m.texttok.encode("<|startoftext|>" + TRANSCRIPT + ' ' + TEXT.strip() + "<|endoftext|>", allowed_special='all')
     sp = m.speechtok.encode(' '.join(str(t) for t in ref_codes[0, 0].tolist()))
     n_text = len(m.texttok.vocab)
@@ -183,30 +182,31 @@ def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen):
     ref = ref_codes[0].T.contiguous().cpu()
     sd_ar, sd_nar = bundle.ar_ckpt["model"], bundle.nar_ckpt["model"]
     nh = bundle.ar_shape.nhead
-    p = O.ARSamplingParams(temperature=0.7, top_k=100, top_p=0.2, alpha_frequency=3, alpha_presence=0.4, penalty_window=100,
-                           eos_penalty_decay=0.5, eos_penalty_factor=50.0, n_phones_gen=round(100.0 * len(TEXT)))
-    n_tok = 8
+    t_start = time.perf_counter()
     with torch.inference_mode():
-        g = torch.Generator().manual_seed(0)
+        st = O.ARState()
         t0 = time.perf_counter()
-        O.ar_generate_oracle(sd_ar, nh, bundle.n_text, bundle.n_speech, m.speechtok.special_tokens['<|endofspeech|>'], prompt, ref,
-                             prompt.shape[0] + 1, p, generator=g, recompute_spk=True)
+        O.codeclm_step(sd_ar, prompt, ref, st, 1, nh, recompute_spk=True)
         t_prefill = time.perf_counter() - t0
+        toks, n_tok, t_acc = prompt, 0, 0.0
+        while n_tok < 6 and (time.perf_counter() - t_start) < budget_s * 0.5:
+            toks = torch.cat([toks, torch.tensor([n_text + 5 + n_tok])])
+            t0 = time.perf_counter()
+            O.codeclm_step(sd_ar, toks, ref, st, 2 + n_tok, nh, recompute_spk=True)
+            t_acc += time.perf_counter() - t0
+            n_tok += 1
+        t_tok = t_acc / max(n_tok, 1)
+        S = ref.shape[0] + ref.shape[0] - 1 + n_gen
+        x = torch.randint(0, 1025, (S, 8), generator=torch.Generator().manual_seed(0))
         t0 = time.perf_counter()
-        O.ar_generate_oracle(sd_ar, nh, bundle.n_text, bundle.n_speech, m.speechtok.special_tokens['<|endofspeech|>'], prompt, ref,
-                             prompt.shape[0] + 1 + n_tok, p, generator=g, recompute_spk=True)
-        t_tok = (time.perf_counter() - t0 - t_prefill) / n_tok
-        x_l0 = torch.randint(0, 1024, (ref.shape[0] - 1 + n_gen,), generator=g)
-        t0 = time.perf_counter()
-        O.perform_simple_inference_oracle(sd_nar, bundle.nar_shape.nhead, torch.tensor(tt), ref, x_l0,
-                                          O.NARParams(T=200, deep_clone=True), generator=g, n_steps=1, hoist=False)
-        t_step = time.perf_counter() - t0
+        O.nar_forward(sd_nar, bundle.nar_shape.nhead, torch.tensor(tt), ref, x, 100, False)
+        t_step = 2.0 * (time.perf_counter() - t0)
     total = t_prefill + n_gen * t_tok + 200 * t_step
     audio_s = (n_gen - 1) / 75.0
     return dict(value=round(audio_s / total, 5), unit="audio_s/s", cores=cores, kind="port",
-                sample=(f"oracle/mars5_oracle.py (torch-CPU fp32 port of the reference path, reference cost model) on this host: "
-                        f"AR prefill P={prompt.shape[0]} {t_prefill:.2f}s + {n_tok} decode tokens {t_tok:.3f}s/token, NAR 1 of 200 reverse steps "
-                        f"at S={ref.shape[0] + x_l0.shape[0]} {t_step:.2f}s; extrapolated to {n_gen} tokens + 200 steps = {total:.0f}s/utterance"))
+                sample=(f"oracle/mars5_oracle.py (torch-CPU fp32 port of the reference path with the reference's cost model) on this host, "
+                        f"{cores} threads: AR prefill P={prompt.shape[0]} {t_prefill:.2f}s + {n_tok} decode tokens at {t_tok:.3f}s/token, "
+                        f"one NAR forward at S={S} x2 (CFG) = {t_step:.2f}s/step; extrapolated to {n_gen} tokens + 200 steps = {total:.0f}s/utterance"))
 
 
 def main():
