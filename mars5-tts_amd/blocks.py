@@ -72,34 +72,39 @@ def round_up(x: int, m: int) -> int:
 
 class SeqWorkspace:
     """Buffers for running encoder/decoder layers over B sequences of S rows (dim D, H heads
-    of 64).  V^T rows are padded to whole 64-key tiles and zero-filled once."""
+    of 64).  Each sequence occupies Sr = round_up(S, row_pad) rows of the row-major [B*Sr, D]
+    activation buffers: with row_pad = 64 every sequence starts on a tile boundary, so the GEMM
+    epilogues and the V^T scatter (4 consecutive s per 8-byte store) stay vector-aligned for
+    B > 1.  The pad rows are ordinary finite rows (zero-initialised, never attended to: keys >= S
+    are masked and never loaded); V^T rows are padded to whole 64-key tiles."""
 
-    def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev):
+    def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev, row_pad: int = 1):
         self.B, self.S, self.D, self.FF, self.dt = B, S, D, FF, dt
         self.H = D // 64
-        self.Sp = round_up(S, 64)
-        M = B * S
+        self.Sr = round_up(S, row_pad)
+        self.Sp = round_up(self.Sr, 64)
+        M = B * self.Sr
         self.M = M
-        self.xn = torch.empty(M, D, dtype=dt, device=dev)
-        self.q = torch.empty(B, self.H, S, 64, dtype=dt, device=dev)
-        self.k = torch.empty(B, self.H, S, 64, dtype=dt, device=dev)
+        self.xn = torch.zeros(M, D, dtype=dt, device=dev)
+        self.q = torch.zeros(B, self.H, self.Sr, 64, dtype=dt, device=dev)
+        self.k = torch.zeros(B, self.H, self.Sr, 64, dtype=dt, device=dev)
         self.vt = torch.zeros(B, self.H, 64, self.Sp, dtype=dt, device=dev)
-        self.att = torch.empty(M, D, dtype=dt, device=dev)
-        self.hff = torch.empty(M, FF, dtype=dt, device=dev)
+        self.att = torch.zeros(M, D, dtype=dt, device=dev)
+        self.hff = torch.zeros(M, FF, dtype=dt, device=dev)
 
     def scatter(self, q=True, k=True, v=True) -> L.QkvScatter:
-        H, S, Sp = self.H, self.S, self.Sp
+        H, S, Sp = self.H, self.Sr, self.Sp
         return L.QkvScatter(q=self.q.data_ptr() if q else None, k=self.k.data_ptr() if k else None,
                             vt=self.vt.data_ptr() if v else None, rows_per_batch=S, n_heads=H, head_dim=64,
                             q_bs=H * S * 64, q_hs=S * 64, q_rs=64, k_bs=H * S * 64, k_hs=S * 64, k_rs=64,
                             vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp)
 
     def self_attn_args(self, key_len: Optional[torch.Tensor], causal: bool = False) -> L.AttnArgs:
-        H, S, Sp, D = self.H, self.S, self.Sp, self.D
-        return L.AttnArgs(q=self.q.data_ptr(), q_bs=H * S * 64, q_hs=S * 64, q_rs=64,
-                          k=self.k.data_ptr(), k_bs=H * S * 64, k_hs=S * 64, k_rs=64,
+        H, S, Sr, Sp, D = self.H, self.S, self.Sr, self.Sp, self.D
+        return L.AttnArgs(q=self.q.data_ptr(), q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64,
+                          k=self.k.data_ptr(), k_bs=H * Sr * 64, k_hs=Sr * 64, k_rs=64,
                           vt=self.vt.data_ptr(), vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp,
-                          o=self.att.data_ptr(), o_bs=S * D, o_rs=D, B=self.B, H=H, Sq=S, Sk=S,
+                          o=self.att.data_ptr(), o_bs=Sr * D, o_rs=D, B=self.B, H=H, Sq=S, Sk=S,
                           key_len=key_len.data_ptr() if key_len is not None else None, causal=1 if causal else 0,
                           scale=64 ** -0.5, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0)
 
@@ -137,13 +142,13 @@ class CrossMemory:
 
 def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mem: CrossMemory, step_ptr: torch.Tensor, stream=None) -> None:
     """x = x + out_proj(SDPA(q_proj(LN2(x)), memory K/V of step *step_ptr))."""
-    H, S, D = ws.H, ws.S, ws.D
+    H, S, Sr, D = ws.H, ws.S, ws.Sr, ws.D
     ops.layernorm(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, stream=stream)
     ops.gemm(ws.xn, lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=ws.scatter(True, False, False), stream=stream)
-    a = L.AttnArgs(q=ws.q.data_ptr(), q_bs=H * S * 64, q_hs=S * 64, q_rs=64,
+    a = L.AttnArgs(q=ws.q.data_ptr(), q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64,
                    k=mem.k.data_ptr(), k_bs=H * mem.Le * 64, k_hs=mem.Le * 64, k_rs=64,
                    vt=mem.vt.data_ptr(), vt_bs=H * 64 * mem.Lep, vt_hs=64 * mem.Lep, vt_ds=mem.Lep,
-                   o=ws.att.data_ptr(), o_bs=S * D, o_rs=D, B=ws.B, H=H, Sq=S, Sk=mem.Le, key_len=None, causal=0,
+                   o=ws.att.data_ptr(), o_bs=Sr * D, o_rs=D, B=ws.B, H=H, Sq=S, Sk=mem.Le, key_len=None, causal=0,
                    scale=64 ** -0.5, kv_index=step_ptr.data_ptr(),
                    kv_index_stride_k=mem.Bm * H * mem.Le * 64, kv_index_stride_v=mem.Bm * H * 64 * mem.Lep)
     ops.attention(ws.dt, a, stream=stream)

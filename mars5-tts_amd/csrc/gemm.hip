@@ -10,6 +10,7 @@
 // Fused epilogues: bias, in-place residual, SwiGLU on interleaved rows, head-major
 // Q/K/V^T scatter (feeds attention.hip with no transpose pass), bias+SiLU.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
@@ -222,6 +223,15 @@ int launch_gemm(int epi, const GemmParams& p, dim3 grid, hipStream_t s) {
 
 }  // namespace
 
+int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                       void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc, const int* sec_kind,
+                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s);   // gemm16.hip
+
+static bool use_v1_gemm() {   // M5_GEMM_V1=1: A/B the first-generation register-staged kernel
+    static const bool v = [] { const char* e = getenv("M5_GEMM_V1"); return e && e[0] == '1'; }();
+    return v;
+}
+
 extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
                        int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, void* stream) {
@@ -248,8 +258,11 @@ extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int
     } else {
         p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     }
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype != M5_F32 && !use_v1_gemm())
+        return m5_gemm16_dispatch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, epi == M5_EPI_QKV ? &p.sc : nullptr,
+                                  p.sec_kind, batch, sA, sW, sC, sBias, s);
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     switch (dtype) {
         case M5_F32: return launch_gemm<F32T>(epi, p, grid, s);
         case M5_F16: return launch_gemm<F16T>(epi, p, grid, s);

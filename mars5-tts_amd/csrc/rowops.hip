@@ -40,6 +40,77 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t 
     }
 }
 
+
+// Vector form (D = 256 NV): lane holds NV float4 (16-byte loads, 1 KiB per wave instruction),
+// the 16-bit output leaves as 8-byte stores.  Same two-pass statistics as the scalar kernel.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                                            float eps, typename T::storage* y, int64_t ldy, int M,
+                                                            int n_affine, int64_t affine_stride, int64_t y_affine_stride) {
+    using st = typename T::storage;
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * ldx;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    for (int a = 0; a < n_affine; ++a) {
+        const float* g = gamma + a * affine_stride;
+        const float* bt = beta + a * affine_stride;
+        st* yr = y + a * y_affine_stride + (int64_t)row * ldy;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            const float4 gg = *reinterpret_cast<const float4*>(g + c), bb = *reinterpret_cast<const float4*>(bt + c);
+            const float o[4] = {v[i].x * rstd * gg.x + bb.x, v[i].y * rstd * gg.y + bb.y,
+                                v[i].z * rstd * gg.z + bb.z, v[i].w * rstd * gg.w + bb.w};
+            if constexpr (sizeof(st) == 4) {
+                *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+                st t[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t[e] = T::from_f32(o[e]);
+                *reinterpret_cast<uint2*>(yr + c) = *reinterpret_cast<const uint2*>(t);
+            }
+        }
+    }
+}
+
+template <typename T>
+bool launch_ln_vec(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y, int64_t ldy, int M,
+                   int D, int n_affine, int64_t affine_stride, int64_t y_affine_stride, hipStream_t s) {
+    using st = typename T::storage;
+    const int es = sizeof(st);
+    if (D % 256 || (ldx % 4) || (ldy * es % (es == 4 ? 16 : 8)) || (affine_stride % 4) || (y_affine_stride * es % (es == 4 ? 16 : 8)) ||
+        (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
+        return false;
+    dim3 grid((M + 3) / 4);
+#define M5_LNV(NV) hipLaunchKernelGGL((layernorm_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (st*)y, ldy, M, n_affine, affine_stride, y_affine_stride)
+    switch (D / 256) {
+        case 1: M5_LNV(1); break;
+        case 2: M5_LNV(2); break;
+        case 4: M5_LNV(4); break;
+        case 6: M5_LNV(6); break;
+        case 8: M5_LNV(8); break;
+        default: return false;
+    }
+#undef M5_LNV
+    return true;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ldx, const float* w, float eps,
                                                       typename T::storage* y, int64_t ldy, int M, int D) {
@@ -152,6 +223,13 @@ extern "C" int m5_layernorm(int out_dtype, const float* x, int64_t ldx, const fl
     if (D % 64 || D > 64 * MAXI) return M5_ERR_UNSUPPORTED;
     dim3 grid((M + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
+    {
+        bool done = false;
+        if (out_dtype == M5_F32) done = launch_ln_vec<F32T>(x, ldx, gamma, beta, eps, y, ldy, M, D, n_affine, affine_stride, y_affine_stride, s);
+        else if (out_dtype == M5_F16) done = launch_ln_vec<F16T>(x, ldx, gamma, beta, eps, y, ldy, M, D, n_affine, affine_stride, y_affine_stride, s);
+        else if (out_dtype == M5_BF16) done = launch_ln_vec<BF16T>(x, ldx, gamma, beta, eps, y, ldy, M, D, n_affine, affine_stride, y_affine_stride, s);
+        if (done) { M5_CHECK_LAUNCH(); return M5_OK; }
+    }
     switch (out_dtype) {
         case M5_F32: hipLaunchKernelGGL(layernorm_kernel<F32T>, grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (float*)y, ldy, M, D, n_affine, affine_stride, y_affine_stride); break;
         case M5_F16: hipLaunchKernelGGL(layernorm_kernel<F16T>, grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (_Float16*)y, ldy, M, D, n_affine, affine_stride, y_affine_stride); break;

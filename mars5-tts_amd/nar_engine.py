@@ -169,9 +169,10 @@ class NARSession:
                 ops.gemm(mem, lw.ca_kv_w, None, L.EPI_QKV, bias=lw.ca_kv_b, scatter=sc, stream=st)
                 self.mems.append(CrossMemory(k, vt, Le, Lep, nb))
             # -- loop-body buffers
-            self.ws = SeqWorkspace(nb, S, D, FF, dt, dev)
-            self.h = torch.empty(nb, S, D, dtype=torch.float32, device=dev)
-            self.hf = torch.empty(nb * S, D, dtype=torch.float32, device=dev)
+            self.ws = SeqWorkspace(nb, S, D, FF, dt, dev, row_pad=64)
+            self.Sr = Sr = self.ws.Sr
+            self.h = torch.zeros(nb, Sr, D, dtype=torch.float32, device=dev)
+            self.hf = torch.zeros(nb * Sr, D, dtype=torch.float32, device=dev)
             self.s_out = S - self.row_offset
             self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
             self.Kp = round_up(K, 4)
@@ -186,15 +187,16 @@ class NARSession:
     def enqueue_forward(self, st: int) -> None:
         """x_t -> logits for both guidance branches (the loop body's GEMM/attention work)."""
         mdl, s = self.m, self.m.shape
-        S, nb, D, Q = self.S, self.nb, s.dim, s.n_codebooks
-        ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr, stream=st)
-        hx = self.h.view(nb * S, D)
+        S, Sr, nb, D, Q = self.S, self.Sr, self.nb, s.dim, s.n_codebooks
+        ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
+                          rows=S, stream=st)
+        hx = self.h.view(nb * Sr, D)
         for lw, mem in zip(mdl.dec, self.mems):
             decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st)
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         so = self.s_out
         for b in range(nb):
-            ops.layernorm(self.hf[b * S + self.row_offset:], mdl.head_g, mdl.head_b, 1e-5, self.hn[:, b * so:], n_affine=Q - 1,
+            ops.layernorm(self.hf[b * Sr + self.row_offset:], mdl.head_g, mdl.head_b, 1e-5, self.hn[:, b * so:], n_affine=Q - 1,
                           affine_stride=D, y_affine_stride=nb * so * D, M=so, stream=st)
         ops.gemm(self.hn[0], mdl.head_w[0], self.logits, L.EPI_F32, bias=mdl.head_bias, ldc=(Q - 1) * self.Kp, batch=Q - 1,
                  sA=nb * so * D, sW=s.n_quant * D, sC=self.Kp, sBias=s.n_quant, stream=st)

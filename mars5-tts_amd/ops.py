@@ -78,14 +78,17 @@ def gather_rows(out: torch.Tensor, table: torch.Tensor, idx: torch.Tensor, alpha
 
 def chunked_embed(out: torch.Tensor, tables: torch.Tensor, codes: Optional[torch.Tensor], lead_row: Optional[torch.Tensor],
                   alpha: Optional[torch.Tensor], pe: Optional[torch.Tensor], add: Optional[torch.Tensor] = None,
-                  add_index: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> None:
-    """out (n_rep, R, D) fp32; tables (n_q, n_codes, D/n_q); codes (R-lead, n_q) int64."""
+                  add_index: Optional[torch.Tensor] = None, rows: Optional[int] = None, stream: Optional[int] = None) -> None:
+    """out (n_rep, Rr, D) fp32, the first R = `rows` (default Rr) rows of every rep are written;
+    tables (n_q, n_codes, D/n_q); codes (R-lead, n_q) int64."""
     assert out.dtype == torch.float32 and out.is_contiguous() and tables.is_contiguous()
-    n_rep, R, D = out.shape
+    n_rep, Rr, D = out.shape
+    R = Rr if rows is None else rows
+    assert R <= Rr
     n_q, n_codes, _ = tables.shape
     if codes is not None:
         assert codes.dtype == torch.int64 and codes.is_contiguous()
-    check(lib.m5_chunked_embed(_p(out), R * D, n_rep, R, D, n_q, n_codes, _p(tables), _p(codes), _p(lead_row), _p(alpha),
+    check(lib.m5_chunked_embed(_p(out), Rr * D, n_rep, R, D, n_q, n_codes, _p(tables), _p(codes), _p(lead_row), _p(alpha),
                                _p(pe), _p(add), _p(add_index), _s(stream)), "m5_chunked_embed")
 
 
