@@ -13,6 +13,7 @@
 // give the B operand the same four consecutive keys with one 8/16-byte LDS read.  No LDS
 // round trip for P, no V transpose in the kernel (the producing GEMM writes V^T).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
@@ -241,6 +242,13 @@ __global__ __launch_bounds__(256) void attn_kernel(M5AttnArgs p) {
 
 }  // namespace
 
+int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s);   // attention16.hip; returns 1 when not handled
+
+static bool use_v1_attn() {   // M5_ATTN_V1=1: A/B the first-generation kernel
+    static const bool v = [] { const char* e = getenv("M5_ATTN_V1"); return e && e[0] == '1'; }();
+    return v;
+}
+
 extern "C" int m5_attention(int dtype, const M5AttnArgs* a, void* stream) {
     if (!a || !a->q || !a->k || !a->vt || !a->o || a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return M5_ERR_ARG;
     const int es = (dtype == M5_F32) ? 4 : 2, al = 16 / es;
@@ -251,6 +259,10 @@ extern "C" int m5_attention(int dtype, const M5AttnArgs* a, void* stream) {
     if (a->vt_ds < ((a->Sk + 63) / 64) * 64) return M5_ERR_ARG;   // V^T rows are read in whole 64-key tiles
     dim3 grid((a->Sq + 63) / 64, a->H, a->B);
     hipStream_t s = (hipStream_t)stream;
+    if (dtype != M5_F32 && !use_v1_attn()) {
+        const int r = m5_attention16_dispatch(dtype, a, s);
+        if (r != 1) return r;
+    }
     switch (dtype) {
         case M5_F32: hipLaunchKernelGGL(attn_kernel<F32T>, grid, dim3(256), 0, s, *a); break;
         case M5_F16: hipLaunchKernelGGL(attn_kernel<F16T>, grid, dim3(256), 0, s, *a); break;

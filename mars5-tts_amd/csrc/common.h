@@ -28,11 +28,9 @@ struct BF16T {
     static constexpr int id = M5_BF16;
     static constexpr int EPL = 8;
     __device__ static inline float to_f32(storage v) { return __uint_as_float(((uint32_t)v) << 16); }
-    __device__ static inline storage from_f32(float f) {
-        uint32_t u = __float_as_uint(f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)0x7fc0;  // NaN
-        u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
-        return (uint16_t)(u >> 16);
+    __device__ static inline storage from_f32(float f) {     // v_cvt_pk_bf16_f32: round to nearest even
+        const __bf16 b = (__bf16)f;
+        return *reinterpret_cast<const uint16_t*>(&b);
     }
 };
 

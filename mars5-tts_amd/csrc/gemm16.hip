@@ -22,6 +22,7 @@
 //     lane-local), bias+SiLU, head-major Q/K scatter.  V^T blocks (s contiguous) flip the
 //     operand order back (block-uniform) so the four consecutive elements run along s.
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
@@ -29,8 +30,6 @@ typedef __attribute__((ext_vector_type(4))) float f4_t;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BKB = 128;      // BKB: K-step in BYTES per row (64 halves)
-constexpr int STAGE = (BM + BN) * BKB;            // 32 KiB
 constexpr int GROUP_M = 8;
 
 struct Gemm16Params {
@@ -38,7 +37,7 @@ struct Gemm16Params {
     int64_t lda, ldw, ldc;           // elements
     int64_t sA, sW, sC, sBias;       // batch strides, elements
     int M, N, K;
-    int tilesM, tilesN, nblk;
+    int tilesM, tilesN, nblk, group_m;
     int vec_c;                       // C rows / batch stride / base allow 16-byte (fp32) or 8-byte (16-bit) vectors
     int vt_vec;                      // V^T scatter may store 4 consecutive s as one 8-byte vector
     M5QkvScatter sc;
@@ -70,6 +69,13 @@ __device__ inline void glds16(const unsigned char* gsrc, uint32_t lds_base) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
 
+// silu with the hardware exp2 / reciprocal (16-bit operand paths; results are rounded to the
+// operand type right after).  The epilogue of a K = 1024 SwiGLU GEMM otherwise spends as many
+// issue cycles in libm expf + IEEE division as the main loop spends in MFMAs.
+__device__ inline float silu_fast(float a) {
+    return a * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * a));
+}
+
 template <typename T>
 __device__ inline uint2 pack4(const float v[4]) {
     using st = typename T::storage;
@@ -79,14 +85,34 @@ __device__ inline uint2 pack4(const float v[4]) {
     return *reinterpret_cast<const uint2*>(t);
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
+// Workgroup tile = (WM x WN) waves, each wave (TM x TN) MFMA tiles of 16x16 (fp32 accumulators
+// 4 TM TN per lane); BKB = K-step in BYTES per row (128: 64 halves, 64: 32 halves); NSTAGE LDS
+// stages (NSTAGE-1 K-steps of DMA in flight ahead of the MFMAs); OCC = workgroups per CU the
+// LDS / register budget is sized for.
+//
+// What bounds these GEMMs on MI355X is the rate at which one CU can pull operand bytes
+// (measured ~45-50 GB/s per CU through L2 -> LDS-DMA, independent of pipeline depth, row
+// stride or K phase; profiles/): time ~ max over CUs of the bytes that CU stages.  So besides
+// the 128x128 configuration (2 workgroups per CU) there are "region" configurations that cut the
+// output into ~240-256 large rectangles, ONE per CU (192x384, 192x192, 96x128): the bytes staged
+// per flop drop 1.5-2x and every CU gets the same amount, instead of 128x128 tiles in 2.06 rounds.
+template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC>
+__global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_kernel(Gemm16Params p) {
     using st = typename T::storage;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int RPI = 1024 / BKB;                    // rows per 1 KiB DMA instruction (8 or 16)
+    constexpr int NQ = (BM + BN) / RPI;                // DMA instructions per stage; instruction q -> wave q % NW
+    constexpr int JN = (NQ + NW - 1) / NW;
+    constexpr int KS = BKB / 64;                       // MFMA k-steps (32 halves) per stage
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "stage tiling");
+    static_assert(NSTAGE * STAGE <= 160 * 1024 && NSTAGE >= 2 && NSTAGE <= 4, "LDS budget");
+    static_assert((NSTAGE - 2) * JN < 64, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lg = lane >> 4;
 
     // ---- workgroup -> tile: XCD-contiguous runs (bijective for any nblk), grouped order
@@ -100,9 +126,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
     t -= bz * tiles;
     int tm, tn;
     {
-        const int width = GROUP_M * p.tilesN;
-        const int g = t / width, first = g * GROUP_M;
-        const int gsz = min(p.tilesM - first, GROUP_M);
+        const int width = p.group_m * p.tilesN;
+        const int g = t / width, first = g * p.group_m;
+        const int gsz = min(p.tilesM - first, p.group_m);
         const int w = t - g * width;
         tm = first + w % gsz;
         tn = w / gsz;
@@ -111,94 +137,114 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
     const unsigned char* A = p.A + (int64_t)bz * p.sA * 2;
     const unsigned char* W = p.W + (int64_t)bz * p.sW * 2;
 
-    // ---- LDS-DMA staging: wave w fills rows [32w, 32w+32) of both operand tiles, 8 rows
-    // (1 KiB) per instruction; lane l lands at row 8j + (l >> 3), chunk slot l & 7, and
-    // fetches source chunk (l & 7) ^ (l >> 3)  (row & 7 == l >> 3 because 8 | row base).
-    const int srow = lane >> 3, schunk = (lane & 7) ^ srow;
-    const unsigned char* ga[4];
-    const unsigned char* gw[4];
+    // ---- LDS-DMA staging: instruction q fills rows [q RPI, (q+1) RPI) of the stage image (A tile
+    // rows first, W tile rows after), 1 KiB each.  The DMA writes lane-linear, so the bank swizzle
+    // lives in the per-lane SOURCE chunk and (same involution) in the fragment reads:
+    //   BKB = 128: lane l -> row l >> 3, slot l & 7,  source chunk slot ^ (row & 7)
+    //   BKB =  64: lane l -> row l >> 2, slot l & 3,  source chunk slot ^ ((-(row >> 2)) & 3)
+    // (conflict-free for ds_read_b128's four 16-lane groups in both layouts: SQ_LDS_BANK_CONFLICT = 0).
+    const int srow = (BKB == 128) ? (lane >> 3) : (lane >> 2);
+    const int schunk = (BKB == 128) ? ((lane & 7) ^ srow) : ((lane & 3) ^ ((-(srow >> 2)) & 3));
+    const unsigned char* gp[JN];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int ra = min(m0 + wave * 32 + j * 8 + srow, p.M - 1);
-        const int rw = min(n0 + wave * 32 + j * 8 + srow, p.N - 1);
-        ga[j] = A + (int64_t)ra * p.lda * 2 + schunk * 16;
-        gw[j] = W + (int64_t)rw * p.ldw * 2 + schunk * 16;
+    for (int j = 0; j < JN; ++j) {
+        const int q = wave + NW * j;                   // wave-uniform
+        const int r = q * RPI + srow;                  // row of the stage image
+        if (r < BM) gp[j] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda * 2 + schunk * 16;
+        else gp[j] = W + (int64_t)min(n0 + r - BM, p.N - 1) * p.ldw * 2 + schunk * 16;
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     auto stage_load = [&](int stage, int kt) {
-        const uint32_t sa = lds_base + stage * STAGE + wave * 32 * BKB;
-        const uint32_t sw = sa + BM * BKB;
+        const uint32_t sbase = lds_base + stage * STAGE + wave * 1024;
         const int64_t koff = (int64_t)kt * BKB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            glds16(ga[j] + koff, sa + j * 8 * BKB);
-            glds16(gw[j] + koff, sw + j * 8 * BKB);
-        }
+        for (int j = 0; j < JN; ++j)
+            if (NQ % NW == 0 || wave + NW * j < NQ) glds16(gp[j] + koff, sbase + j * NW * 1024);
     };
 
-    // fragment read offsets: row (16 i + l15), chunk (4 ks + lg) ^ (l15 & 7)
-    int foff[2];
+    // fragment read offsets: row (16 i + l15), k-chunk (4 ks + lg) swizzled like the source
+    int foff[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) foff[ks] = l15 * BKB + (((ks * 4 + lg) ^ (l15 & 7)) << 4);
-    const int a_row0 = wm * 64 * BKB, w_row0 = BM * BKB + wn * 64 * BKB;
+    for (int ks = 0; ks < KS; ++ks)
+        foff[ks] = l15 * BKB + ((BKB == 128) ? (((ks * 4 + lg) ^ (l15 & 7)) << 4) : ((lg ^ ((-(l15 >> 2)) & 3)) << 4));
+    const int a_row0 = wm * TM * 16 * BKB, w_row0 = BM * BKB + wn * TN * 16 * BKB;
 
-    f4_t acc[4][4];
+    f4_t acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    // V^T blocks keep (row-major m along registers): block-uniform
+    // A wave whose columns lie in the V section keeps the unswapped operand order (4 consecutive
+    // ROWS per lane, for the V^T scatter).  Wave-uniform: the host only picks configurations whose
+    // per-wave column span (16 TN) divides the section width Dm.
     bool vblock = false;
     const int Dm = p.sc.n_heads * p.sc.head_dim;
-    if constexpr (EPI == M5_EPI_QKV) vblock = p.sec_kind[min(n0 / Dm, 2)] == 2;
+    if constexpr (EPI == M5_EPI_QKV) vblock = p.sec_kind[min((n0 + wn * TN * 16) / Dm, 2)] == 2;
 
-    const int nk = p.K / 64;
-    stage_load(0, 0);
+    const int nk = p.K * 2 / BKB;
+    const bool full_share = (NQ % NW == 0) || (wave < NQ % NW);     // this wave issues JN (else JN - 1) DMAs per stage
+#pragma unroll
+    for (int sgi = 0; sgi < NSTAGE - 1; ++sgi)
+        if (sgi < nk) stage_load(sgi, sgi);
+    int slot = 0;                                      // stage slot of K-step kt
     for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // K-step kt has landed once at most min(NSTAGE-2, nk-1-kt) younger stages remain in flight
+        // (vmcnt is per wave: a wave that issues JN - 1 instructions per stage counts with JN - 1)
+        const int younger = min(NSTAGE - 2, nk - 1 - kt);
+        if (NSTAGE >= 4 && younger == 2) {
+            if (full_share) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * JN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (JN - 1)) : "memory");
+        } else if (NSTAGE >= 3 && younger == 1) {
+            if (full_share) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(JN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(JN - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
-        if (kt + 1 < nk) stage_load((kt + 1) & 1, kt + 1);
-        const unsigned char* sb = lds + (kt & 1) * STAGE;
+        // the slot read during K-step kt-1 is free now: refill it with K-step kt+NSTAGE-1
+        if (kt + NSTAGE - 1 < nk) stage_load(slot == 0 ? NSTAGE - 1 : slot - 1, kt + NSTAGE - 1);
+        const unsigned char* sb = lds + slot * STAGE;
+        slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[4], bf[4];
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *reinterpret_cast<const uint4*>(sb + a_row0 + i * 16 * BKB + foff[ks]);
-                bf[i] = *reinterpret_cast<const uint4*>(sb + w_row0 + i * 16 * BKB + foff[ks]);
-            }
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_row0 + i * 16 * BKB + foff[ks]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const uint4*>(sb + w_row0 + j * 16 * BKB + foff[ks]);
             if (EPI == M5_EPI_QKV && vblock) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(af[i], bf[j], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<T>(af[i], bf[j], acc[i][j]);
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
             }
         }
     }
 
-    // ---- epilogue.  swapped layout: acc[i][j][r] = C[m0+wm*64+16i+l15][n0+wn*64+16j+4lg+r]
+    // ---- epilogue.  swapped layout: acc[i][j][r] = C[mw + 16 i + l15][nw + 16 j + 4 lg + r]
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
     constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL);
     unsigned char* Cb = p.C + (int64_t)bz * p.sC * (F32OUT ? 4 : 2);
+    const int mw = m0 + wm * TM * 16, nw = n0 + wn * TN * 16;
 
     if (EPI == M5_EPI_QKV && vblock) {
-        // unswapped layout: acc[i][j][r] = C[m0+wm*64+16i+4lg+r][n0+wn*64+16j+l15]
+        // unswapped layout: acc[i][j][r] = C[mw + 16 i + 4 lg + r][nw + 16 j + l15]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 64 + j * 16 + l15;
+        for (int j = 0; j < TN; ++j) {
+            const int col = nw + j * 16 + l15;
             if (col >= p.N) continue;
             const float bv = bias ? bias[col] : 0.f;
             const int c = col % Dm, hh = c / p.sc.head_dim, dd = c % p.sc.head_dim;
             st* vt = reinterpret_cast<st*>(p.sc.vt) + hh * p.sc.vt_hs + (int64_t)dd * p.sc.vt_ds;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = m0 + wm * 64 + i * 16 + lg * 4;
+            for (int i = 0; i < TM; ++i) {
+                const int row = mw + i * 16 + lg * 4;
                 if (row >= p.M) continue;
                 float v[4];
 #pragma unroll
@@ -221,61 +267,56 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
         return;
     }
 
-    const int nb0 = n0 + wn * 64 + lg * 4;
-    float4 oldv[4][4];
-    if constexpr (EPI == M5_EPI_RESIDUAL) {
-        // issue every read of C before the first write (the compiler cannot reorder a load
-        // above a possibly-aliasing store, which would serialise 16 round trips)
+    // per-column-group constants (this lane's 4 consecutive columns of each of the TN tiles)
+    float bv[TN][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 64 + i * 16 + l15;
+    for (int j = 0; j < TN; ++j) {
+        const int col = nw + j * 16 + lg * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int col = nb0 + j * 16;
-                oldv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < p.M && col < p.N) {
-                    const float* cp = reinterpret_cast<const float*>(Cb) + (int64_t)row * p.ldc + col;
-                    if (p.vec_c && col + 3 < p.N) {
-                        oldv[i][j] = *reinterpret_cast<const float4*>(cp);
-                    } else {
-                        oldv[i][j].x = cp[0];
-                        if (col + 1 < p.N) oldv[i][j].y = cp[1];
-                        if (col + 2 < p.N) oldv[i][j].z = cp[2];
-                        if (col + 3 < p.N) oldv[i][j].w = cp[3];
-                    }
+        for (int r = 0; r < 4; ++r) bv[j][r] = bias ? bias[min(col + r, p.N - 1)] : 0.f;
+    }
+    // in-place residual: row i+1's reads of C are issued BEFORE row i's writes (the compiler cannot
+    // hoist a load above a possibly-aliasing store, which would serialise TM x TN round trips)
+    auto load_old = [&](int i, float4* o) {
+        const int row = mw + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = nw + j * 16 + lg * 4;
+            o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.M && col < p.N) {
+                const float* cp = reinterpret_cast<const float*>(Cb) + (int64_t)row * p.ldc + col;
+                if (p.vec_c && col + 3 < p.N) {
+                    o[j] = *reinterpret_cast<const float4*>(cp);
+                } else {
+                    o[j].x = cp[0];
+                    if (col + 1 < p.N) o[j].y = cp[1];
+                    if (col + 2 < p.N) o[j].z = cp[2];
+                    if (col + 3 < p.N) o[j].w = cp[3];
                 }
             }
         }
-    }
+    };
+    float4 oldc[TN], oldn[TN];
+    if constexpr (EPI == M5_EPI_RESIDUAL) load_old(0, oldc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = nb0 + j * 16;
-        if (col >= p.N) continue;
-        const bool full = col + 3 < p.N;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv[r] = bias[min(col + r, p.N - 1)];
+    for (int i = 0; i < TM; ++i) {
+        if constexpr (EPI == M5_EPI_RESIDUAL) {
+            if (i + 1 < TM) load_old(i + 1, oldn);
         }
-        int kind = 0, hh = 0, dd = 0;
-        if constexpr (EPI == M5_EPI_QKV) {
-            kind = p.sec_kind[min(col / Dm, 2)];
-            const int c = col % Dm;
-            hh = c / p.sc.head_dim;
-            dd = c % p.sc.head_dim;
-        }
+        const int row = mw + i * 16 + l15;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = m0 + wm * 64 + i * 16 + l15;
-            if (row >= p.M) continue;
+        for (int j = 0; j < TN; ++j) {
+            const int col = nw + j * 16 + lg * 4;
+            if (row >= p.M || col >= p.N) continue;
+            const bool full = col + 3 < p.N;
             float v[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[r];
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv[j][r];
             if constexpr (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL) {
                 float* cp = reinterpret_cast<float*>(Cb) + (int64_t)row * p.ldc + col;
                 if constexpr (EPI == M5_EPI_RESIDUAL) {
-                    v[0] = oldv[i][j].x + v[0]; v[1] = oldv[i][j].y + v[1];
-                    v[2] = oldv[i][j].z + v[2]; v[3] = oldv[i][j].w + v[3];
+                    v[0] = oldc[j].x + v[0]; v[1] = oldc[j].y + v[1];
+                    v[2] = oldc[j].z + v[2]; v[3] = oldc[j].w + v[3];
                 }
                 if (p.vec_c && full) {
                     *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
@@ -287,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
             } else if constexpr (EPI == M5_EPI_DT || EPI == M5_EPI_SILU_DT) {
                 if constexpr (EPI == M5_EPI_SILU_DT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = silu_fast(v[r]);
                 }
                 st* cp = reinterpret_cast<st*>(Cb) + (int64_t)row * p.ldc + col;
                 if (p.vec_c && full) {
@@ -303,8 +344,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float a = round_dt<T>(v[2 * h]), b = round_dt<T>(v[2 * h + 1]);
-                    const float s = round_dt<T>(silu_f(a));
-                    o[h] = T::from_f32(s * b);
+                    const float sl = round_dt<T>(silu_fast(a));
+                    o[h] = T::from_f32(sl * b);
                 }
                 st* cp = reinterpret_cast<st*>(Cb) + (int64_t)row * p.ldc + (col >> 1);
                 if (full) {
@@ -313,6 +354,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
                     if (col + 1 < p.N) cp[0] = o[0];
                 }
             } else if constexpr (EPI == M5_EPI_QKV) {
+                const int kind = p.sec_kind[min(col / Dm, 2)];
+                const int c = col % Dm, hh = c / p.sc.head_dim, dd = c % p.sc.head_dim;
                 const int b = row / p.sc.rows_per_batch, s = row - b * p.sc.rows_per_batch;
                 st* dst = (kind == 0)
                     ? reinterpret_cast<st*>(p.sc.q) + b * p.sc.q_bs + hh * p.sc.q_hs + (int64_t)s * p.sc.q_rs + dd
@@ -320,23 +363,77 @@ __global__ __launch_bounds__(256, 2) void gemm16_kernel(Gemm16Params p) {
                 *reinterpret_cast<uint2*>(dst) = pack4<T>(v);   // Dm % 4 == 0: a 4-group never straddles N or a head
             }
         }
+        if constexpr (EPI == M5_EPI_RESIDUAL) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) oldc[j] = oldn[j];
+        }
     }
 }
 
-template <typename T>
-int launch16(int epi, const Gemm16Params& p, hipStream_t s) {
-    const dim3 grid(p.nblk), blk(256);
+template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC>
+int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
+    const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
+    if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
+    p.nblk = (int)nblk;
+    p.group_m = max(1, GROUP_M * 128 / BM);
+    const dim3 grid(p.nblk), blk(WM * WN * 64);
+#define M5_G16(E) hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC>), grid, blk, 0, s, p)
     switch (epi) {
-        case M5_EPI_F32: hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_F32>), grid, blk, 0, s, p); break;
-        case M5_EPI_DT: hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_DT>), grid, blk, 0, s, p); break;
-        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_RESIDUAL>), grid, blk, 0, s, p); break;
-        case M5_EPI_SWIGLU: hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_SWIGLU>), grid, blk, 0, s, p); break;
-        case M5_EPI_QKV: hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_QKV>), grid, blk, 0, s, p); break;
-        case M5_EPI_SILU_DT: hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_SILU_DT>), grid, blk, 0, s, p); break;
+        case M5_EPI_F32: M5_G16(M5_EPI_F32); break;
+        case M5_EPI_DT: M5_G16(M5_EPI_DT); break;
+        case M5_EPI_RESIDUAL: M5_G16(M5_EPI_RESIDUAL); break;
+        case M5_EPI_SWIGLU: M5_G16(M5_EPI_SWIGLU); break;
+        case M5_EPI_QKV: M5_G16(M5_EPI_QKV); break;
+        case M5_EPI_SILU_DT: M5_G16(M5_EPI_SILU_DT); break;
         default: return M5_ERR_ARG;
     }
+#undef M5_G16
     M5_CHECK_LAUNCH();
     return M5_OK;
+}
+
+// Tile configurations.  M5_GEMM_CFG=<n> forces one (tuning sweeps); otherwise pick_config().
+struct CfgInfo { int bm, bn, tn, occ; float t_fix_us, t_iter_us; };   // t_iter: per 64-deep K-step, measured (profiles/)
+static const CfgInfo kCfg[] = {
+    {128, 128, 4, 2, 8.f, 0.72f},     // 0: 128x128 tile, 4 waves, 2 stages, 2 WG/CU
+    {192, 384, 6, 1, 8.f, 2.37f},     // 1: region 192x384, 8 waves (2x4 of 96x96), 2 stages
+    {192, 192, 4, 1, 8.f, 1.50f},     // 2: region 192x192, 6 waves (2x3 of 96x64), 3 stages
+    { 96, 128, 4, 1, 8.f, 0.64f},     // 3: region  96x128, 4 waves (2x2 of 48x64), 4 stages
+    { 96, 128, 2, 2, 8.f, 0.66f},     // 4: tile    96x128, 8 waves (2x4 of 48x32), 2 stages, 2 WG/CU
+};
+constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
+
+template <typename T>
+int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s) {
+    switch (cfg) {
+        case 0: return launch16<T, 2, 2, 4, 4, 128, 2, 2>(epi, p, batch, s);
+        case 1: return launch16<T, 2, 4, 6, 6, 128, 2, 1>(epi, p, batch, s);
+        case 2: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s);
+        case 3: return launch16<T, 2, 2, 3, 4, 128, 4, 1>(epi, p, batch, s);
+        case 4: return launch16<T, 2, 4, 3, 2, 128, 2, 2>(epi, p, batch, s);
+        default: return M5_ERR_ARG;
+    }
+}
+
+// Cheapest configuration under: time = rounds x (fixed + K-steps x per-step time), rounds =
+// ceil(workgroups / (256 CUs x workgroups per CU)).  `span_div`: for QKV scatters with a V section
+// the per-wave column span must divide the section width.
+int pick_config(int M, int N, int K, int batch, int span_div) {
+    int best = 0;
+    float best_t = 1e30f;
+    for (int c = 0; c < kNumCfg; ++c) {
+        const CfgInfo& f = kCfg[c];
+        if (span_div && (span_div % (f.tn * 16))) continue;
+        const int64_t wg = (int64_t)((M + f.bm - 1) / f.bm) * ((N + f.bn - 1) / f.bn) * batch;
+        const int64_t slots = 256 * f.occ;
+        const int64_t rounds = (wg + slots - 1) / slots;
+        // a partially filled last round of an occ-2 configuration runs its workgroups alone on their CUs
+        const float t = (float)rounds * (f.t_fix_us + (float)(K / 64) * f.t_iter_us);
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
 }
 
 }  // namespace
@@ -349,10 +446,6 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = sA; p.sW = sW; p.sC = sC; p.sBias = sBias;
     p.M = M; p.N = N; p.K = K;
-    p.tilesM = (M + BM - 1) / BM; p.tilesN = (N + BN - 1) / BN;
-    const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
-    if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
-    p.nblk = (int)nblk;
     const bool f32out = (epi == M5_EPI_F32 || epi == M5_EPI_RESIDUAL);
     const int cal = f32out ? 15 : 7;
     p.vec_c = (C && (ldc % 4 == 0) && (sC % 4 == 0) && (((uintptr_t)C & cal) == 0)) ? 1 : 0;
@@ -369,6 +462,11 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     } else {
         p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     }
-    if (dtype == M5_F16) return launch16<F16T>(epi, p, s);
-    return launch16<BF16T>(epi, p, s);
+    const char* fe = getenv("M5_GEMM_CFG");                  // tuning sweeps only; read per call on purpose
+    const int forced = (fe && fe[0]) ? atoi(fe) : -1;
+    const int span_div = (sc && sc->vt) ? sc->n_heads * sc->head_dim : 0;
+    int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div);
+    if (cfg < 0 || cfg >= kNumCfg || (span_div && (span_div % (kCfg[cfg].tn * 16)))) cfg = 0;
+    if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s);
+    return launch_cfg<BF16T>(cfg, epi, p, batch, s);
 }

@@ -12,7 +12,7 @@ from mars5_tts_amd import ops, _lib as L
 
 dev = torch.device("cuda:0")
 dt = torch.bfloat16
-REP = 20
+REP = int(os.environ.get("REP", "20"))
 
 def ref_epi(a, w, bias, epi, c0):
     y = a.float() @ w.float().T
@@ -27,10 +27,13 @@ def ref_epi(a, w, bias, epi, c0):
         return torch.nn.functional.silu(y)
     return y
 
-def run_case(name, M, N, K, epi, bias=True, rpb=None, check=True):
+def run_case(name, M, N, K, epi, bias=True, rpb=None, check=True, pad=0):
     g = torch.Generator(device="cpu").manual_seed(1)
     a = (torch.randn(M, K, generator=g) * 0.5).to(dev, dt)
     w = (torch.randn(N, K, generator=g) * (1.0 / K ** 0.5)).to(dev, dt)
+    if pad:
+        ap = torch.zeros(M, K + pad, dtype=dt, device=dev); ap[:, :K] = a; a = ap[:, :K]
+        wp = torch.zeros(N, K + pad, dtype=dt, device=dev); wp[:, :K] = w; w = wp[:, :K]
     b = torch.randn(N, generator=g).to(dev) if bias else None
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
@@ -95,23 +98,44 @@ def run_case(name, M, N, K, epi, bias=True, rpb=None, check=True):
         stream.synchronize()
     us = e0.elapsed_ms(e1) * 1e3 / (5 * REP)
     tf = 2.0 * M * N * K / us / 1e6
-    print(f"{name:28s} M={M:6d} N={N:5d} K={K:5d} epi={epi}  {us:8.2f} us  {tf:7.1f} TF  maxerr={err}", flush=True)
+    print(f"{name:40s} M={M:6d} N={N:5d} K={K:5d} epi={epi}  {us:8.2f} us  {tf:7.1f} TF  maxerr={err}", flush=True)
     return dict(name=name, M=M, N=N, K=K, epi=epi, us=us, tflops=tf, err=err)
+
+CASES = [
+    ("nar self qkv", 2816, 3072, 1024, L.EPI_QKV, True, 1408),
+    ("nar out_proj", 2816, 1024, 1024, L.EPI_RESIDUAL, True, None),
+    ("nar cross q", 2816, 1024, 1024, L.EPI_QKV, True, 1408),
+    ("nar swiglu", 2816, 6144, 1024, L.EPI_SWIGLU, False, None),
+    ("nar linear2", 2816, 1024, 3072, L.EPI_RESIDUAL, True, None),
+    ("nar head (1 of 7)", 1798, 1025, 1024, L.EPI_F32, True, None),
+    ("enc qkv (hoisted)", 15600, 3072, 1024, L.EPI_QKV, True, 39),
+    ("enc swiglu (hoisted)", 15600, 6144, 1024, L.EPI_SWIGLU, False, None),
+    ("ar prefill qkv", 489, 4608, 1536, L.EPI_DT, False, None),
+    ("ar prefill w13", 489, 7168, 1536, L.EPI_SWIGLU, False, None),
+    ("ar prefill w2", 489, 1536, 3584, L.EPI_RESIDUAL, False, None),
+    ("spk enc qkv", 451, 3072, 1024, L.EPI_QKV, True, 451),
+]
 
 if __name__ == "__main__":
     res = []
-    for Mrows, rpb in ((2698, 1349), (2816, 1408)):
-        res.append(run_case("nar self qkv", Mrows, 3072, 1024, L.EPI_QKV, rpb=rpb))
-        res.append(run_case("nar out_proj", Mrows, 1024, 1024, L.EPI_RESIDUAL))
-        res.append(run_case("nar cross q", Mrows, 1024, 1024, L.EPI_QKV, rpb=rpb))
-        res.append(run_case("nar swiglu", Mrows, 6144, 1024, L.EPI_SWIGLU, bias=False))
-        res.append(run_case("nar linear2", Mrows, 1024, 3072, L.EPI_RESIDUAL))
-    res.append(run_case("nar head (1 of 7)", 1798, 1025, 1024, L.EPI_F32))
-    res.append(run_case("enc qkv (hoisted)", 15600, 3072, 1024, L.EPI_QKV, rpb=39))
-    res.append(run_case("ar prefill qkv", 489, 4608, 1536, L.EPI_DT, bias=False))
-    res.append(run_case("ar prefill w13", 489, 7168, 1536, L.EPI_SWIGLU, bias=False))
-    res.append(run_case("ar prefill w2", 489, 1536, 3584, L.EPI_RESIDUAL, bias=False))
-    res.append(run_case("timestep mlp silu", 200, 1024, 1024, L.EPI_SILU_DT))
+    cfgs = [int(c) for c in os.environ.get("SWEEP", "").split(",") if c != ""]
+    if os.environ.get("M5_GEMM_V1") == "1" or not cfgs:
+        cfgs = [None]
+    pads = [int(c) for c in os.environ.get("PADS", "0").split(",")]
+    krots = os.environ.get("KROTS", "0").split(",")
+    only = [s for s in os.environ.get("ONLY", "").split(",") if s]
+    for (name, M, N, K, epi, bias, rpb) in CASES:
+        if only and name not in only:
+            continue
+        for cfg in cfgs:
+            for pad in pads:
+                for kr in krots:
+                    if cfg is not None:
+                        os.environ["M5_GEMM_CFG"] = str(cfg)
+                    os.environ["M5_GEMM_KROT"] = kr
+                    r = run_case(f"{name} cfg={cfg} pad={pad} kr={kr}", M, N, K, epi, bias=bias, rpb=rpb, pad=pad)
+                    r["cfg"] = cfg; r["pad"] = pad; r["krot"] = kr
+                    res.append(r)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     tag = "v1" if os.environ.get("M5_GEMM_V1") == "1" else "v2"
     json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"gemm_bench_{tag}.json"), "w"), indent=1)

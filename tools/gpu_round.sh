@@ -9,6 +9,9 @@ export TMPDIR=/tmp
 for s in $STEPS; do
   case $s in
     test) timeout 600 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest.log ;;
+    sweep) SWEEP=${SWEEP:-0,1,2,3,4,5,6,7} timeout 600 python tools/gemm_bench.py > $OUT/gemm_sweep.log 2>&1; echo "sweep rc=$?"; cat $OUT/gemm_sweep.log ;;
+    attn) timeout 300 python tools/attn_bench.py > $OUT/attn_v2.log 2>&1; echo "attn v2 rc=$?"; tail -12 $OUT/attn_v2.log
+          M5_ATTN_V1=1 timeout 300 python tools/attn_bench.py > $OUT/attn_v1.log 2>&1; echo "attn v1 rc=$?"; tail -8 $OUT/attn_v1.log ;;
     gemm) timeout 300 python tools/gemm_bench.py > $OUT/gemm_v2.log 2>&1; echo "gemm v2 rc=$?"; cat $OUT/gemm_v2.log | tail -25
           M5_GEMM_V1=1 timeout 300 python tools/gemm_bench.py > $OUT/gemm_v1.log 2>&1; echo "gemm v1 rc=$?"; tail -25 $OUT/gemm_v1.log ;;
     bench) timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -3 $OUT/bench.err ;;
