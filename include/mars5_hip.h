@@ -209,6 +209,10 @@ int m5_event_record(void* ev, void* stream);
 int m5_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
 int m5_event_destroy(void* ev);
 
+/* Diagnostics: placement census of a grid (nblocks x threads, lds_bytes of LDS per workgroup);
+ * out[6 * block] = {XCC_ID, HW_ID, start clock lo/hi, end clock lo/hi}.  tools/census.py. */
+int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int spin, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -2,8 +2,7 @@
 //
 // One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns 32 queries for the
 // whole key loop.  Per 64-key tile, K [64 keys][64 d] and V^T [64 d][64 keys] arrive by LDS-DMA
-// (16 x 1 KiB instructions, 3 stages in flight, one barrier per tile; 48 KiB per workgroup so
-// three workgroups share a CU and cover each other's softmax VALU with MFMAs).
+// (16 x 1 KiB instructions, 3 LDS stages, one barrier per tile; 48 KiB per workgroup).
 //
 // Everything is computed TRANSPOSED so that the query index is the MFMA column (lane & 31) in both
 // products and all softmax state is lane-local -- no cross-lane traffic for the running max /
@@ -18,10 +17,12 @@
 // LDS image of both tiles: [64 rows][128 B], 16-byte chunk index XOR ((row >> 1) & 7), applied on
 // the DMA source address and on the fragment reads (conflict-free for ds_read_b128's lane groups).
 #include "common.h"
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
 typedef __attribute__((ext_vector_type(16))) float f16_t;
+typedef __attribute__((ext_vector_type(2))) float f2_t;
 
 namespace {
 
@@ -45,14 +46,18 @@ __device__ inline void glds16(const unsigned char* gsrc, uint32_t lds_base) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
 }
 
-constexpr int NWAVE = 4, QB = 32 * NWAVE, KT = 64;
+constexpr int KT = 64;
 constexpr int TILE_B = 64 * 128;                 // one operand tile: 64 rows x 128 bytes
 constexpr int STAGE_B = 2 * TILE_B;              // K tile + V^T tile
 constexpr int NST = 3;
 
-template <typename T>
-__global__ __launch_bounds__(NWAVE * 64, 3) void attn16_kernel(M5AttnArgs p) {
+// VARIANT: 0 = product kernel; 1..3 = timing ablations (WRONG results; M5_ATTN_VARIANT, tools only):
+// 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.
+template <typename T, int NWAVE, int VARIANT>
+__global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p) {
     using st = typename T::storage;
+    constexpr int QB = 32 * NWAVE;
+    constexpr int NJ = 16 / NWAVE;                  // DMA instructions per wave per tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_B];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,33 +88,40 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn16_kernel(M5AttnArgs p) {
         qf[ds] = *reinterpret_cast<const uint4*>(Qg + ((int64_t)qrow * p.q_rs + ds * 16 + hh * 8) * 2);
 
     // ---- DMA assignment: instruction q = 4 wave + j; q < 8: K rows 8q..8q+7, else V^T rows 8(q-8)..
-    // lane l -> row 8q' + (l >> 3), chunk slot l & 7, source chunk slot ^ ((row >> 1) & 7)
+    // lane l -> row 8q' + (l >> 3), chunk slot l & 7, source chunk slot ^ ((row >> 1) & 7).
+    // Tiles are loaded in order, so each lane just advances a running source pointer (K: 64 rows,
+    // V^T: 128 bytes along the row); K rows past Sk - 1 (last tile only) read row Sk - 1 instead
+    // (valid memory; those keys are masked by index).
     const int srow = lane >> 3;
-    const unsigned char* gsrc[4];
-    int64_t gstep[4];
+    const unsigned char* gcur[NJ];
+    const unsigned char* klast[NJ];
+    int64_t gstep[NJ];
+    int krow_of[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = wave * 4 + j;                              // wave-uniform
+    for (int j = 0; j < NJ; ++j) {
+        const int q = wave * NJ + j;                              // wave-uniform
         const int row = (q & 7) * 8 + srow;
         const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        if (q < 8) {       // K tile: rows are keys (clamped to valid memory; masked by index later)
-            gsrc[j] = Kg + chunk * 16;                           // + min(kbase + row, Sk-1) * k_rs * 2 per tile
-            gstep[j] = row;
-        } else {           // V^T tile: rows are d, the tile advances along the row
-            gsrc[j] = Vg + (int64_t)row * p.vt_ds * 2 + chunk * 16;
-            gstep[j] = -1;
+        if (q < 8) {
+            gcur[j] = Kg + (int64_t)row * p.k_rs * 2 + chunk * 16;
+            klast[j] = Kg + (int64_t)(p.Sk - 1) * p.k_rs * 2 + chunk * 16;
+            gstep[j] = (int64_t)KT * p.k_rs * 2;
+            krow_of[j] = row;
+        } else {
+            gcur[j] = Vg + (int64_t)row * p.vt_ds * 2 + chunk * 16;
+            klast[j] = gcur[j];
+            gstep[j] = KT * 2;
+            krow_of[j] = -(1 << 30);                             // never past the end
         }
     }
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    auto stage_load = [&](int stage, int kt) {
-        const int kbase = kt * KT;
-        const uint32_t sb = lds_base + stage * STAGE_B + wave * 4 * 1024;
+    auto stage_load = [&](int stage, int kt) {                   // called with kt = 0, 1, 2, ... in order
+        const int over = kt * KT - p.Sk;                         // row r is past the end iff r + over >= 0
+        const uint32_t sb = lds_base + stage * STAGE_B + wave * NJ * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned char* src = (gstep[j] >= 0)
-                ? gsrc[j] + (int64_t)min(kbase + (int)gstep[j], p.Sk - 1) * p.k_rs * 2
-                : gsrc[j] + (int64_t)kbase * 2;
-            glds16(src, sb + j * 1024);
+        for (int j = 0; j < NJ; ++j) {
+            glds16((krow_of[j] + over >= 0) ? klast[j] : gcur[j], sb + j * 1024);
+            gcur[j] += gstep[j];
         }
     };
 
@@ -142,60 +154,78 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn16_kernel(M5AttnArgs p) {
     float m_run = -INFINITY, l_run = 0.f;
     const float sc2 = p.scale * 1.4426950408889634f;          // scores in the exp2 domain
 
-    if (ntiles > 0) stage_load(0, 0);
-    if (ntiles > 1) stage_load(1, 1);
-    int slot = 0;
-    for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile kt landed, kt+1 may be in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 2 < ntiles) stage_load(slot == 0 ? 2 : slot - 1, kt + 2);
-        const unsigned char* sb = lds + slot * STAGE_B;
-        slot = (slot == 2) ? 0 : slot + 1;
-        const int kbase = kt * KT;
-
-        // ---- S^T = K . Q^T : sacc[kb][8 m + j] = score(key kbase + 32 kb + 16 m + 8 hh + j, query l31)
-        f16_t sacc[2];
+    // S^T = K . Q^T of one tile: s[kb][8 m + j] = score(key 64 kt + 32 kb + 16 m + 8 hh + j, query l31)
+    auto qk_tile = [&](const unsigned char* sb, f16_t (&s)[2]) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
             for (int ds = 0; ds < 4; ++ds) {
                 const uint4 a = *reinterpret_cast<const uint4*>(sb + koffs[kb][ds]);
-                sacc[kb] = mfma32<T>(a, qf[ds], sacc[kb]);
+                s[kb] = mfma32<T>(a, qf[ds], s[kb]);
             }
         }
-        // ---- scale, mask (only tiles that touch the key limit or the causal diagonal)
+    };
+    // softmax of tile kt (scores in `s`, overwritten by the probabilities) and O^T += V^T . P^T
+    auto softmax_pv = [&](const unsigned char* sb, int kt, f16_t (&s)[2]) {
+        const int kbase = kt * KT;
+        // mask (only tiles that touch the key limit or the causal diagonal); online softmax in the
+        // exp2 domain with the score scale folded into the exponent's fma:
+        //   p = exp2(s * sc2 - m),  m = running max of s * sc2   (sc2 > 0, so max commutes)
+        // VALU per lane and tile: 16 v_max3 + 16 v_pk_fma + 32 v_exp + 16 v_pk_add + 16 cvt_pk.
         const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);
-        float mx = -INFINITY;
+        if (need_mask) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float s = sacc[kb][r] * sc2;
-                if (need_mask) {
+                for (int r = 0; r < 16; ++r) {
                     const int kidx = kbase + 32 * kb + 16 * (r >> 3) + 8 * hh + (r & 7);
                     const bool vis = kidx < kl && (!p.causal || kidx <= qpos);
-                    s = vis ? s : -INFINITY;
+                    s[kb][r] = vis ? s[kb][r] : -INFINITY;
                 }
-                sacc[kb][r] = s;
-                mx = fmaxf(mx, s);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        }
+        if (VARIANT == 3) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    st tmp[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) tmp[j] = T::from_f32(s[kb][8 * m + j]);
+                    const uint4 pb = *reinterpret_cast<const uint4*>(tmp);
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(sb + voffs[db][2 * kb + m]);
+                        oacc[db] = mfma32<T>(a, pb, oacc[db]);
+                    }
+                }
+            l_run = 1.f;
+            return;
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);      // -> v_max3_f32
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc2;
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);      // m_run = -inf -> 0
-        float ps = 0.f;
+        const f2_t sc2v = {sc2, sc2}, mneg = {-m_use, -m_use};
+        f2_t psum = {0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(sacc[kb][r] - m_use);   // masked -> 0
-                sacc[kb][r] = e;
-                ps += e;
+            for (int r = 0; r < 16; r += 2) {
+                const f2_t sv = {s[kb][r], s[kb][r + 1]};
+                const f2_t arg = __builtin_elementwise_fma(sv, sc2v, mneg);          // masked: -inf
+                f2_t e;
+                e[0] = __builtin_amdgcn_exp2f(arg[0]);
+                e[1] = __builtin_amdgcn_exp2f(arg[1]);
+                s[kb][r] = e[0];
+                s[kb][r + 1] = e[1];
+                psum += e;
             }
-        l_run = l_run * alpha + ps;                  // per half-lane partial sum; halves merged at the end
+        l_run = l_run * alpha + (psum[0] + psum[1]);   // per half-lane partial sum; halves merged at the end
         m_run = m_new;
         if (!__all(alpha == 1.0f)) {
 #pragma unroll
@@ -203,14 +233,13 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn16_kernel(M5AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         }
-        // ---- O^T += V^T . P^T
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 st tmp[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tmp[j] = T::from_f32(sacc[kb][8 * m + j]);
+                for (int j = 0; j < 8; ++j) tmp[j] = T::from_f32(s[kb][8 * m + j]);
                 const uint4 pb = *reinterpret_cast<const uint4*>(tmp);
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
@@ -218,6 +247,35 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn16_kernel(M5AttnArgs p) {
                     oacc[db] = mfma32<T>(a, pb, oacc[db]);
                 }
             }
+    };
+
+    // ---- key loop, software-pipelined across tiles: the S^T MFMAs of tile kt+1 are issued BEFORE
+    // the softmax VALU work of tile kt, so one wave keeps the matrix pipe and the VALU busy at the
+    // same time (there are only ~1.4 waves per SIMD at NAR sizes: no other wave would cover it).
+    // Two score register sets ping-pong (loop unrolled by two, no register moves).
+    // Per tile: wait tile kt+1 -> barrier -> DMA tile kt+2 into the slot tile kt-1 used.
+    if (ntiles > 0) stage_load(0, 0);
+    if (ntiles > 1) stage_load(1, 1);
+    f16_t sA[2], sB[2];
+    if (ntiles > 0) {
+        if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        qk_tile(lds, sA);
+    }
+    int slot = 0;                                                // LDS slot of tile kt
+    auto step = [&](int kt, f16_t (&cur)[2], f16_t (&nxt)[2]) {
+        const int s1 = (slot == 2) ? 0 : slot + 1;               // slot of tile kt+1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile kt+1 (the only DMA in flight) landed
+        if (VARIANT != 2) __syncthreads();                       // ... for every wave; tile kt-1 fully consumed
+        if (VARIANT != 1 && kt + 2 < ntiles) stage_load(slot == 0 ? 2 : slot - 1, kt + 2);
+        if (kt + 1 < ntiles) qk_tile(lds + s1 * STAGE_B, nxt);
+        softmax_pv(lds + slot * STAGE_B, kt, cur);
+        slot = s1;
+    };
+    for (int kt = 0; kt < ntiles; kt += 2) {
+        step(kt, sA, sB);
+        if (kt + 1 < ntiles) step(kt + 1, sB, sA);
     }
 
     // ---- normalise and store: oacc[db][r] = O[query l31][d = 32 db + (r&3) + 8 (r>>2) + 4 hh]
@@ -243,9 +301,25 @@ __global__ __launch_bounds__(NWAVE * 64, 3) void attn16_kernel(M5AttnArgs p) {
 int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     if ((a->o_rs % 4) || (a->o_bs % 4) || ((uintptr_t)a->o & 7)) return 1;      // 8-byte output vectors
     if ((a->k_rs % 8) || (a->q_rs % 8) || (a->vt_ds % 8)) return 1;
-    dim3 grid((a->Sq + QB - 1) / QB, a->H, a->B);
-    if (dtype == M5_F16) hipLaunchKernelGGL(attn16_kernel<F16T>, grid, dim3(NWAVE * 64), 0, s, *a);
-    else hipLaunchKernelGGL(attn16_kernel<BF16T>, grid, dim3(NWAVE * 64), 0, s, *a);
+    // M5_ATTN_NW / M5_ATTN_VARIANT: tuning + ablation hooks (tools/attn_bench.py); product = 4 waves, variant 0
+    static const int nw = [] { const char* e = getenv("M5_ATTN_NW"); return e ? atoi(e) : 4; }();
+    static const int var = [] { const char* e = getenv("M5_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+#define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a)
+    if (dtype == M5_F16) {
+        M5_A16(F16T, 4, 0);
+    } else if (nw == 2) {
+        M5_A16(BF16T, 2, 0);
+    } else if (nw == 8) {
+        M5_A16(BF16T, 8, 0);
+    } else {
+        switch (var) {
+            case 1: M5_A16(BF16T, 4, 1); break;
+            case 2: M5_A16(BF16T, 4, 2); break;
+            case 3: M5_A16(BF16T, 4, 3); break;
+            default: M5_A16(BF16T, 4, 0); break;
+        }
+    }
+#undef M5_A16
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

@@ -51,3 +51,32 @@ extern "C" int m5_event_destroy(void* ev) {
     if (!ev) return M5_ERR_ARG;
     return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? M5_OK : M5_ERR_LAUNCH;
 }
+
+// ---- placement census (diagnostics; tools/census.py): where does the dispatcher put the
+// workgroups of a grid with this shape?  Each workgroup records {XCC_ID, HW_ID, start, end clock}
+// and spins for `spin` clock ticks so that the whole grid is co-resident when it fits.
+namespace {
+__global__ void census_kernel(uint32_t* out, int lds_bytes, int spin) {
+    extern __shared__ unsigned char dyn[];
+    uint32_t xcc, hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    const uint64_t t0 = __builtin_readcyclecounter();
+    if (lds_bytes > 0) dyn[threadIdx.x % lds_bytes] = (unsigned char)threadIdx.x;
+    while ((int64_t)(__builtin_readcyclecounter() - t0) < spin) __builtin_amdgcn_s_sleep(8);
+    const uint64_t t1 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) {
+        uint32_t* o = out + (size_t)blockIdx.x * 6;
+        o[0] = xcc; o[1] = hwid; o[2] = (uint32_t)t0; o[3] = (uint32_t)(t0 >> 32); o[4] = (uint32_t)t1; o[5] = (uint32_t)(t1 >> 32);
+    }
+}
+}  // namespace
+
+extern "C" int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int spin, void* stream) {
+    if (!out || nblocks <= 0 || threads <= 0 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024) return M5_ERR_ARG;
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)census_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(census_kernel, dim3(nblocks), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, out, lds_bytes, spin);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
