@@ -1,0 +1,141 @@
+"""Utterance-level sharding across the GPUs of one node.
+
+Utterances are independent (the reference's ``tts()`` is per-utterance, ``inference.py:201-307``; the
+only shared state is the RNG), so the multi-GPU form of the hot path is REPLICAS: one process per
+GPU, full weights on each, requests partitioned by estimated cost.  The only collectives are the
+request scatter and the result gather (~30 KB per utterance each way) -- ``torch.distributed`` over
+RCCL/xGMI on the GPU box (backend ``nccl``), ``gloo`` in the CPU tests.  Per-utterance seeds make the
+result of an utterance independent of which rank ran it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class Request:
+    idx: int                    # position in the caller's batch
+    text_ids: torch.Tensor      # (Lt,) int64: tokenised "<|startoftext|> transcript text <|endoftext|>"
+    ref_codes: torch.Tensor     # (Lc, 8) int64 Encodec codes of the reference audio
+    seed: int                   # per-utterance RNG seed (placement-independent results)
+    n_gen_est: int = 450        # expected generated frames (cost model only)
+
+
+def estimate_cost(req: Request) -> float:
+    """Relative cost of one deep-clone utterance: AR decode steps (~ generated frames) stream the
+    weights once each; every NAR step is quadratic-ish in S = 2 Lc + G (attention) on top of a
+    linear GEMM term."""
+    lc, g = int(req.ref_codes.shape[0]), int(req.n_gen_est)
+    s = 2 * lc + g
+    return 0.8 * g + 200 * (3.0e-3 * s + 4.0e-7 * s * s)
+
+
+def lpt_partition(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Longest-processing-time-first: items by decreasing cost onto the least-loaded rank.
+    Deterministic (ties by index), so every rank computes the same partition."""
+    order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
+    loads = [0.0] * world
+    parts: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (loads[k], k))
+        parts[r].append(i)
+        loads[r] += costs[i]
+    return parts
+
+
+def _dev(group=None) -> torch.device:
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def _pack(reqs: List[Request]) -> torch.Tensor:
+    """[n, then per request: idx, seed, n_gen_est, Lt, Lc, text_ids..., ref_codes (row-major)...]"""
+    parts = [torch.tensor([len(reqs)], dtype=torch.int64)]
+    for r in reqs:
+        parts.append(torch.tensor([r.idx, r.seed, r.n_gen_est, r.text_ids.numel(), r.ref_codes.shape[0]], dtype=torch.int64))
+        parts.append(r.text_ids.reshape(-1).to(torch.int64).cpu())
+        parts.append(r.ref_codes.reshape(-1).to(torch.int64).cpu())
+    return torch.cat(parts)
+
+
+def _unpack(buf: torch.Tensor) -> List[Request]:
+    buf = buf.cpu()
+    n, p, out = int(buf[0]), 1, []
+    for _ in range(n):
+        idx, seed, n_gen, lt, lc = (int(v) for v in buf[p:p + 5])
+        p += 5
+        text = buf[p:p + lt].clone()
+        p += lt
+        codes = buf[p:p + lc * 8].reshape(lc, 8).clone()
+        p += lc * 8
+        out.append(Request(idx, text, codes, seed, n_gen))
+    return out
+
+
+def scatter_requests(requests: Optional[List[Request]], src: int = 0, group=None) -> List[Request]:
+    """Rank `src` holds the whole batch; every rank returns its own shard (LPT by estimated cost).
+    One broadcast of the per-rank payload sizes + one ``dist.scatter`` of padded int64 payloads."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _dev(group)
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    payloads: List[torch.Tensor] = []
+    if rank == src:
+        assert requests is not None
+        parts = lpt_partition([estimate_cost(r) for r in requests], world)
+        payloads = [_pack([requests[i] for i in part]) for part in parts]
+        sizes = torch.tensor([p.numel() for p in payloads], dtype=torch.int64, device=dev)
+    dist.broadcast(sizes, src=src, group=group)
+    width = int(sizes.max())
+    mine = torch.zeros(width, dtype=torch.int64, device=dev)
+    chunks = None
+    if rank == src:
+        chunks = [torch.cat([p, torch.zeros(width - p.numel(), dtype=torch.int64)]).to(dev) for p in payloads]
+    dist.scatter(mine, chunks, src=src, group=group)
+    return _unpack(mine[: int(sizes[rank])])
+
+
+def gather_results(results: List[Tuple[int, torch.Tensor]], n_total: int, dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+    """results: (request idx, codes (G, 8) int64) of this rank.  Rank `dst` returns the codes of all
+    `n_total` requests in batch order; other ranks return None.  One all-reduce (max payload width)
+    + one ``dist.gather``."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _dev(group)
+    parts = [torch.tensor([len(results)], dtype=torch.int64)]
+    for idx, codes in results:
+        parts.append(torch.tensor([idx, codes.shape[0]], dtype=torch.int64))
+        parts.append(codes.reshape(-1).to(torch.int64).cpu())
+    buf = torch.cat(parts)
+    width = torch.tensor([buf.numel()], dtype=torch.int64, device=dev)
+    dist.all_reduce(width, op=dist.ReduceOp.MAX, group=group)
+    w = int(width)
+    mine = torch.cat([buf, torch.zeros(w - buf.numel(), dtype=torch.int64)]).to(dev)
+    bins = [torch.zeros(w, dtype=torch.int64, device=dev) for _ in range(world)] if rank == dst else None
+    dist.gather(mine, bins, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out: List[Optional[torch.Tensor]] = [None] * n_total
+    for b in bins:
+        b = b.cpu()
+        n, p = int(b[0]), 1
+        for _ in range(n):
+            idx, g = int(b[p]), int(b[p + 1])
+            p += 2
+            out[idx] = b[p:p + g * 8].reshape(g, 8).clone()
+            p += g * 8
+    assert all(o is not None for o in out), "gather_results: missing utterances"
+    return out  # type: ignore[return-value]
+
+
+def run_sharded(requests: Optional[List[Request]], n_total: int, worker: Callable[[Request], torch.Tensor],
+                src: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+    """scatter -> each rank runs `worker(request) -> (G, 8) codes` on its shard (seeded per utterance)
+    -> gather on `src`."""
+    shard = scatter_requests(requests, src=src, group=group)
+    done = []
+    for r in shard:
+        torch.manual_seed(r.seed)
+        done.append((r.idx, worker(r)))
+    return gather_results(done, n_total, dst=src, group=group)
