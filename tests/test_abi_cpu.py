@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads (no GPU needed for that) and
+exports exactly the entry points ``include/mars5_hip.h`` declares; argument validation answers with
+status codes, never exceptions or crashes; the host-side containers keep the reference's surface."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "mars5_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(m5_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_header_symbol():
+    from mars5_tts_amd import _lib
+    names = _header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(_lib.lib, n), f"libmars5_hip.so does not export {n}"
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes prototype table and header disagree"
+    assert _lib.lib.m5_version() == 1
+    assert b"gfx950" in _lib.lib.m5_build_info()
+
+
+def test_argument_validation_returns_status_codes():
+    from mars5_tts_amd import _lib
+    lib = _lib.lib
+    # null pointers / bad sizes are rejected before any launch (safe to call without a GPU)
+    assert lib.m5_gemm(_lib.BF16, None, 64, None, 64, None, None, 64, 8, 8, 64, _lib.EPI_F32, None, 1, 0, 0, 0, 0, None) == _lib.M5_ERR_ARG
+    assert lib.m5_layernorm(_lib.BF16, None, 0, None, None, 1e-5, None, 0, 1, 64, 1, 0, 0, None) == _lib.M5_ERR_ARG
+    assert lib.m5_attention(_lib.BF16, None, None) == _lib.M5_ERR_ARG
+    assert lib.m5_ar_sample(None, None) == _lib.M5_ERR_ARG
+    assert lib.m5_nar_sample(None, None) == _lib.M5_ERR_ARG
+    assert lib.m5_graph_begin(None) == _lib.M5_ERR_ARG
+    with pytest.raises(_lib.Mars5HipError):
+        _lib.check(_lib.M5_ERR_UNSUPPORTED, "unit test")
+
+
+def test_inference_config_surface_matches_reference():
+    """21 fields, names and defaults of reference inference.py:24-77."""
+    from inference import InferenceConfig
+    cfg = InferenceConfig()
+    want = dict(temperature=0.7, top_k=200, top_p=0.2, typical_p=1.0, freq_penalty=3, presence_penalty=0.4, rep_penalty_window=80,
+                eos_penalty_decay=0.5, eos_penalty_factor=1, eos_estimated_gen_length_factor=1.0, timesteps=200, x_0_temp=0.7,
+                q0_override_steps=20, nar_guidance_w=3, max_prompt_dur=12, generate_max_len_override=-1, deep_clone=True,
+                use_kv_cache=True, trim_db=27, beam_width=1, ref_audio_pad=0)
+    assert {k: getattr(cfg, k) for k in want} == want
+    assert len(cfg.__dataclass_fields__) == 21
+
+
+def test_containers_take_reference_state_dict_names(tiny_bundle):
+    from mars5_tts_amd import model
+    a, n = tiny_bundle.ar_shape, tiny_bundle.nar_shape
+    lm = model.CodecLM(a.n_vocab, dim=a.dim, nhead=a.nhead, n_layers=a.n_layers, n_spk_layers=a.n_spk_layers,
+                       dim_ff_scale=a.hidden_dim / a.dim + 1e-9)
+    lm.load_state_dict(tiny_bundle.ar_ckpt["model"])
+    sd = lm.state_dict()
+    for k in ("embed.weight", "ar.layers.0.attention.wq.weight", "ar.layers.0.feed_forward.w1.weight", "ar.norm.weight",
+              "ar.output.weight", "spk_identity_emb.weight", "ref_chunked_emb.embs.0.weight"):
+        assert k in sd, k
+    nar = model.ResidualTransformer(n.n_text_vocab, n_quant=n.n_quant, dim=n.dim, nhead=n.nhead, enc_layers=n.enc_layers,
+                                    dec_layers=n.dec_layers, n_spk_layers=n.n_spk_layers, t_emb_dim=n.t_emb_dim, p_cond_drop=0)
+    nar.load_state_dict(tiny_bundle.nar_ckpt["model"])
+    for k in ("tfm.decoder.layers.0.multihead_attn.in_proj_weight", "residual_decoder.7.1.weight", "text_embed.weight"):
+        assert k in nar.state_dict(), k
+    with pytest.raises(Exception):
+        bad = dict(tiny_bundle.ar_ckpt["model"])
+        bad.pop("ar.norm.weight")
+        lm.load_state_dict(bad)
