@@ -133,11 +133,11 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
         sess.stream.synchronize()
     finally:
         ops.gemm, ops.attention = orig_gemm, orig_attn
-    names = {L.EPI_F32: "gemm_kernel<T,EPI_F32> (heads)", L.EPI_RESIDUAL: "gemm_kernel<T,EPI_RESIDUAL>",
-             L.EPI_SWIGLU: "gemm_kernel<T,EPI_SWIGLU>", L.EPI_QKV: "gemm_kernel<T,EPI_QKV>"}
+    names = {L.EPI_F32: "gemm16_kernel<EPI_F32> (7 heads, batched)", L.EPI_RESIDUAL: "gemm16_kernel<EPI_RESIDUAL> (out_proj / cross out_proj / linear2)",
+             L.EPI_SWIGLU: "gemm16_kernel<EPI_SWIGLU>", L.EPI_QKV: "gemm16_kernel<EPI_QKV> (self qkv / cross q)"}
     agg = {}
     for kind, key, flops, e0, e1, shp in rec:
-        nm = names.get(key, f"gemm epi {key}") if kind == "gemm" else ("attn_kernel<T> self" if key > 64 * 4 else "attn_kernel<T> cross")
+        nm = names.get(key, f"gemm epi {key}") if kind == "gemm" else ("attn16_kernel self" if key > 64 * 4 else "attn16_kernel cross")
         a = agg.setdefault(nm, dict(ms=0.0, flops=0.0, n=0, shape=shp))
         a["ms"] += e0.elapsed_ms(e1)
         a["flops"] += flops
@@ -147,8 +147,18 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     peak = PEAK_MFMA_TFLOPS[dtype_name]
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
     achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
+    traffic = None
+    try:        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json), same shapes
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = {"RESIDUAL": "gemm16 residual (out_proj / cross out_proj / linear2 mean)", "SWIGLU": "gemm16 swiglu 2816x6144x1024",
+               "QKV": "gemm16 qkv 2816x3072x1024", "attn16_kernel self": "attn16 self B2 H16 S1349"}
+        for k, v in key.items():
+            if k in dom[0] and dtype_name == "bf16" and S == 1349:
+                traffic = tj[v]["bytes_per_launch"]
+    except Exception:
+        traffic = None
     roof = dict(bound="mfma", kernel=dom[0], achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                traffic=None, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_timed=dom[1]["n"])
+                traffic=traffic, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_timed=dom[1]["n"])
     # NAR loop as a whole (graph replay + RNG + sample kernel), from the last timed utterance
     step_ms = ns["loop_ms"] / ns["steps"]
     nar = dict(ms_per_step=round(step_ms, 3), tflops=round(eng.flops_per_step(S, Le, s_out) / step_ms / 1e9, 1), S=S, Le=Le)
@@ -160,7 +170,7 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     bytes_tok = ae.weight_bytes_per_token() + kv_per_pos * (avg_len + 1)
     tok_ms = ars["decode_ms"] / max(ars["n_generated"] - 1, 1)
     gbs = bytes_tok / tok_ms / 1e6
-    ar = dict(bound="hbm", kernel="AR decode step (132 launches, hipGraph)", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+    ar = dict(bound="hbm", kernel="AR decode step (132 launches: 26 x {gemv qkv+rope, attn_decode, gemv wo, gemv w13+swiglu, gemv w2} + head + sampler, hipGraph)", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
               frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_token=int(bytes_tok), us_per_token=round(1e3 * tok_ms, 1))
     return roof, ar, nar, kernels
 

@@ -213,6 +213,10 @@ int m5_event_destroy(void* ev);
  * out[6 * block] = {XCC_ID, HW_ID, start clock lo/hi, end clock lo/hi}.  tools/census.py. */
 int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int spin, void* stream);
 
+/* Diagnostics: n dependent trivial launches (blocks x threads; touch = 1: one read-modify-write of
+ * buf[0] per launch) on `stream` -- measures the per-launch floor, eager vs hipGraph.  tools/launch_floor.py. */
+int m5_debug_launch_chain(int32_t* buf, int n, int blocks, int threads, int touch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

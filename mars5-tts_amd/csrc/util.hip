@@ -80,3 +80,16 @@ extern "C" int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_
     M5_CHECK_LAUNCH();
     return M5_OK;
 }
+
+// ---- launch-floor probe (diagnostics; tools/launch_floor.py): n dependent trivial launches on a stream.
+namespace {
+__global__ void probe_kernel(int* p, int touch) {
+    if (touch && threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1;
+}
+}  // namespace
+extern "C" int m5_debug_launch_chain(int* buf, int n, int blocks, int threads, int touch, void* stream) {
+    if (!buf || n <= 0 || blocks <= 0 || threads <= 0) return M5_ERR_ARG;
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(probe_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, buf, touch);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
