@@ -249,7 +249,7 @@ class SynthBundle:
 
 
 def make_bundle(size: str = "tiny", seed: int = 0, text_merges: int = None, speech_merges: int = None,
-                dtype_round: str = None) -> SynthBundle:
+                dtype_round: str = None, sliding_window: int = None) -> SynthBundle:
     """size 'tiny' (CPU-test scale) or 'full' (the real MARS5 geometry, n_vocab 4096).
 
     full: text vocab 256+2813+2 = 3071, speech vocab 1024+0+1 = 1025 (merge-free: one AR
@@ -271,6 +271,9 @@ def make_bundle(size: str = "tiny", seed: int = 0, text_merges: int = None, spee
         a, n = tiny_ar_shape(n_vocab), tiny_nar_shape(n_text + 1)
     else:
         a, n = full_ar_shape(n_vocab), full_nar_shape(n_text + 1)
+    if sliding_window is not None:      # rotating-KV-cache tests: same weights, smaller window (reference model.py:44)
+        import dataclasses
+        a = dataclasses.replace(a, sliding_window=int(sliding_window))
     ar_sd, nar_sd = make_ar_state_dict(a, seed), make_nar_state_dict(n, seed + 1)
     if dtype_round is not None:
         dt = {"f16": torch.float16, "bf16": torch.bfloat16}[dtype_round]

@@ -103,7 +103,8 @@ def gen_ar(tag, b, lm, tt, st, n_ref, n_gen, deep_clone, sample_kwargs, seed, sa
     g = torch.Generator().manual_seed(seed)
     o_tokens, o_logits = O.ar_generate_oracle(b.ar_ckpt["model"], b.ar_shape.nhead, b.n_text, b.n_speech,
                                               st.special_tokens["<|endofspeech|>"], prompt, spk_ref,
-                                              prompt.shape[0] + n_gen, p, generator=g, return_logits=True)
+                                              prompt.shape[0] + n_gen, p, generator=g, return_logits=True,
+                                              sliding_window=b.ar_shape.sliding_window)
     assert torch.equal(out, o_tokens), f"{tag}: oracle tokens differ from reference\n{out}\n{o_tokens}"
     err = max(float((a - c).abs().max()) for a, c in zip(rec, o_logits))
     print(f"[{tag}] P={prompt.shape[0]} gen={out.shape[0] - prompt.shape[0]} tokens equal; max |logit diff| = {err:.3e}")
@@ -251,6 +252,11 @@ def main():
     gen_nar("nar_tiny_deep", b, nar, tt, out, fi, rc, ttk, st, True, 24, 4321, True)
     out, fi, rc, ttk = gen_ar("ar_tiny_sampled_deep", b, lm, tt, st, 40, 24, True, sampled, 1234, False)
     out, fi, rc, ttk = gen_ar("ar_tiny_greedy_shallow", b, lm, tt, st, 40, 24, False, greedy, 1234, False)
+    # rotating KV cache (BASELINE config 5's mechanism at test scale): sliding_window 48, prompt 23 tokens,
+    # 100 generated tokens -> positions wrap the 48-slot buffer twice (nn_future.py:249-259)
+    bw = synth.make_bundle("tiny", seed=0, sliding_window=48)
+    lmw, _ = ref_models(bw)
+    gen_ar("ar_tiny_window48_shallow", bw, lmw, tt, st, 40, 100, False, dict(greedy, eos_penalty_factor=50.0, eos_penalty_decay=0.0), 1234, True)
     gen_nar("nar_tiny_shallow", b, nar, tt, out, fi, rc, ttk, st, False, 4, 4321, False)
 
     if args.full:

@@ -211,7 +211,7 @@ def mistral_forward(sd: Dict[str, Tensor], h: Tensor, positions: Tensor, st: ARS
 
 
 def codeclm_step(sd: Dict[str, Tensor], tokens: Tensor, ref_codes: Tensor, st: ARState, counter: int,
-                 nhead: int, recompute_spk: bool = False) -> Tensor:
+                 nhead: int, recompute_spk: bool = False, sliding_window: int = 3000) -> Tensor:
     """CodecLM.forward with a KV cache (model.py:95-141): internal sequence is
     [spk_vec, tok_0 .. tok_{L-1}] so token i sits at position i+1; counter == 1 runs the
     whole prefix (prefill) and strips the speaker position; later steps feed the last
@@ -227,7 +227,7 @@ def codeclm_step(sd: Dict[str, Tensor], tokens: Tensor, ref_codes: Tensor, st: A
     else:
         x = sd["embed.weight"][tokens[-1:]]
         positions = torch.tensor([L])
-    return mistral_forward(sd, x, positions, st, nhead)[-1]
+    return mistral_forward(sd, x, positions, st, nhead, sliding_window=sliding_window)[-1]
 
 
 # ---- sampler chain  (samplers.py + ar_generate.py:74-115) ----------------------------
@@ -294,7 +294,7 @@ def draw_token(z: Tensor, q: Tensor) -> int:
 def ar_generate_oracle(sd: Dict[str, Tensor], nhead: int, n_text: int, n_speech: int, eos_special: int,
                        prompt: Tensor, ref_codes: Tensor, max_len: int, params: ARSamplingParams,
                        generator: Optional[torch.Generator] = None, noise: Optional[Tensor] = None,
-                       recompute_spk: bool = False, return_logits: bool = False):
+                       recompute_spk: bool = False, return_logits: bool = False, sliding_window: int = 3000):
     """ar_generate.py:15-165 for bs = beam = 1 with the KV cache.  prompt (P,) int64 (global
     ids), ref_codes (Lc, 8).  Returns the full sequence (prompt + generated, EOS not appended,
     ar_generate.py:121-131).  RNG: one Exp(1) vector of size V per step, from ``noise[step]``
@@ -308,7 +308,7 @@ def ar_generate_oracle(sd: Dict[str, Tensor], nhead: int, n_text: int, n_speech:
     all_logits = []
     while tokens.shape[0] < max_len:
         counter += 1
-        logits = codeclm_step(sd, tokens, ref_codes, st, counter, nhead, recompute_spk).float()
+        logits = codeclm_step(sd, tokens, ref_codes, st, counter, nhead, recompute_spk, sliding_window).float()
         if return_logits:
             all_logits.append(logits.clone())
         z = filter_logits(logits, prev, params, n_text, eos_idx)

@@ -32,7 +32,7 @@ def _lm(b, dt, dev):
     from mars5_tts_amd import model
     a = b.ar_shape
     lm = model.CodecLM(a.n_vocab, dim=a.dim, nhead=a.nhead, n_layers=a.n_layers, n_spk_layers=a.n_spk_layers,
-                       dim_ff_scale=a.hidden_dim / a.dim + 1e-9)
+                       dim_ff_scale=a.hidden_dim / a.dim + 1e-9, sliding_window=a.sliding_window)
     lm.load_state_dict(b.ar_ckpt["model"])
     return lm.to(dev).set_engine_dtype(dt)
 
@@ -76,6 +76,49 @@ def test_ar_tiny_f32_matches_reference_tokens(dev, tiny_bundle, gold_dir, tag, u
     noise = torch.stack([torch.empty(V).exponential_(1, generator=g) for _ in range(24)])
     out = _run_ar(lm, tt, st, fx, SAMPLERS[tag], 24, use_graph, noise)
     assert out.cpu().tolist() == fx["tokens"].tolist()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_ar_rotating_window_matches_reference(dev, gold_dir, use_graph):
+    """BASELINE config 5's mechanism (long-form decode past the sliding window) at test scale: the
+    reference was run with sliding_window = 48 for 100 tokens (positions wrap the rotating buffer
+    twice); the engine's slot = pos % window cache + decode attention over min(pos+1, window) keys
+    must give the same greedy tokens and the same logits."""
+    from mars5_tts_amd import synth
+    from mars5_tts_amd.ar_engine import ARSamplingConfig, ARSession
+    from mars5_tts_amd.ar_generate import ar_generate
+    fx = np.load(os.path.join(gold_dir, "ar_tiny_window48_shallow.npz"))
+    b = synth.make_bundle("tiny", seed=0, sliding_window=48)
+    tt, st = _toks(b)
+    lm = _lm(b, torch.float32, dev)
+    V = b.ar_shape.n_vocab
+    prompt = torch.from_numpy(fx["prompt"])
+    ref = torch.from_numpy(fx["ref_codes"])[0].T.contiguous()
+    out = ar_generate(tt, st, lm, prompt, ref, int(fx["first_codec_idx"]), max_len=prompt.shape[0] + 100, fp16=False,
+                      temperature=0.7, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4, eos_penalty_decay=0.0,
+                      eos_penalty_factor=50.0, n_phones_gen=round(len(TEXT)), vocode=False, noise=torch.ones(100, V),
+                      use_graph=use_graph, topk=1, top_p=0.2, penalty_window=80)
+    assert out.cpu().tolist() == fx["tokens"].tolist()
+    if use_graph:
+        return
+    # teacher-forced logits through both wraps of the 48-slot buffer
+    eng = lm.engine()
+    n_text = len(tt.vocab)
+    eos = n_text + st.special_tokens["<|endofspeech|>"]
+    sess = ARSession(eng, prompt.shape[0] + 100)
+    cfg = ARSamplingConfig(temperature=0.7, topk=1, top_p=0.2, alpha_frequency=3, alpha_presence=0.4, penalty_window=80,
+                           eos_penalty_factor=50.0, eos_penalty_decay=0.0, n_phones_gen=round(len(TEXT)))
+    sess.configure_sampler(cfg, n_text, eos, torch.ones(100, V, device=dev))
+    sess.prefill(prompt, ref)
+    stv = sess.stream.cuda_stream
+    errs = []
+    for i in range(100):
+        sess.enqueue_head_and_sample(stv)
+        sess.stream.synchronize()
+        errs.append(float((sess.logits.cpu() - torch.from_numpy(fx["logits"][i])).abs().max()))
+        if i < 99:
+            sess.enqueue_layers(stv)
+    assert max(errs) < 2e-4, (max(errs), errs.index(max(errs)))
 
 
 def test_ar_tiny_f32_logits_vs_reference(dev, tiny_bundle, gold_dir):

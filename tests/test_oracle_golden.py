@@ -77,6 +77,31 @@ def test_ar_golden(tiny_bundle, gold_dir, tag, deep, kw):
         np.testing.assert_allclose(torch.stack(logits).numpy(), fx["logits"], rtol=0, atol=5e-5)
 
 
+def test_ar_rotating_window_golden(gold_dir):
+    """Reference run with sliding_window = 48 (prompt 18 tokens + 100 generated: positions wrap the
+    rotating KV buffer twice, nn_future.py:249-259): the oracle reproduces tokens and logits."""
+    from mars5_tts_amd import synth
+    fx = np.load(os.path.join(gold_dir, "ar_tiny_window48_shallow.npz"))
+    b = synth.make_bundle("tiny", seed=0, sliding_window=48)
+    tt, st = _toks(b)
+    p = O.ARSamplingParams(temperature=0.7, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4, eos_penalty_decay=0.0,
+                           eos_penalty_factor=50.0, n_phones_gen=round(len(TEXT)), top_k=1, top_p=0.2, penalty_window=80)
+    prompt = torch.from_numpy(fx["prompt"])
+    ref = torch.from_numpy(fx["ref_codes"])[0].T.contiguous()
+    g = torch.Generator().manual_seed(int(fx["seed"]))
+    out, logits = O.ar_generate_oracle(b.ar_ckpt["model"], b.ar_shape.nhead, b.n_text, b.n_speech,
+                                       st.special_tokens["<|endofspeech|>"], prompt, ref, prompt.shape[0] + 100, p,
+                                       generator=g, return_logits=True, sliding_window=48)
+    assert out.shape[0] == prompt.shape[0] + 100 and out.shape[0] > 2 * 48
+    assert out.tolist() == fx["tokens"].tolist()
+    np.testing.assert_allclose(torch.stack(logits).numpy(), fx["logits"], rtol=0, atol=5e-5)
+    # and the window matters: an unbounded cache gives different logits once the buffer has wrapped
+    out2, logits2 = O.ar_generate_oracle(b.ar_ckpt["model"], b.ar_shape.nhead, b.n_text, b.n_speech,
+                                         st.special_tokens["<|endofspeech|>"], prompt, ref, prompt.shape[0] + 60, p,
+                                         generator=torch.Generator().manual_seed(int(fx["seed"])), return_logits=True)
+    assert float((torch.stack(logits2)[55] - torch.from_numpy(fx["logits"][55])).abs().max()) > 1e-3
+
+
 @pytest.mark.parametrize("tag", ["nar_tiny_deep", "nar_tiny_shallow"])
 def test_nar_golden(tiny_bundle, gold_dir, tag):
     fx = np.load(os.path.join(gold_dir, f"{tag}.npz"))
