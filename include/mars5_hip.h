@@ -217,6 +217,15 @@ int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int 
  * buf[0] per launch) on `stream` -- measures the per-launch floor, eager vs hipGraph.  tools/launch_floor.py. */
 int m5_debug_launch_chain(int32_t* buf, int n, int blocks, int threads, int touch, void* stream);
 
+/* Diagnostics: subsequent 16-bit m5_gemm launches record {shader clock, 100 MHz wall clock} at the entry
+ * and at the end of the main loop of workgroup 0 into buf[0..3] (device memory); NULL disables. */
+int m5_debug_gemm_clock(unsigned long long* buf);
+
+/* Diagnostics: operand-feed probe -- every workgroup stages the same L2-resident panel into LDS `iters`
+ * times; mode 0 LDS-DMA, 1 global_load -> ds_write, 2 global loads only.  tools/feed_probe.py. */
+int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int iters, int row_bytes, int mode, int blocks, int threads,
+                        float* sink, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

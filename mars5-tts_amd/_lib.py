@@ -118,6 +118,8 @@ PROTOTYPES = {
     "m5_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "m5_event_destroy": (C.c_int, [vp]),
     "m5_debug_census": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "m5_debug_gemm_clock": (C.c_int, [vp]),
+    "m5_debug_feed_probe": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "m5_debug_launch_chain": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }
 

@@ -215,8 +215,24 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
         }
     }
 
-    // ---- the wave's whole weight share in flight
+    // ---- epilogue operands that depend only on the row / position: issued now, consumed after the
+    // weight stream, so their L2 / HBM round trip is off the tail of the launch
     const int row0 = (blockIdx.x * NW + wave) * R;
+    float xold = 0.f, rcs = 1.f, rsn = 0.f;
+    int pos_e = 0;
+    if constexpr (EPI == M5_GEPI_RESIDUAL) {
+        if (lane < R && row0 + lane < a.N) xold = a.xres[row0 + lane];
+    } else if constexpr (EPI == M5_GEPI_QKV_ROPE) {
+        pos_e = a.state[M5_ST_POS];
+        const int n = row0 + 2 * lane;
+        if (lane < R / 2 && n + 1 < a.N && n < 2 * a.dim) {
+            const int d = (n % a.dim) & 63;
+            rcs = a.rope[((int64_t)pos_e * 32 + (d >> 1)) * 2];
+            rsn = a.rope[((int64_t)pos_e * 32 + (d >> 1)) * 2 + 1];
+        }
+    }
+
+    // ---- the wave's whole weight share in flight
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     u32x4 wv[R][NIT];
 #pragma unroll
@@ -322,7 +338,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
             float v = 0.f;
 #pragma unroll
             for (int r = 0; r < R; ++r) if (lane == r) v = acc[r];
-            a.xres[row0 + lane] += v;
+            a.xres[row0 + lane] = xold + v;
         }
     } else if constexpr (EPI == M5_GEPI_F32) {
         if (lane < R && row0 + lane < a.N) {
@@ -350,14 +366,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
             const int n = row0 + 2 * lane;
             const int D = a.dim;
             const int sec = n / D, c = n - sec * D, h = c >> 6, d = c & 63;
-            const int pos = a.state[M5_ST_POS];
+            const int pos = pos_e;
             const float x0 = round_dt<T>(va), x1 = round_dt<T>(vb);
             float o0 = x0, o1 = x1;
             if (sec < 2) {
-                const float cs = a.rope[((int64_t)pos * 32 + (d >> 1)) * 2];
-                const float sn = a.rope[((int64_t)pos * 32 + (d >> 1)) * 2 + 1];
-                o0 = x0 * cs - x1 * sn;
-                o1 = x0 * sn + x1 * cs;
+                o0 = x0 * rcs - x1 * rsn;
+                o1 = x0 * rsn + x1 * rcs;
             }
             st* dst;
             if (sec == 0) {

@@ -38,6 +38,8 @@ struct Gemm16Params {
     int64_t sA, sW, sC, sBias;       // batch strides, elements
     int M, N, K;
     int tilesM, tilesN, nblk, group_m;
+    unsigned long long* dbg;         // diagnostics: workgroup 0 records {shader clock, 100 MHz wall clock} at entry / exit
+    int vec16;                       // 16-bit outputs: rows / batch stride / base / width allow 16-byte row chunks (LDS-staged epilogue)
     int vec_c;                       // C rows / batch stride / base allow 16-byte (fp32) or 8-byte (16-bit) vectors
     int vt_vec;                      // V^T scatter may store 4 consecutive s as one 8-byte vector
     M5QkvScatter sc;
@@ -114,6 +116,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lg = lane >> 4;
+    const bool dbg_on = p.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+    unsigned long long* dbg = p.dbg + (blockIdx.x == 0 ? 0 : 8);
+    if (dbg_on) { dbg[0] = clock64(); dbg[1] = wall_clock64(); }
 
     // ---- workgroup -> tile: XCD-contiguous runs (bijective for any nblk), grouped order
     int t;
@@ -182,6 +187,34 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     const int Dm = p.sc.n_heads * p.sc.head_dim;
     if constexpr (EPI == M5_EPI_QKV) vblock = p.sec_kind[min((n0 + wn * TN * 16) / Dm, 2)] == 2;
 
+    // in-place residual: the old C values of this wave's tile are requested BEFORE the K loop (they come
+    // from HBM: 11.5 MB of fp32 per 2816 x 1024 launch) and consumed after it -- the epilogue then only writes
+    constexpr bool PRELOAD_C = (EPI == M5_EPI_RESIDUAL) && (TM * TN <= 16);
+    float4 oldpre[PRELOAD_C ? TM : 1][PRELOAD_C ? TN : 1];
+    if constexpr (PRELOAD_C) {
+        const float* Cr = reinterpret_cast<const float*>(p.C) + (int64_t)bz * p.sC;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = m0 + wm * TM * 16 + i * 16 + l15;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
+                oldpre[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < p.M && col < p.N) {
+                    const float* cp = Cr + (int64_t)row * p.ldc + col;
+                    if (p.vec_c && col + 3 < p.N) {
+                        oldpre[i][j] = *reinterpret_cast<const float4*>(cp);
+                    } else {
+                        oldpre[i][j].x = cp[0];
+                        if (col + 1 < p.N) oldpre[i][j].y = cp[1];
+                        if (col + 2 < p.N) oldpre[i][j].z = cp[2];
+                        if (col + 3 < p.N) oldpre[i][j].w = cp[3];
+                    }
+                }
+            }
+        }
+    }
+
     const int nk = p.K * 2 / BKB;
     const bool full_share = (NQ % NW == 0) || (wave < NQ % NW);     // this wave issues JN (else JN - 1) DMAs per stage
 #pragma unroll
@@ -226,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             }
         }
     }
-
+    if (dbg_on) { dbg[2] = clock64(); dbg[3] = wall_clock64(); }
     // ---- epilogue.  swapped layout: acc[i][j][r] = C[mw + 16 i + l15][nw + 16 j + 4 lg + r]
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
     constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL);
@@ -267,6 +300,70 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         return;
     }
 
+    // ---- 16-bit outputs (plain / SiLU / SwiGLU): stage the wave's output tile through LDS and store
+    // whole 16-byte row chunks.  Straight from the accumulator layout a SwiGLU store instruction writes
+    // 16 rows x 16 bytes (4 bytes per lane); measured 10 us of a 47 us K = 1024 SwiGLU launch went into
+    // that epilogue.  The stage buffers are dead after the last K-step, each wave owns a private slice.
+    if constexpr (EPI == M5_EPI_DT || EPI == M5_EPI_SILU_DT || EPI == M5_EPI_SWIGLU) {
+        constexpr int OUTC = (EPI == M5_EPI_SWIGLU) ? TN * 8 : TN * 16;   // output columns of the wave tile
+        constexpr int RB = OUTC * 2;                                      // bytes per output row
+        constexpr int RBS = RB + 16;                                      // padded LDS row stride
+        constexpr int CPR = RB / 16, RPP = 64 / (CPR > 0 ? CPR : 1);      // 16-byte chunks per row, rows per pass
+        if constexpr (RB % 16 == 0 && NW * TM * 16 * RBS <= NSTAGE * STAGE) {
+            if (p.vec16) {
+                __syncthreads();                                          // every wave is done reading the stages
+                unsigned char* ws = lds + wave * (TM * 16 * RBS);
+                const float* biasp = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
+                    float bv4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) bv4[r] = biasp ? biasp[min(col + r, p.N - 1)] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv4[r];
+                        unsigned char* dst = ws + (i * 16 + l15) * RBS;
+                        if constexpr (EPI == M5_EPI_SWIGLU) {
+                            st o[2];
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const float a = round_dt<T>(v[2 * h]), b = round_dt<T>(v[2 * h + 1]);
+                                const float sl = round_dt<T>(silu_fast(a));
+                                o[h] = T::from_f32(sl * b);
+                            }
+                            *reinterpret_cast<uint32_t*>(dst + (j * 8 + lg * 2) * 2) = *reinterpret_cast<const uint32_t*>(o);
+                        } else {
+                            if constexpr (EPI == M5_EPI_SILU_DT) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = silu_fast(v[r]);
+                            }
+                            *reinterpret_cast<uint2*>(dst + (j * 16 + lg * 4) * 2) = pack4<T>(v);
+                        }
+                    }
+                }
+                // read back 16-byte chunks: lane -> (row = pass * RPP + lane / CPR, chunk = lane % CPR)
+                const int rr = lane / CPR, ch = lane - rr * CPR;
+                const int nout = (EPI == M5_EPI_SWIGLU) ? p.N / 2 : p.N;
+                const int ocol = ((EPI == M5_EPI_SWIGLU) ? (n0 + wn * TN * 16) / 2 : (n0 + wn * TN * 16)) + ch * 8;
+                st* Cd = reinterpret_cast<st*>(p.C) + (int64_t)bz * p.sC;
+                const int mrow0 = m0 + wm * TM * 16;
+#pragma unroll
+                for (int pass = 0; pass < (TM * 16 + RPP - 1) / RPP; ++pass) {
+                    const int r = pass * RPP + rr;
+                    if (rr < RPP && r < TM * 16 && mrow0 + r < p.M && ocol < nout) {
+                        const uint4 val = *reinterpret_cast<const uint4*>(ws + r * RBS + ch * 16);
+                        *reinterpret_cast<uint4*>(Cd + (int64_t)(mrow0 + r) * p.ldc + ocol) = val;
+                    }
+                }
+                if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
+                return;
+            }
+        }
+    }
+
     // per-column-group constants (this lane's 4 consecutive columns of each of the TN tiles)
     float bv[TN][4];
 #pragma unroll
@@ -297,11 +394,16 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         }
     };
     float4 oldc[TN], oldn[TN];
-    if constexpr (EPI == M5_EPI_RESIDUAL) load_old(0, oldc);
+    if constexpr (EPI == M5_EPI_RESIDUAL && !PRELOAD_C) load_old(0, oldc);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         if constexpr (EPI == M5_EPI_RESIDUAL) {
-            if (i + 1 < TM) load_old(i + 1, oldn);
+            if constexpr (PRELOAD_C) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) oldc[j] = oldpre[i][j];
+            } else {
+                if (i + 1 < TM) load_old(i + 1, oldn);
+            }
         }
         const int row = mw + i * 16 + l15;
 #pragma unroll
@@ -363,11 +465,12 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 *reinterpret_cast<uint2*>(dst) = pack4<T>(v);   // Dm % 4 == 0: a 4-group never straddles N or a head
             }
         }
-        if constexpr (EPI == M5_EPI_RESIDUAL) {
+        if constexpr (EPI == M5_EPI_RESIDUAL && !PRELOAD_C) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) oldc[j] = oldn[j];
         }
     }
+    if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
 }
 
 template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC>
@@ -436,7 +539,14 @@ int pick_config(int M, int N, int K, int batch, int span_div) {
     return best;
 }
 
+unsigned long long* g_gemm_dbg = nullptr;
+
 }  // namespace
+
+extern "C" int m5_debug_gemm_clock(unsigned long long* buf) {   // diagnostics (tools/gemm_clock.py); nullptr disables
+    g_gemm_dbg = buf;
+    return M5_OK;
+}
 
 // Called by m5_gemm (gemm.hip) for F16 / BF16 operands after argument validation.
 int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -446,8 +556,13 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = sA; p.sW = sW; p.sC = sC; p.sBias = sBias;
     p.M = M; p.N = N; p.K = K;
+    p.dbg = g_gemm_dbg;
     const bool f32out = (epi == M5_EPI_F32 || epi == M5_EPI_RESIDUAL);
     const int cal = f32out ? 15 : 7;
+    {
+        const int nout = (epi == M5_EPI_SWIGLU) ? N / 2 : N;
+        p.vec16 = (!f32out && C && (ldc % 8 == 0) && (sC % 8 == 0) && (((uintptr_t)C & 15) == 0) && (nout % 8 == 0)) ? 1 : 0;
+    }
     p.vec_c = (C && (ldc % 4 == 0) && (sC % 4 == 0) && (((uintptr_t)C & cal) == 0)) ? 1 : 0;
     if (sc) {
         p.sc = *sc;

@@ -93,3 +93,66 @@ extern "C" int m5_debug_launch_chain(int* buf, int n, int blocks, int threads, i
     M5_CHECK_LAUNCH();
     return M5_OK;
 }
+
+// ---- operand-feed probe (diagnostics; tools/feed_probe.py): how many bytes per second can one CU
+// pull from an L2-resident panel into LDS, by LDS-DMA vs by register staging?  Every workgroup
+// (NW waves) repeatedly stages the same `panel_bytes` slice (its XCD-mates share it through L2).
+namespace {
+__device__ inline void probe_glds16(const unsigned char* gsrc, uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+template <int MODE>   // 0: LDS-DMA, 1: global_load_dwordx4 -> ds_write_b128, 2: global loads only (no LDS)
+__global__ void feed_probe_kernel(const unsigned char* src, int64_t panel_bytes, int iters, int row_bytes, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = blockDim.x >> 6;
+    // panel = rows of `row_bytes` (128-byte K-slab of each row, like a GEMM stage); XCD x reads panel x
+    const unsigned char* base = src + (int64_t)(blockIdx.x & 7) * panel_bytes;
+    const int64_t nchunk = panel_bytes / 1024;                  // 1 KiB wave-instructions in the panel
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)dyn;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (int64_t c = wave; c < nchunk; c += nw * 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t cc = min(c + (int64_t)u * nw, nchunk - 1);
+                // 8 rows x 128 B per instruction: lane -> row lane>>3, 16-B chunk lane&7, rows `row_bytes` apart
+                const unsigned char* g = base + (cc * 8 + (lane >> 3)) * (int64_t)row_bytes % panel_bytes + (lane & 7) * 16;
+                const uint32_t slot = (uint32_t)(((wave + u * nw) & 31) * 1024);
+                if (MODE == 0) probe_glds16(g, lds_base + slot);
+                else v[u] = *reinterpret_cast<const uint4*>(g);
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    *reinterpret_cast<uint4*>(dyn + ((wave + u * nw) & 31) * 1024 + lane * 16) = v[u];
+            } else if (MODE == 2) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].w;
+            }
+        }
+        if (MODE == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        acc ^= *reinterpret_cast<const uint32_t*>(dyn + (tid & 1023) * 16);
+    }
+    if (acc == 0x12345678u) sink[0] = 1.f;
+}
+}  // namespace
+extern "C" int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int iters, int row_bytes, int mode, int blocks, int threads,
+                                   float* sink, void* stream) {
+    if (!src || !sink || panel_bytes < 8192 || (panel_bytes % 1024) || iters <= 0 || blocks <= 0 || threads % 64 || row_bytes % 128) return M5_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = 32 * 1024;
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(feed_probe_kernel<0>, dim3(blocks), dim3(threads), lds, s, (const unsigned char*)src, panel_bytes, iters, row_bytes, sink); break;
+        case 1: hipLaunchKernelGGL(feed_probe_kernel<1>, dim3(blocks), dim3(threads), lds, s, (const unsigned char*)src, panel_bytes, iters, row_bytes, sink); break;
+        case 2: hipLaunchKernelGGL(feed_probe_kernel<2>, dim3(blocks), dim3(threads), lds, s, (const unsigned char*)src, panel_bytes, iters, row_bytes, sink); break;
+        default: return M5_ERR_ARG;
+    }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
