@@ -172,6 +172,7 @@ typedef struct {
     int32_t n_est; const float* eos_table;      /* eos_table[n], n = 0..n_est, or NULL       */
     float temperature; int32_t div_mode;         /* 0: z / T (CPU reference), 1: z * (1/T)    */
     int32_t top_k; float top_p;
+    float typical_p;                             /* samplers.py:96-122; > 0.999 disables (reference default 1.0) */
     const float* noise; int64_t noise_stride;    /* Exp(1) draws [step][V]                    */
     const float* embed; int32_t dim; float* xres;
 } M5SampleArgs;

@@ -77,7 +77,7 @@ class SampleArgs(C.Structure):
                 ("n_text", i32), ("eos_idx", i32),
                 ("n_est", i32), ("eos_table", vp),
                 ("temperature", f32), ("div_mode", i32),
-                ("top_k", i32), ("top_p", f32),
+                ("top_k", i32), ("top_p", f32), ("typical_p", f32),
                 ("noise", vp), ("noise_stride", i64),
                 ("embed", vp), ("dim", i32), ("xres", vp)]
 

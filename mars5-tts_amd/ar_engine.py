@@ -191,9 +191,6 @@ class ARSession:
     def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: torch.Tensor) -> None:
         """noise: (n_steps, V) fp32 device tensor of Exp(1) draws (one row per sampler call)."""
         m, s = self.m, self.m.shape
-        if not cfg.typical_p > 0.999:
-            raise NotImplementedError("typical_p <= 0.999 (samplers.py:96-122) is not on the device path yet; "
-                                      "the reference default 1.0 is a no-op")
         eos_tab = None
         n_est = 0
         if cfg.n_phones_gen is not None:
@@ -205,7 +202,7 @@ class ARSession:
                          max_len=self.max_len, alpha_frequency=cfg.alpha_frequency, alpha_presence=cfg.alpha_presence,
                          penalty_window=cfg.penalty_window, n_text=n_text, eos_idx=eos_idx, n_est=n_est,
                          eos_table=eos_tab.data_ptr() if eos_tab is not None else None, temperature=cfg.temperature,
-                         div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, noise=noise.data_ptr(),
+                         div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, typical_p=float(cfg.typical_p), noise=noise.data_ptr(),
                          noise_stride=s.n_vocab, embed=m.embed.data_ptr(), dim=s.dim, xres=self.xdec.data_ptr())
         self._sample_args = a
         self.n_noise = noise.shape[0]

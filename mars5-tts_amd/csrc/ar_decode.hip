@@ -531,6 +531,22 @@ __device__ inline float key_to_float(uint32_t k) {
     return __uint_as_float(u);
 }
 
+// in-LDS bitonic sort of n2 (power of two) 64-bit keys, ascending; 1024 threads; ends with a barrier
+__device__ inline void bitonic_sort_u64(unsigned long long* sk, int n2, int tid) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += 1024) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long x = sk[i], y = sk[l];
+                const bool asc = (i & k) == 0;
+                if ((x > y) == asc) { sk[i] = y; sk[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* sk = reinterpret_cast<unsigned long long*>(smem);            // V2 sort keys
@@ -574,18 +590,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
     }
     __syncthreads();
     // ---- bitonic sort ascending on (desc_key, index): value descending, index ascending
-    for (int k = 2; k <= V2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (V2 >> 1); t += 1024) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const unsigned long long x = sk[i], y = sk[l];
-                const bool asc = (i & k) == 0;
-                if ((x > y) == asc) { sk[i] = y; sk[l] = x; }
-            }
-            __syncthreads();
-        }
-    }
+    bitonic_sort_u64(sk, V2, tid);
     // ---- 6. top-k: threshold = k-th largest, keep everything >= it (samplers.py:70-74)
     if (tid == 0) {
         int nk = V;
@@ -644,9 +649,94 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
         n_keep = min(n_keep, nk2);
     }
     __syncthreads();
+    float v0f = v0;
+    // ---- 8. typical-p (samplers.py:96-122; a no-op at the reference default 1.0): over the kept set,
+    // normalized = log_softmax, ent = -sum p log p, keep the tokens whose |-log p - ent| is within the
+    // smallest-deviation prefix of cumulative mass `typical_p` (ties with the threshold kept).
+    if (a.typical_p <= 0.999f) {
+        float* fv = fs + V2;                                                 // values of the kept set
+        int* fid = reinterpret_cast<int*>(fs + 2 * V2);                      // ids of the kept set
+        float pt = 0.f;
+        for (int j = tid; j < n_keep; j += 1024) pt += expf(key_to_float((uint32_t)(sk[j] >> 32)) - v0);
+        const float St = block_sum<16>(pt, red);
+        const float logSt = logf(St);
+        float et = 0.f;
+        for (int j = tid; j < n_keep; j += 1024) {
+            const float nl = (key_to_float((uint32_t)(sk[j] >> 32)) - v0) - logSt;
+            if (nl > -INFINITY) et += nl * expf(nl);            // masked (-inf) entries: 0 * -inf, dropped like nansum does
+        }
+        const float ent = -block_sum<16>(et, red);
+        for (int j = tid; j < V2; j += 1024) {
+            unsigned long long key = 0xffffffffffffffffull;
+            if (j < n_keep) {
+                const float v = key_to_float((uint32_t)(sk[j] >> 32));
+                const float nl = (v - v0) - logSt;
+                const float shifted = fabsf((-nl) - ent);
+                fv[j] = v;
+                fid[j] = (int)(sk[j] & 0xffffffffu);
+                key = ((unsigned long long)__float_as_uint(shifted) << 32) | (unsigned)j;   // shifted >= 0: bit order = value order
+            }
+            sk[j] = key;                           // own slot only: read above, written here
+        }
+        __syncthreads();
+        bitonic_sort_u64(sk, V2, tid);             // ascending deviation
+        // cumulative probability in that order
+        float part_t = 0.f;
+        for (int j = tid; j < V2; j += 1024) {
+            float e = 0.f;
+            if (j < n_keep) e = expf((fv[(int)(sk[j] & 0xffffffffu)] - v0) - logSt);
+            fs[j] = e;
+            part_t += e;
+        }
+        __syncthreads();
+        const int per = V2 >> 10 ? V2 >> 10 : 1;
+        const int j0 = tid * per;
+        float loc = 0.f;
+        if (j0 < V2)
+            for (int q = 0; q < per; ++q) { loc += fs[j0 + q]; fs[j0 + q] = loc; }
+        float inc = loc;
+        const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float n = __shfl_up(inc, off);
+            if (lane >= off) inc += n;
+        }
+        __syncthreads();
+        if (lane == 63) red[wv] = inc;
+        __syncthreads();
+        float woff = 0.f;
+        for (int w = 0; w < wv; ++w) woff += red[w];
+        const float excl = woff + inc - loc;
+        if (j0 < V2)
+            for (int q = 0; q < per; ++q) fs[j0 + q] += excl;
+        __syncthreads();
+        int cnt_lt = 0;
+        for (int j = tid; j < n_keep; j += 1024) cnt_lt += (fs[j] < a.typical_p) ? 1 : 0;
+        int last = (int)(block_sum<16>((float)cnt_lt, red) + 0.5f);
+        last = min(last, n_keep - 1);
+        const uint32_t thr = (uint32_t)(sk[last] >> 32);
+        int cnt_keep = 0;
+        for (int j = tid; j < n_keep; j += 1024) cnt_keep += ((uint32_t)(sk[j] >> 32) <= thr) ? 1 : 0;   // sorted: a prefix
+        const int n_keep2 = (int)(block_sum<16>((float)cnt_keep, red) + 0.5f);
+        // survivors back into (desc_key(value), id) form for the draw; their maximum may have changed
+        float mx = -INFINITY;
+        unsigned long long mine[8];
+        int nm = 0;
+        for (int j = tid; j < n_keep2 && nm < 8; j += 1024) {
+            const int src = (int)(sk[j] & 0xffffffffu);
+            mine[nm++] = ((unsigned long long)desc_key(fv[src]) << 32) | (unsigned)fid[src];
+            mx = fmaxf(mx, fv[src]);
+        }
+        __syncthreads();
+        nm = 0;
+        for (int j = tid; j < n_keep2 && nm < 8; j += 1024) sk[j] = mine[nm++];
+        v0f = block_max<16>(mx, red);
+        n_keep = n_keep2;
+        __syncthreads();
+    }
     // ---- 9. log_softmax over the kept set, p / q, argmax (ar_generate.py:102,115)
     float part = 0.f;
-    for (int j = tid; j < n_keep; j += 1024) part += expf(key_to_float((uint32_t)(sk[j] >> 32)) - v0);
+    for (int j = tid; j < n_keep; j += 1024) part += expf(key_to_float((uint32_t)(sk[j] >> 32)) - v0f);
     const float S2 = block_sum<16>(part, red);
     const float logS = logf(S2);
     const float* q = a.noise + (int64_t)n_gen * a.noise_stride;
@@ -655,7 +745,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
     for (int j = tid; j < n_keep; j += 1024) {
         const float v = key_to_float((uint32_t)(sk[j] >> 32));
         const int id = (int)(sk[j] & 0xffffffffu);
-        const float pz = expf((v - v0) - logS);
+        const float pz = expf((v - v0f) - logS);
         const float sc = pz / q[id];
         if (sc > best || (sc == best && id < besti)) { best = sc; besti = id; }
     }
@@ -733,10 +823,11 @@ extern "C" int m5_ar_sample(const M5SampleArgs* a, void* stream) {
     if (!(a->temperature > 0.f)) return M5_ERR_ARG;
     int V2 = 1024;
     while (V2 < a->V) V2 <<= 1;
-    const size_t sm = (size_t)V2 * 12;
+    if (a->typical_p <= 0.999f && V2 > 4096) return M5_ERR_UNSUPPORTED;      // typical-p scratch: 20 B per slot
+    const size_t sm = (size_t)V2 * (a->typical_p <= 0.999f ? 20 : 12);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);
+        (void)hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);   // = 4096 * 24 >= 4096 * 20
         attr_set = true;
     }
     hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), sm, (hipStream_t)stream, *a, V2);

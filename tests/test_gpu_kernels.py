@@ -355,8 +355,6 @@ def test_ar_sampler_golden_cases(dev, gold_dir):
     n_checked = 0
     for i in range(fx["logits"].shape[0]):
         c = json.loads(str(fx["cfg"][i]))
-        if c["typical_p"] <= 0.999:
-            continue
         prev = [int(t) for t in fx["prev"][i]]
         n_est = int(fx["n_est"][i])
         P = 5
@@ -373,7 +371,8 @@ def test_ar_sampler_golden_cases(dev, gold_dir):
         a = L.SampleArgs(logits=logits.data_ptr(), V=V, state=state.data_ptr(), tokens=tokens.data_ptr(), max_len=10 ** 6,
                          alpha_frequency=c["af"], alpha_presence=c["ap"], penalty_window=c["win"], n_text=n_text, eos_idx=eos,
                          n_est=n_est, eos_table=tab.data_ptr(), temperature=c["temperature"], div_mode=0, top_k=c["topk"],
-                         top_p=c["top_p"], noise=noise.data_ptr(), noise_stride=V, embed=embed.data_ptr(), dim=D, xres=xres.data_ptr())
+                         top_p=c["top_p"], typical_p=c["typical_p"], noise=noise.data_ptr(), noise_stride=V, embed=embed.data_ptr(), dim=D,
+                         xres=xres.data_ptr())
         ops.ar_sample(a)
         torch.cuda.synchronize()
         st = state.cpu()
@@ -385,7 +384,7 @@ def test_ar_sampler_golden_cases(dev, gold_dir):
             assert int(st[L.ST_NGEN]) == len(prev) + 1 and int(tokens[P + len(prev)]) == tok
             assert torch.equal(xres.cpu(), embed[tok].cpu())
         n_checked += 1
-    assert n_checked >= 9
+    assert n_checked >= 12          # incl. the typical_p = 0.6 cases
 
 
 def test_ar_sampler_random_vs_oracle(dev):
@@ -397,14 +396,17 @@ def test_ar_sampler_random_vs_oracle(dev):
     for V, n_text in [(4096, 3071), (1376, 288), (3000, 500)]:
         eos = V - 1
         embed = torch.zeros(V, 64, device=dev)
-        for trial in range(6):
+        for trial in range(9):
             cfg = [dict(t=0.7, k=100, p=0.2), dict(t=1.0, k=0, p=1.0), dict(t=0.7, k=100, p=1.0), dict(t=0.9, k=5, p=0.5),
-                   dict(t=0.7, k=1, p=0.2), dict(t=1.3, k=4000, p=0.97)][trial]
+                   dict(t=0.7, k=1, p=0.2), dict(t=1.3, k=4000, p=0.97),
+                   # typical-p (samplers.py:96-122): alone, after top-k, after top-k + top-p
+                   dict(t=1.0, k=0, p=1.0, ty=0.6), dict(t=0.8, k=200, p=1.0, ty=0.3), dict(t=0.9, k=100, p=0.9, ty=0.9)][trial]
+            ty = cfg.get("ty", 1.0)
             logits = torch.randn(V, generator=g) * 2.5
-            n_prev = [0, 3, 90, 120, 2, 40][trial]
+            n_prev = [0, 3, 90, 120, 2, 40, 10, 0, 77][trial]
             prev = torch.randint(n_text - 1, V - 1, (n_prev,), generator=g).tolist()
             q = torch.empty(V).exponential_(1, generator=g)
-            p = O.ARSamplingParams(cfg["t"], cfg["k"], cfg["p"], 1.0, 3.0, 0.4, 100, 0.5, 1.0, 30)
+            p = O.ARSamplingParams(cfg["t"], cfg["k"], cfg["p"], ty, 3.0, 0.4, 100, 0.5, 1.0, 30)
             z = O.filter_logits(logits, prev, p, n_text, eos)
             tok = O.draw_token(z, q)
             P = 3
@@ -420,7 +422,7 @@ def test_ar_sampler_random_vs_oracle(dev):
             xres = torch.zeros(64, device=dev)
             a = L.SampleArgs(logits=ld.data_ptr(), V=V, state=state.data_ptr(), tokens=tokens.data_ptr(), max_len=10 ** 6,
                              alpha_frequency=3.0, alpha_presence=0.4, penalty_window=100, n_text=n_text, eos_idx=eos, n_est=30,
-                             eos_table=tab.data_ptr(), temperature=cfg["t"], div_mode=0, top_k=cfg["k"], top_p=cfg["p"],
+                             eos_table=tab.data_ptr(), temperature=cfg["t"], div_mode=0, top_k=cfg["k"], top_p=cfg["p"], typical_p=ty,
                              noise=noise.data_ptr(), noise_stride=V, embed=embed.data_ptr(), dim=64, xres=xres.data_ptr())
             ops.ar_sample(a)
             torch.cuda.synchronize()
