@@ -149,6 +149,7 @@ typedef struct {
     const float* rope; const int32_t* state;
     void* kcache; void* vcache; void* qbuf;                /* this layer's cache [h][W][64]  */
     int32_t w_alloc, window, dim;
+    unsigned long long* dbg;                               /* diagnostics: phase stamps of workgroup 0 (NULL = off) */
 } M5GemvArgs;
 int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void* stream);
 

@@ -62,7 +62,7 @@ class GemvArgs(C.Structure):
                 ("y_dt", vp), ("y_f32", vp), ("xres", vp),
                 ("rope", vp), ("state", vp),
                 ("kcache", vp), ("vcache", vp), ("qbuf", vp),
-                ("w_alloc", i32), ("window", i32), ("dim", i32)]
+                ("w_alloc", i32), ("window", i32), ("dim", i32), ("dbg", vp)]
 
 
 class AttnDecodeArgs(C.Structure):

@@ -14,6 +14,13 @@
 
 namespace {
 
+// diagnostics (tools/ar_phase_clock.py): when set, workgroup 0 of every decode launch stamps the 100 MHz
+// wall clock at its phases into dbg[slot * 8 + k]; slot advances on the host per launch
+__device__ unsigned long long* g_ar_dbg = nullptr;
+__device__ inline void ar_stamp(unsigned long long* d, int k) {
+    if (d && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) d[k] = wall_clock64();
+}
+
 // ----------------------------------------------------------------------------- GEMV
 template <typename T, int PRO, int EPI, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(M5GemvArgs a) {
@@ -188,6 +195,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
     __shared__ float wsm[24 * 8 + 24];           // PRO_ATTN: split weights [h][s], then l_tot[h]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long* dbg = a.dbg;
+    ar_stamp(dbg, 0);
     const int done = a.state ? a.state[M5_ST_DONE] : 0;     // consumed only before the epilogue's writes
 
     // ---- activation loads first (short queue in front of the weight stream)
@@ -243,6 +252,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
             wv[r][it] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wr + it * 1024));
     }
 
+    ar_stamp(dbg, 1);
     // ---- prologue under the stream: activation vector -> LDS (fp32 values already rounded to dtype)
     if constexpr (PRO == M5_PRO_RMS) {
         float ss = 0.f;
@@ -312,6 +322,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
         for (int e = 0; e < PER; ++e) xs[i0 + e] = round_dt<T>(o[e] / l);
     }
     __syncthreads();
+    ar_stamp(dbg, 2);
     if (row0 >= a.N || done) return;
 
     float acc[R];
@@ -332,6 +343,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
+    ar_stamp(dbg, 3);
 
     if constexpr (EPI == M5_GEPI_RESIDUAL) {
         if (lane < R && row0 + lane < a.N) {
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
     constexpr int LPP = 64 / EPL;          // lanes per position: 8 (16-bit) or 16 (f32)
     constexpr int PPW = 64 / LPP;          // positions per wave instruction
     __shared__ float sm[4][LPP][EPL + 2];
-    if (a.state[M5_ST_DONE]) return;
+    const int done = a.state[M5_ST_DONE];          // consumed before the only global write (a finished sequence just idles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, split = blockIdx.y;
     const int pos = a.state[M5_ST_POS];
@@ -448,32 +460,43 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.f;
 
-    for (int base = start + wave * PPW; base < end; base += 4 * PPW) {
-        const int p = base + grp;
-        const bool ok = p < end;
-        Vec16<T> kv, vv;
-        if (ok) {
-            kv.load(Kh + (int64_t)p * 64 + sub * EPL);
-            vv.load(Vh + (int64_t)p * 64 + sub * EPL);
-        } else {
-            kv.zero();
-            vv.zero();
+    // The key range of a workgroup is short (<= ~47 positions per wave at the 3000-slot window), and one
+    // launch lives for a few microseconds: issue the loads of UN wave-iterations before touching any of
+    // them, so the K / V round trips overlap instead of queueing behind each other's softmax updates.
+    constexpr int UN = 4;
+    for (int base0 = start + wave * PPW; base0 < end; base0 += UN * 4 * PPW) {
+        Vec16<T> kv[UN], vv[UN];
+        bool okv[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int p = base0 + u * 4 * PPW + grp;
+            okv[u] = p < end;
+            if (okv[u]) {
+                kv[u].load(Kh + (int64_t)p * 64 + sub * EPL);
+                vv[u].load(Vh + (int64_t)p * 64 + sub * EPL);
+            } else {
+                kv[u].zero();
+                vv[u].zero();
+            }
         }
-        float kf[EPL], vf[EPL];
-        kv.to_float(kf);
-        vv.to_float(vf);
-        float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) s = fmaf(qv[e], kf[e], s);
+        for (int u = 0; u < UN; ++u) {
+            float kf[EPL], vf[EPL];
+            kv[u].to_float(kf);
+            vv[u].to_float(vf);
+            float s = 0.f;
 #pragma unroll
-        for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off);
-        if (ok) {
-            const float mn = fmaxf(m, s);
-            const float al = expf(m - mn), pe = expf(s - mn);
-            l = l * al + pe;
+            for (int e = 0; e < EPL; ++e) s = fmaf(qv[e], kf[e], s);
 #pragma unroll
-            for (int e = 0; e < EPL; ++e) o[e] = o[e] * al + pe * vf[e];
-            m = mn;
+            for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off);
+            if (okv[u]) {
+                const float mn = fmaxf(m, s);
+                const float al = expf(m - mn), pe = expf(s - mn);
+                l = l * al + pe;
+#pragma unroll
+                for (int e = 0; e < EPL; ++e) o[e] = o[e] * al + pe * vf[e];
+                m = mn;
+            }
         }
     }
     // merge the PPW position groups of the wave
@@ -498,7 +521,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
         sm[wave][sub][EPL + 1] = l;
     }
     __syncthreads();
-    if (tid < LPP) {
+    if (tid < LPP && !done) {
         float mm = -INFINITY;
         for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm[w][tid][EPL]);
         float ll = 0.f, oo[EPL];
