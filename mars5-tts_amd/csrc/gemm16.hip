@@ -39,6 +39,7 @@ struct Gemm16Params {
     int M, N, K;
     int tilesM, tilesN, nblk, group_m;
     unsigned long long* dbg;         // diagnostics: workgroup 0 records {shader clock, 100 MHz wall clock} at entry / exit
+    int qkv_stage;                   // QKV scatter: alignment / shape allow the LDS-staged 16-byte-chunk epilogue
     int vec16;                       // 16-bit outputs: rows / batch stride / base / width allow 16-byte row chunks (LDS-staged epilogue)
     int vec_c;                       // C rows / batch stride / base allow 16-byte (fp32) or 8-byte (16-bit) vectors
     int vt_vec;                      // V^T scatter may store 4 consecutive s as one 8-byte vector
@@ -265,6 +266,83 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL);
     unsigned char* Cb = p.C + (int64_t)bz * p.sC * (F32OUT ? 4 : 2);
     const int mw = m0 + wm * TM * 16, nw = n0 + wn * TN * 16;
+
+    // ---- Q / K / V^T scatter, one head (64 columns) per wave: stage through LDS, store 16-byte chunks.
+    // Q, K: rows of 128 bytes ([s][64 d]) go out whole.  V^T: the unswapped accumulator layout gives each
+    // lane 4 consecutive s of one d; the tile is staged transposed ([d][s]) and leaves as 16-byte runs of s.
+    if constexpr (EPI == M5_EPI_QKV && TN == 4) {
+        constexpr int RBQ = 128 + 16;                         // Q/K stage row: 64 d
+        constexpr int RBV = TM * 32 + 16;                     // V^T stage row: TM*16 s
+        constexpr int WSZ = (TM * 16 * RBQ > 64 * RBV) ? TM * 16 * RBQ : 64 * RBV;
+        if constexpr (NW * WSZ <= NSTAGE * STAGE) {
+            if (p.qkv_stage) {
+                __syncthreads();
+                unsigned char* ws = lds + wave * WSZ;
+                const int ncol0 = n0 + wn * 64;                // this wave's first column: one (section, head)
+                if (ncol0 >= p.N) return;                      // (whole-head granularity: N is a multiple of 64)
+                const int kind = p.sec_kind[min(ncol0 / Dm, 2)];
+                const int hh = (ncol0 % Dm) >> 6;
+                const float* biasp = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
+                const int mrow0 = m0 + wm * TM * 16;
+                if (!vblock) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = ncol0 + j * 16 + lg * 4;
+                        float bv4[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bv4[r] = biasp ? biasp[min(col + r, p.N - 1)] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv4[r];
+                            *reinterpret_cast<uint2*>(ws + (i * 16 + l15) * RBQ + (j * 16 + lg * 4) * 2) = pack4<T>(v);
+                        }
+                    }
+                    st* base = (kind == 0) ? reinterpret_cast<st*>(p.sc.q) + hh * p.sc.q_hs : reinterpret_cast<st*>(p.sc.k) + hh * p.sc.k_hs;
+                    const int64_t bs = (kind == 0) ? p.sc.q_bs : p.sc.k_bs, rs = (kind == 0) ? p.sc.q_rs : p.sc.k_rs;
+                    const int rr = lane >> 3, ch = lane & 7;
+#pragma unroll
+                    for (int pass = 0; pass < TM * 2; ++pass) {
+                        const int r = pass * 8 + rr, row = mrow0 + r;
+                        if (row < p.M) {
+                            const int b = row / p.sc.rows_per_batch, sq = row - b * p.sc.rows_per_batch;
+                            const uint4 val = *reinterpret_cast<const uint4*>(ws + r * RBQ + ch * 16);
+                            *reinterpret_cast<uint4*>(base + b * bs + (int64_t)sq * rs + ch * 8) = val;
+                        }
+                    }
+                } else {
+                    // unswapped: acc[i][j][r] = C[mrow0 + 16 i + 4 lg + r][ncol0 + 16 j + l15]
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float bvv = biasp ? biasp[min(ncol0 + j * 16 + l15, p.N - 1)] : 0.f;
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) {
+                            float v[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bvv;
+                            *reinterpret_cast<uint2*>(ws + (j * 16 + l15) * RBV + (i * 16 + lg * 4) * 2) = pack4<T>(v);
+                        }
+                    }
+                    constexpr int CPRV = TM * 2, RPPV = 64 / CPRV;      // 16-byte chunks (8 s) per d-row, d-rows per pass
+                    const int rr = lane / CPRV, ch = lane - rr * CPRV;
+                    st* base = reinterpret_cast<st*>(p.sc.vt) + hh * p.sc.vt_hs;
+                    const int row = mrow0 + ch * 8;                      // 8 consecutive rows: same batch (rows_per_batch % 8 == 0)
+                    const int b = row / p.sc.rows_per_batch, sq = row - b * p.sc.rows_per_batch;
+#pragma unroll
+                    for (int pass = 0; pass < (64 + RPPV - 1) / RPPV; ++pass) {
+                        const int d = pass * RPPV + rr;
+                        if (rr < RPPV && d < 64 && row < p.M) {
+                            const uint4 val = *reinterpret_cast<const uint4*>(ws + d * RBV + ch * 16);
+                            *reinterpret_cast<uint4*>(base + b * p.sc.vt_bs + (int64_t)d * p.sc.vt_ds + sq) = val;
+                        }
+                    }
+                }
+                if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
+                return;
+            }
+        }
+    }
 
     if (EPI == M5_EPI_QKV && vblock) {
         // unswapped layout: acc[i][j][r] = C[mw + 16 i + 4 lg + r][nw + 16 j + l15]
@@ -502,7 +580,7 @@ struct CfgInfo { int bm, bn, tn, occ; float t_fix_us, t_iter_us; };   // t_iter:
 static const CfgInfo kCfg[] = {
     {128, 128, 4, 2, 8.f, 0.72f},     // 0: 128x128 tile, 4 waves, 2 stages, 2 WG/CU
     {192, 384, 6, 1, 8.f, 2.37f},     // 1: region 192x384, 8 waves (2x4 of 96x96), 2 stages
-    {192, 192, 4, 1, 8.f, 1.50f},     // 2: region 192x192, 6 waves (2x3 of 96x64), 3 stages
+    {192, 192, 4, 1, 7.f, 1.40f},     // 2: region 192x192, 6 waves (2x3 of 96x64), 3 stages
     { 96, 128, 4, 1, 8.f, 0.64f},     // 3: region  96x128, 4 waves (2x2 of 48x64), 4 stages
     { 96, 128, 2, 2, 8.f, 0.66f},     // 4: tile    96x128, 8 waves (2x4 of 48x32), 2 stages, 2 WG/CU
 };
@@ -523,7 +601,7 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s) {
 // Cheapest configuration under: time = rounds x (fixed + K-steps x per-step time), rounds =
 // ceil(workgroups / (256 CUs x workgroups per CU)).  `span_div`: for QKV scatters with a V section
 // the per-wave column span must divide the section width.
-int pick_config(int M, int N, int K, int batch, int span_div) {
+int pick_config(int M, int N, int K, int batch, int span_div, int epi) {
     int best = 0;
     float best_t = 1e30f;
     for (int c = 0; c < kNumCfg; ++c) {
@@ -533,7 +611,8 @@ int pick_config(int M, int N, int K, int batch, int span_div) {
         const int64_t slots = 256 * f.occ;
         const int64_t rounds = (wg + slots - 1) / slots;
         // a partially filled last round of an occ-2 configuration runs its workgroups alone on their CUs
-        const float t = (float)rounds * (f.t_fix_us + (float)(K / 64) * f.t_iter_us);
+        float t = (float)rounds * (f.t_fix_us + (float)(K / 64) * f.t_iter_us);
+        if (epi == M5_EPI_QKV && c == 3) t += 2.5f * (float)rounds;     // measured: its 4-wave scatter epilogue is the slowest
         if (t < best_t) { best_t = t; best = c; }
     }
     return best;
@@ -570,6 +649,14 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
         const bool one_batch = M <= sc->rows_per_batch;
         p.vt_vec = (sc->vt && (sc->vt_ds % 4 == 0) && (sc->vt_hs % 4 == 0) && (sc->vt_bs % 4 == 0) &&
                     (((uintptr_t)sc->vt & 7) == 0) && (one_batch || sc->rows_per_batch % 4 == 0)) ? 1 : 0;
+        {
+            auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+            const bool ok_q = !sc->q || (al16(sc->q) && sc->q_rs % 8 == 0 && sc->q_hs % 8 == 0 && sc->q_bs % 8 == 0 && sc->q_rs >= 64);
+            const bool ok_k = !sc->k || (al16(sc->k) && sc->k_rs % 8 == 0 && sc->k_hs % 8 == 0 && sc->k_bs % 8 == 0 && sc->k_rs >= 64);
+            const bool ok_v = !sc->vt || (al16(sc->vt) && sc->vt_ds % 8 == 0 && sc->vt_hs % 8 == 0 && sc->vt_bs % 8 == 0);
+            p.qkv_stage = (sc->head_dim == 64 && ok_q && ok_k && ok_v && (M % 8 == 0) &&
+                           (one_batch || sc->rows_per_batch % 8 == 0)) ? 1 : 0;
+        }
         // Q / K scatter stores 4 consecutive d as 8 bytes
         if (sc->head_dim % 4 || (sc->q && ((sc->q_rs % 4) || (sc->q_hs % 4) || (sc->q_bs % 4) || ((uintptr_t)sc->q & 7))) ||
             (sc->k && ((sc->k_rs % 4) || (sc->k_hs % 4) || (sc->k_bs % 4) || ((uintptr_t)sc->k & 7))))
@@ -580,7 +667,7 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     const char* fe = getenv("M5_GEMM_CFG");                  // tuning sweeps only; read per call on purpose
     const int forced = (fe && fe[0]) ? atoi(fe) : -1;
     const int span_div = (sc && sc->vt) ? sc->n_heads * sc->head_dim : 0;
-    int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div);
+    int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div, epi);
     if (cfg < 0 || cfg >= kNumCfg || (span_div && (span_div % (kCfg[cfg].tn * 16)))) cfg = 0;
     if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s);
     return launch_cfg<BF16T>(cfg, epi, p, batch, s);
