@@ -612,23 +612,93 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
         sk[i] = key;
     }
     __syncthreads();
-    // ---- bitonic sort ascending on (desc_key, index): value descending, index ascending
-    bitonic_sort_u64(sk, V2, tid);
-    // ---- 6. top-k: threshold = k-th largest, keep everything >= it (samplers.py:70-74)
-    if (tid == 0) {
-        int nk = V;
-        sh_i[0] = nk;
-    }
-    __syncthreads();
-    if (a.top_k > 0) {
-        const int k = min(max(a.top_k, 1), V);
-        const uint32_t thr = (uint32_t)(sk[k - 1] >> 32);
-        for (int j = tid; j < V; j += 1024) {
-            const uint32_t hj = (uint32_t)(sk[j] >> 32);
-            const uint32_t hn = (j + 1 < V2) ? (uint32_t)(sk[j + 1] >> 32) : 0xffffffffu;
-            if (hj == thr && hn != thr) sh_i[0] = j + 1;     // last entry equal to the threshold
+    // ---- 6. top-k: threshold = k-th largest, keep everything >= it (samplers.py:70-74).
+    // Fast path (small k): a 4-pass radix select finds the threshold key, the survivors are compacted and
+    // rank-sorted into sk[0..n) - the same (value desc, index asc) order the full sort produces, so everything
+    // downstream (top-p cumulative sums included) sees identical data. Falls back to the full bitonic sort when
+    // top-k is off or the tie set at the threshold is large.
+    __shared__ int hist[256];
+    __shared__ uint32_t sel[2];
+    bool selected = false;
+    const int cap = min(V2 >> 1, 1024);                                   // tmp lives in the fs scratch (V2 * 4 B)
+    if (a.top_k > 0 && min(max(a.top_k, 1), V) <= 256) {
+        uint32_t prefix = 0;
+        int rank = min(max(a.top_k, 1), V) - 1;
+        for (int pass = 3; pass >= 0; --pass) {
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const int shv = pass * 8;
+            for (int i = tid; i < V; i += 1024) {
+                const uint32_t hi = (uint32_t)(sk[i] >> 32);
+                const bool match = (pass == 3) || ((hi >> (shv + 8)) == prefix);
+                if (match) atomicAdd(&hist[(hi >> shv) & 255u], 1);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                int hs[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) hs[q] = hist[4 * tid + q];
+                const int s4 = hs[0] + hs[1] + hs[2] + hs[3];
+                int inc = s4;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int n = __shfl_up(inc, off);
+                    if (tid >= off) inc += n;
+                }
+                int base = inc - s4;                                      // entries in bins below 4*tid
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (rank >= base && rank < base + hs[q]) {
+                        sel[0] = (prefix << 8) | (uint32_t)(4 * tid + q);
+                        sel[1] = (uint32_t)(rank - base);
+                    }
+                    base += hs[q];
+                }
+            }
+            __syncthreads();
+            prefix = sel[0];
+            rank = (int)sel[1];
+        }
+        const uint32_t thr = prefix;                                      // key of the k-th largest value
+        unsigned long long* tmp = reinterpret_cast<unsigned long long*>(fs);
+        if (tid == 0) sh_i[2] = 0;
+        __syncthreads();
+        for (int i = tid; i < V; i += 1024) {
+            const unsigned long long key = sk[i];
+            if ((uint32_t)(key >> 32) <= thr) {
+                const int slot = atomicAdd(&sh_i[2], 1);
+                if (slot < cap) tmp[slot] = key;
+            }
         }
         __syncthreads();
+        const int nk = sh_i[2];
+        if (nk <= cap) {                                                  // block-uniform
+            for (int j = tid; j < nk; j += 1024) {
+                const unsigned long long my = tmp[j];
+                int r = 0;
+                for (int i = 0; i < nk; ++i) r += (tmp[i] < my) ? 1 : 0;  // keys are unique -> a permutation
+                sk[r] = my;
+            }
+            if (tid == 0) sh_i[0] = nk;
+            selected = true;
+            __syncthreads();
+        }
+    }
+    if (!selected) {
+        // ---- bitonic sort ascending on (desc_key, index): value descending, index ascending
+        bitonic_sort_u64(sk, V2, tid);
+        if (tid == 0) sh_i[0] = V;
+        __syncthreads();
+        if (a.top_k > 0) {
+            const int k = min(max(a.top_k, 1), V);
+            const uint32_t thr = (uint32_t)(sk[k - 1] >> 32);
+            for (int j = tid; j < V; j += 1024) {
+                const uint32_t hj = (uint32_t)(sk[j] >> 32);
+                const uint32_t hn = (j + 1 < V2) ? (uint32_t)(sk[j + 1] >> 32) : 0xffffffffu;
+                if (hj == thr && hn != thr) sh_i[0] = j + 1;     // last entry equal to the threshold
+            }
+            __syncthreads();
+        }
     }
     int n_keep = sh_i[0];
     const float v0 = key_to_float((uint32_t)(sk[0] >> 32));

@@ -40,14 +40,16 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
         } else {
             const float* u2 = a.u2 + (int64_t)row * K;
             const float c4 = cst[4], c5 = cst[5];
+            // log_add_exp(one_hot_log + c4, c5) takes only two values per row: evaluate each once
+            // (same arithmetic per element as the reference, just not 1025 times)
+            const float q_hit = lae(0.f + c4, c5), q_miss = lae(a.log_eps + c4, c5);
             float best = -INFINITY;
             int bi = 0x7fffffff;
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int k = lane + 64 * i;
                 if (k < K) {
-                    const float lk = (k == (int)xk) ? 0.f : a.log_eps;
-                    const float v = gumbel(u2[k]) + lae(lk + c4, c5);
+                    const float v = gumbel(u2[k]) + ((k == (int)xk) ? q_hit : q_miss);
                     if (v > best) { best = v; bi = k; }
                 }
             }
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
             if (lane + 64 * i < K) se += expf(z[i] - mx);
         const float lse0 = logf(wave_sum(se));
         const float c0 = cst[0], c1 = cst[1], c2 = cst[2], c3 = cst[3];
+        const float p_hit = lae(0.f + c2, c3), p_miss = lae(a.log_eps + c2, c3);   // two values per row, as above
         float mu = -INFINITY;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
@@ -100,8 +103,7 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
             if (k < K) {
                 const float l0 = (z[i] - mx) - lse0;               // log_softmax (:367)
                 const float ev = (t == 0) ? l0 : lae(l0 + c0, c1); // q_pred(t-1) / where(t==0) (:187-193)
-                const float lx = (k == xt) ? 0.f : a.log_eps;       // index_to_log_onehot (:368)
-                const float un = ev + lae(lx + c2, c3);             // + q_pred_one_timestep (:199)
+                const float un = ev + ((k == xt) ? p_hit : p_miss); // + q_pred_one_timestep(index_to_log_onehot(x_t)) (:368, :199)
                 z[i] = un;
                 mu = fmaxf(mu, un);
             }

@@ -429,6 +429,41 @@ def test_ar_sampler_random_vs_oracle(dev):
             assert int(state[L.ST_LAST]) == tok, f"V={V} trial {trial}: {int(state[L.ST_LAST])} != {tok}"
 
 
+def test_ar_sampler_topk_ties_and_masked_threshold(dev):
+    """top-k radix-select path: ties at the threshold (all kept, torch `logits < kth` semantics), tie sets
+    larger than the select buffer, and a threshold that falls into the masked (-inf) region."""
+    import mars5_oracle as O
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.tables import eos_penalty_table
+    g = torch.Generator().manual_seed(17)
+    cases = [  # (V, n_text, quantum, top_k, top_p)
+        (4096, 3071, 0.5, 100, 1.0), (4096, 3071, 0.5, 100, 0.6), (4096, 3071, 2.0, 50, 1.0), (4096, 300, 4.0, 20, 0.9),
+        (4096, 4000, 0.0, 200, 1.0), (1376, 1300, 0.25, 100, 0.8), (3000, 500, 1.0, 256, 1.0), (3000, 500, 8.0, 3, 1.0)]
+    for ci, (V, n_text, quantum, k, top_p) in enumerate(cases):
+        eos = V - 1
+        embed = torch.zeros(V, 64, device=dev)
+        logits = torch.randn(V, generator=g) * 2.5
+        if quantum > 0:
+            logits = torch.round(logits / quantum) * quantum
+        q = torch.empty(V).exponential_(1, generator=g)
+        p = O.ARSamplingParams(1.0, k, top_p, 1.0, 0.0, 0.0, 100, 0.5, 1.0, 30)
+        z = O.filter_logits(logits, [], p, n_text, eos)
+        tok = O.draw_token(z, q)
+        tokens = torch.zeros(8, dtype=torch.int64, device=dev)
+        state = torch.tensor([3, 0, 0, 3, -1, 0, 0, 0], dtype=torch.int32, device=dev)
+        noise = q.reshape(1, V).to(dev)
+        tab = eos_penalty_table(30, 0.5, 1.0).to(dev)
+        ld = logits.to(dev)
+        xres = torch.zeros(64, device=dev)
+        a = L.SampleArgs(logits=ld.data_ptr(), V=V, state=state.data_ptr(), tokens=tokens.data_ptr(), max_len=10 ** 6,
+                         alpha_frequency=0.0, alpha_presence=0.0, penalty_window=100, n_text=n_text, eos_idx=eos, n_est=30,
+                         eos_table=tab.data_ptr(), temperature=1.0, div_mode=0, top_k=k, top_p=top_p, typical_p=1.0,
+                         noise=noise.data_ptr(), noise_stride=V, embed=embed.data_ptr(), dim=64, xres=xres.data_ptr())
+        ops.ar_sample(a)
+        torch.cuda.synchronize()
+        assert int(state[L.ST_LAST]) == tok, f"case {ci}: {int(state[L.ST_LAST])} != {tok}"
+
+
 def test_nar_sample_vs_oracle(dev):
     """Fused posterior/sample kernel vs the oracle's reverse_step on identical logits and
     uniforms: integer outputs, exact up to libm-ulp near-ties (bound: <= 2 of ~5k rows)."""
