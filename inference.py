@@ -11,14 +11,14 @@ import io
 import logging
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Dict, Optional, Tuple, Type, Union
+from typing import Dict, List, Optional, Tuple, Type, Union
 
 import torch
 import torch.nn.functional as F
 from torch import Tensor
 
 from mars5_tts_amd.ar_generate import ar_generate
-from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_simple_inference
+from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_batch_inference, perform_simple_inference
 from mars5_tts_amd.minbpe import GPT4_SPLIT_PATTERN, CodebookTokenizer, RegexTokenizer
 from mars5_tts_amd.model import CodecLM, ResidualTransformer
 from mars5_tts_amd.trim import trim
@@ -124,11 +124,10 @@ class Mars5TTS:
         return self.codeclm.get_spk_embedding(spk_reference)
 
     # ------------------------------------------------------------------ the hot path
-    @torch.inference_mode()
-    def tts_from_codes(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str],
-                       cfg: InferenceConfig = InferenceConfig(), ar_noise: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-        """``tts`` between the codec and the vocoder (reference inference.py:222-301):
-        prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out."""
+    def _ar_stage(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str], cfg: InferenceConfig,
+                  ar_noise: Optional[Tensor] = None, generator: Optional[torch.Generator] = None):
+        """Prompt construction + AR decode + BPE expansion (reference inference.py:222-285).
+        Returns (L0 frames (G,), the ``perform_simple_inference`` batch tuple, frames to skip in front)."""
         text_tokens = self.texttok.encode("<|startoftext|>" + text.strip() + "<|endoftext|>", allowed_special='all')
         text_tokens_full = self.texttok.encode("<|startoftext|>" + ref_transcript + ' ' + str(text).strip() + "<|endoftext|>",
                                                allowed_special='all')
@@ -156,7 +155,7 @@ class Mars5TTS:
                                penalty_window=cfg.rep_penalty_window, eos_penalty_decay=cfg.eos_penalty_decay,
                                eos_penalty_factor=cfg.eos_penalty_factor, beam_width=cfg.beam_width, beam_length_penalty=1,
                                n_phones_gen=round(cfg.eos_estimated_gen_length_factor * len(text)), vocode=False,
-                               use_kv_cache=cfg.use_kv_cache, noise=ar_noise)
+                               use_kv_cache=cfg.use_kv_cache, noise=ar_noise, generator=generator)
 
         # AR -> NAR hand-off: token ids -> L0 frames through the BPE expansion table
         # (same result as speechtok.decode_int on the id list, inference.py:272-275)
@@ -170,17 +169,57 @@ class Mars5TTS:
         c_codes_lengths = torch.tensor([c_codes.shape[1]], dtype=torch.long, device=self.device)
         _x = gen_codes_decoded[None, :, None].repeat(1, 1, 8)
         x_padding_mask = torch.zeros((1, _x.shape[1]), dtype=torch.bool, device=_x.device)
+        skip_front = raw_prompt_acoustic_len if cfg.deep_clone else 0
+        return gen_codes_decoded, (c_text, c_codes, c_texts_lengths, c_codes_lengths, _x, x_padding_mask), skip_front
 
+    def _dsh(self, cfg: InferenceConfig) -> DSH:
+        return DSH(last_greedy=True, x_0_temp=cfg.x_0_temp, guidance_w=cfg.nar_guidance_w, deep_clone=cfg.deep_clone,
+                   jump_len=1, jump_n_sample=1, q0_override_steps=cfg.q0_override_steps,
+                   enable_kevin_scaled_inference=True, progress=False)
+
+    @torch.inference_mode()
+    def tts_from_codes(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str],
+                       cfg: InferenceConfig = InferenceConfig(), ar_noise: Optional[Tensor] = None,
+                       generator: Optional[torch.Generator] = None) -> Tuple[Tensor, Tensor]:
+        """``tts`` between the codec and the vocoder (reference inference.py:222-301):
+        prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out."""
+        gen_codes_decoded, batch, skip_front = self._ar_stage(text, prompt_codec, ref_transcript, cfg, ar_noise, generator)
         T = self.default_T
         diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
-        dsh_cfg = DSH(last_greedy=True, x_0_temp=cfg.x_0_temp, guidance_w=cfg.nar_guidance_w, deep_clone=cfg.deep_clone,
-                      jump_len=1, jump_n_sample=1, q0_override_steps=cfg.q0_override_steps,
-                      enable_kevin_scaled_inference=True, progress=False)
-        final_output = perform_simple_inference(self.codecnar, (c_text, c_codes, c_texts_lengths, c_codes_lengths, _x, x_padding_mask),
-                                                diff, diff.num_timesteps, torch.float16, dsh=dsh_cfg, retain_quant0=True)
-        skip_front = raw_prompt_acoustic_len if cfg.deep_clone else 0
+        final_output = perform_simple_inference(self.codecnar, batch, diff, diff.num_timesteps, torch.float16, dsh=self._dsh(cfg),
+                                                retain_quant0=True, generator=generator)
         final_output = final_output[0, skip_front:].to(self.device)
         return gen_codes_decoded, final_output
+
+    @torch.inference_mode()
+    def tts_batch_from_codes(self, texts: List[str], prompt_codecs: List[Tensor], ref_transcripts: List[Optional[str]],
+                             cfg: InferenceConfig = InferenceConfig(), seeds: Optional[List[int]] = None,
+                             nar_batch: int = 8) -> List[Tuple[Tensor, Tensor]]:
+        """Several independent requests on one GPU (BASELINE config 3).  Request i gets a private
+        device generator seeded ``seeds[i]``, so its result equals ``torch.manual_seed(seeds[i]);
+        tts_from_codes(...)`` whatever else is in the batch.  The AR stage runs request by request
+        (its decode step is a batch-1 weight stream); the NAR stage refines up to `nar_batch` requests
+        of similar length per decoder pass (``perform_batch_inference``)."""
+        n = len(texts)
+        assert len(prompt_codecs) == n and len(ref_transcripts) == n
+        gens = []
+        for i in range(n):
+            g = torch.Generator(device=self.device)
+            g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.seed()))
+            gens.append(g)
+        staged = [self._ar_stage(texts[i], prompt_codecs[i], ref_transcripts[i], cfg, None, gens[i]) for i in range(n)]
+        T = self.default_T
+        diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
+        # group requests of similar total NAR length: the batch is padded to its longest member
+        order = sorted(range(n), key=lambda i: staged[i][1][4].shape[1] + staged[i][2])
+        finals: List[Optional[Tensor]] = [None] * n
+        for g0 in range(0, n, max(1, nar_batch)):
+            grp = order[g0:g0 + max(1, nar_batch)]
+            outs = perform_batch_inference(self.codecnar, [staged[i][1] for i in grp], diff, diff.num_timesteps, dsh=self._dsh(cfg),
+                                           generators=[gens[i] for i in grp])
+            for i, o in zip(grp, outs):
+                finals[i] = o[0, staged[i][2]:].to(self.device)
+        return [(staged[i][0], finals[i]) for i in range(n)]
 
     @torch.inference_mode()
     def tts(self, text: str, ref_audio: Tensor, ref_transcript: Optional[str] = None,

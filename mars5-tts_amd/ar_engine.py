@@ -244,7 +244,9 @@ class ARSession:
                 break
         ev1.record(st)
         self.stream.synchronize()
-        n_tok = int(self.state[L.ST_NTOK].item())
+        final = self.state.cpu()
+        n_tok = int(final[L.ST_NTOK])
+        self.ended_on_eos = bool(int(final[L.ST_DONE])) and int(final[L.ST_LAST]) == int(self._sample_args.eos_idx)
         LAST_STATS.update(decode_ms=ev0.elapsed_ms(ev1), decode_steps_launched=done, n_generated=n_tok - self.P,
                           prefill_len=self.P + 1, final_len=n_tok)
         return self.tokens[:n_tok].clone()

@@ -17,7 +17,8 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
                 top_p=1.0, alpha_frequency=0, alpha_presence=0, penalty_window=100,
                 typical_p=1.0, eos_penalty_factor=1.0, eos_penalty_decay=0, n_phones_gen=None, vocode=True,
                 beam_width: int = 1, beam_length_penalty=2, use_kv_cache: bool = True,
-                noise: Optional[Tensor] = None, use_graph: bool = True, div_mode: int = 0) -> Tensor:
+                noise: Optional[Tensor] = None, use_graph: bool = True, div_mode: int = 0,
+                generator: Optional[torch.Generator] = None) -> Tensor:
     """Autoregressively complete `xx` (seq_len,) with the `codeclm` language model; `ss_gen`
     (ref_len, 8) is the speaker reference.  Returns the full sequence (prompt + generated),
     EOS not appended.  `fp16`, `beam_length_penalty` and `use_kv_cache` are accepted for
@@ -25,7 +26,8 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
     cache is always on -- "disabling/enabling kv caching won't affect output", inference.py:66).
 
     Extensions (keyword-only in spirit): `noise` (n_steps, V) Exp(1) draws to use instead of
-    the device generator (parity tests), `use_graph`, `div_mode`.
+    the device generator (parity tests), `use_graph`, `div_mode`, `generator` (a private device
+    generator instead of the global one: per-utterance RNG streams for batched serving).
     """
     assert xx.dim() == 1, "Only batch size of 1 is currently supported."
     assert beam_width == 1, "Only beam size of 1 is currently supported."
@@ -45,13 +47,19 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
 
     sess = ARSession(eng, max_len)
     n_steps = max_len - P
+    gen = None
     with torch.cuda.stream(sess.stream):
         if noise is None:
-            # one Exp(1) vector per sampler call, drawn call-by-call like torch.multinomial does
-            # (ar_generate.py:115), so a seeded run consumes the device generator the same way.
+            # One Exp(1) vector per sampler call, drawn call-by-call like torch.multinomial does
+            # (ar_generate.py:115).  All max_len - P rows are drawn up front so the decode loop never
+            # touches the host; the generator is then rewound to where the reference leaves it (one
+            # draw per executed loop iteration), so what follows (the NAR stage) sees the same stream.
+            gen = generator if generator is not None else torch.cuda.default_generators[dev.index]
+            off0 = gen.get_offset()
             noise_d = torch.empty(n_steps, n_vocab, dtype=torch.float32, device=dev)
             for i in range(n_steps):
-                noise_d[i].exponential_(1)
+                noise_d[i].exponential_(1, generator=generator)
+            per_draw = (gen.get_offset() - off0) // n_steps
         else:
             noise_d = noise.to(device=dev, dtype=torch.float32).contiguous()
     cfg = ARSamplingConfig(temperature=float(temperature), topk=topk, top_p=float(top_p), alpha_frequency=float(alpha_frequency),
@@ -61,6 +69,9 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
     sess.configure_sampler(cfg, n_text, eos_idx, noise_d)
     sess.prefill(xx, ss_gen)
     out = sess.decode(use_graph=use_graph)
+    if gen is not None:
+        n_iter = (int(out.shape[-1]) - P) + (1 if sess.ended_on_eos else 0)      # loop iterations the reference executes
+        gen.set_offset(off0 + n_iter * per_draw)
     if out.shape[-1] >= max_len - 1:
         logging.warning(f"[autoregressive generation] output length = {out.shape[-1]} -- inference likely failed or input too long!")
     return out

@@ -140,24 +140,35 @@ class CrossMemory:
     Bm: int          # memory batch entries per step (2 = cond, uncond)
 
 
-def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mem: CrossMemory, step_ptr: torch.Tensor, stream=None) -> None:
-    """x = x + out_proj(SDPA(q_proj(LN2(x)), memory K/V of step *step_ptr))."""
+def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None) -> None:
+    """x = x + out_proj(SDPA(q_proj(LN2(x)), memory K/V of step *step_ptr)).
+    `mems`: one CrossMemory covering all ws.B sequences, or a list of them (one per utterance, each
+    covering its Bm consecutive sequences of the workspace; memories of different utterances have
+    different lengths, so the attention is launched per utterance while the projections stay batched)."""
     H, S, Sr, D = ws.H, ws.S, ws.Sr, ws.D
     ops.layernorm(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, stream=stream)
     ops.gemm(ws.xn, lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=ws.scatter(True, False, False), stream=stream)
-    a = L.AttnArgs(q=ws.q.data_ptr(), q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64,
-                   k=mem.k.data_ptr(), k_bs=H * mem.Le * 64, k_hs=mem.Le * 64, k_rs=64,
-                   vt=mem.vt.data_ptr(), vt_bs=H * 64 * mem.Lep, vt_hs=64 * mem.Lep, vt_ds=mem.Lep,
-                   o=ws.att.data_ptr(), o_bs=Sr * D, o_rs=D, B=ws.B, H=H, Sq=S, Sk=mem.Le, key_len=None, causal=0,
-                   scale=64 ** -0.5, kv_index=step_ptr.data_ptr(),
-                   kv_index_stride_k=mem.Bm * H * mem.Le * 64, kv_index_stride_v=mem.Bm * H * 64 * mem.Lep)
-    ops.attention(ws.dt, a, stream=stream)
+    if isinstance(mems, CrossMemory):
+        mems = [mems]
+    b0 = 0
+    esz = ws.q.element_size()
+    for mem in mems:
+        a = L.AttnArgs(q=ws.q.data_ptr() + b0 * H * Sr * 64 * esz, q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64,
+                       k=mem.k.data_ptr(), k_bs=H * mem.Le * 64, k_hs=mem.Le * 64, k_rs=64,
+                       vt=mem.vt.data_ptr(), vt_bs=H * 64 * mem.Lep, vt_hs=64 * mem.Lep, vt_ds=mem.Lep,
+                       o=ws.att.data_ptr() + b0 * Sr * D * esz, o_bs=Sr * D, o_rs=D, B=mem.Bm, H=H, Sq=S, Sk=mem.Le, key_len=None,
+                       causal=0, scale=64 ** -0.5, kv_index=step_ptr.data_ptr(),
+                       kv_index_stride_k=mem.Bm * H * mem.Le * 64, kv_index_stride_v=mem.Bm * H * 64 * mem.Lep)
+        ops.attention(ws.dt, a, stream=stream)
+        b0 += mem.Bm
+    assert b0 == ws.B
     ops.gemm(ws.att, lw.ca_out_w, x, L.EPI_RESIDUAL, bias=lw.ca_out_b, stream=stream)
 
 
-def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mem: CrossMemory, step_ptr: torch.Tensor, stream=None) -> None:
-    self_attn_block(x, lw, ws, None, stream)
-    cross_attn_block(x, lw, ws, mem, step_ptr, stream)
+def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
+                  key_len: Optional[torch.Tensor] = None) -> None:
+    self_attn_block(x, lw, ws, key_len, stream)
+    cross_attn_block(x, lw, ws, mems, step_ptr, stream)
     ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream)
 
 

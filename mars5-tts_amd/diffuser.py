@@ -6,12 +6,12 @@ forward-jump branch (dead at the shipped jump_len = jump_n_sample = 1) are out o
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, Optional, Union
+from typing import Callable, List, Optional, Union
 
 import torch
 from torch import Tensor
 
-from .nar_engine import NARConfig, NARSession
+from .nar_engine import NARBatchSession, NARConfig, NARSession
 from .tables import diffusion_log_tables
 
 
@@ -60,51 +60,102 @@ def get_schedule(t_T, jump_len=10, jump_n_sample=10):
     return ts
 
 
+def _inpaint_state(batch: tuple, K: int, dsh, dev, randint: Optional[Callable], generator: Optional[torch.Generator]):
+    """The state ``perform_simple_inference`` builds before its loop (diffuser.py:405-436): random
+    codes with codebook 0 pinned to the AR output, the known-value / mask tensors, and in deep-clone
+    mode the reference codes prepended as fully known frames.  Returns (xr, x_known, m, offset)."""
+    c_text, c_codes, c_text_lengths, c_codes_lengths, x, x_padding_mask = batch
+    assert c_text.shape[0] == 1, "batch size 1 per call (the reference breaks for bs > 1, SURVEY App. B-9)"
+    x = x.to(dev)
+    c_codes = c_codes.to(dev)
+    assert int(x.max()) < K, f'Error: {int(x.max())} >= {K}'           # diffuser.py:36
+    x_quant0 = x[0, :, 0].clone()
+    if randint is None:
+        xr = torch.randint(0, K, x.shape, dtype=x.dtype, device=dev, generator=generator)[0]
+    else:
+        xr = randint(tuple(x.shape)).to(dev)[0]
+    xr[:, 0] = x_quant0
+    x_known = torch.zeros_like(xr)
+    x_known[:, 0] = xr[:, 0]
+    m = torch.zeros_like(xr, dtype=torch.uint8)
+    m[:, 0] = 1
+    offset = 0
+    if dsh.deep_clone:
+        prompt = c_codes[0]
+        xr = torch.cat((prompt, xr), dim=0)
+        x_known = torch.cat((prompt, x_known), dim=0)
+        m = torch.cat((torch.ones_like(prompt, dtype=torch.uint8), m), dim=0)
+        offset = int(c_codes_lengths[0])
+    return xr, x_known, m, offset
+
+
+def _nar_config(T, dsh, div_mode: int) -> NARConfig:
+    if dsh.jump_len != 1 or dsh.jump_n_sample != 1:
+        raise NotImplementedError("RePaint resampling (jump_len/jump_n_sample != 1) is outside the shipped inference path")
+    return NARConfig(T=T, x_0_temp=float(dsh.x_0_temp), guidance_w=float(dsh.guidance_w), deep_clone=bool(dsh.deep_clone),
+                     q0_override_steps=int(dsh.q0_override_steps), div_mode=div_mode)
+
+
 @torch.inference_mode()
 def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T, dtype=torch.float16,
                              retain_quant0: bool = True, dsh=DSH,
                              uniform: Optional[Callable[[tuple], Tensor]] = None, randint: Optional[Callable] = None,
-                             use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None) -> Tensor:
+                             use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None,
+                             generator: Optional[torch.Generator] = None) -> Tensor:
     """batch = (c_text (1,Lt), c_codes (1,Lc,8), c_text_lengths, c_codes_lengths, x (1,Lx,8),
     x_padding_mask); returns (1, S - offset, 8) int64.  RNG draws follow the reference order:
     randint(0,K,(1,Lx,8)) then per step rand (1,S,8,K) x2 (x1 at t = 0).
-    `uniform(shape)` / `randint(shape)` override the device generator (parity tests)."""
-    c_text, c_codes, c_text_lengths, c_codes_lengths, x, x_padding_mask = batch
-    assert c_text.shape[0] == 1, "batch size 1 per call (the reference breaks for bs > 1, SURVEY App. B-9)"
+    `uniform(shape)` / `randint(shape)` override the device generator (parity tests);
+    `generator` draws from a private device generator instead of the global one."""
+    c_text, c_codes = batch[0], batch[1]
     assert retain_quant0, "retain_quant0=False is not a shipped configuration (inference.py:298)"
-    if dsh.jump_len != 1 or dsh.jump_n_sample != 1:
-        raise NotImplementedError("RePaint resampling (jump_len/jump_n_sample != 1) is outside the shipped inference path")
+    cfg = _nar_config(T, dsh, div_mode)
     eng = model.engine()
     dev = eng.dev
     K = diff.num_classes
     assert K == eng.shape.n_quant
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
-    cfg = NARConfig(T=T, x_0_temp=float(dsh.x_0_temp), guidance_w=float(dsh.guidance_w), deep_clone=bool(dsh.deep_clone),
-                    q0_override_steps=int(dsh.q0_override_steps), div_mode=div_mode)
     sess = NARSession(eng, cfg)
     with torch.cuda.stream(sess.stream):
-        x = x.to(dev)
-        c_codes = c_codes.to(dev)
-        assert int(x.max()) < K, f'Error: {int(x.max())} >= {K}'           # diffuser.py:36
-        x_quant0 = x[0, :, 0].clone()
-        if randint is None:
-            xr = torch.randint(0, K, x.shape, dtype=x.dtype, device=dev)[0]
-        else:
-            xr = randint(tuple(x.shape)).to(dev)[0]
-        xr[:, 0] = x_quant0
-        x_known = torch.zeros_like(xr)
-        x_known[:, 0] = xr[:, 0]
-        m = torch.zeros_like(xr, dtype=torch.uint8)
-        m[:, 0] = 1
-        offset = 0
-        if dsh.deep_clone:
-            prompt = c_codes[0]
-            xr = torch.cat((prompt, xr), dim=0)
-            x_known = torch.cat((prompt, x_known), dim=0)
-            m = torch.cat((torch.ones_like(prompt, dtype=torch.uint8), m), dim=0)
-            offset = int(c_codes_lengths[0])
+        xr, x_known, m, offset = _inpaint_state(batch, K, dsh, dev, randint, generator)
         if uniform is None:
-            uniform = lambda shape: torch.rand(shape, dtype=torch.float32, device=dev)   # noqa: E731
-    sess.prepare(c_text[0], c_codes[0], xr, x_known, m, offset, times)
+            uniform = lambda shape: torch.rand(shape, dtype=torch.float32, device=dev, generator=generator)   # noqa: E731
+    sess.prepare(c_text[0], c_codes[0].to(dev), xr, x_known, m, offset, times)
     out = sess.run(uniform, use_graph=use_graph, n_steps=n_steps)
     return out[None, offset:].clone()
+
+
+@torch.inference_mode()
+def perform_batch_inference(model, batches: List[tuple], diff: MultinomialDiffusion, T, dsh=DSH,
+                            generators: Optional[List[Optional[torch.Generator]]] = None,
+                            uniforms: Optional[List[Callable[[tuple], Tensor]]] = None,
+                            randints: Optional[List[Callable]] = None,
+                            use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None) -> List[Tensor]:
+    """``perform_simple_inference`` for several independent utterances at once (BASELINE config 3):
+    one batched decoder pass per reverse step over all of them (``NARBatchSession``).  Utterance i
+    draws its random numbers from ``generators[i]`` in the order a lone call would (randint, then
+    per step two rand), so result i equals ``perform_simple_inference(batches[i], generator=generators[i])``
+    whatever else is in the batch.  Returns a list of (1, S_i - offset_i, 8) int64 tensors."""
+    cfg = _nar_config(T, dsh, div_mode)
+    eng = model.engine()
+    dev = eng.dev
+    K = diff.num_classes
+    assert K == eng.shape.n_quant
+    U = len(batches)
+    generators = generators if generators is not None else [None] * U
+    times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
+    sess = NARBatchSession(eng, cfg)
+    items, offsets, us = [], [], []
+    with torch.cuda.stream(sess.stream):
+        for i, batch in enumerate(batches):
+            g = generators[i]
+            xr, x_known, m, offset = _inpaint_state(batch, K, dsh, dev, randints[i] if randints else None, g)
+            items.append(dict(c_text=batch[0][0], c_codes=batch[1][0].to(dev), x=xr, x_known=x_known, m_mask=m, row_offset=offset))
+            offsets.append(offset)
+            if uniforms is not None:
+                us.append(uniforms[i])
+            else:
+                us.append(lambda shape, g=g: torch.rand(shape, dtype=torch.float32, device=dev, generator=g))
+    sess.prepare(items, times)
+    outs = sess.run(us, use_graph=use_graph, n_steps=n_steps)
+    return [o[None, off:].clone() for o, off in zip(outs, offsets)]

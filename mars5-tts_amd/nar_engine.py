@@ -106,6 +106,26 @@ class NARSession:
         """c_text (Lt,), c_codes (Lc, 8): conditioning.  x / x_known (S, 8) int64, m_mask (S, 8)
         uint8: the inpainting state built by ``perform_simple_inference`` (diffuser.py:405-436).
         row_offset: prompt frames prepended in deep-clone mode (never sampled from the model)."""
+        self.prepare_state(x, x_known, m_mask, row_offset)
+        self.prepare_cond(c_text, c_codes, times)
+        self.prepare_loop()
+
+    def prepare_state(self, x: torch.Tensor, x_known: torch.Tensor, m_mask: torch.Tensor, row_offset: int) -> None:
+        """The inpainting state of one utterance (depends on the AR output)."""
+        dev = self.m.dev
+        with torch.cuda.stream(self.stream):
+            self.x = x.to(dev).contiguous().clone()
+            self.x_known = x_known.to(dev).contiguous()
+            self.m_mask = m_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        self.S, self.row_offset = int(self.x.shape[0]), int(row_offset)
+        self.s_out = self.S - self.row_offset
+        assert self.S <= self.m.pe.shape[0]
+
+    def prepare_cond(self, c_text: torch.Tensor, c_codes: torch.Tensor, times: Optional[List[int]] = None) -> None:
+        """Everything that depends only on the conditioning (text ids, reference codes) and the
+        schedule - independent of the AR output, so a server can run it beside the AR decode:
+        speaker vectors, timestep MLPs, the text encoder for every (step, cond/uncond) pair and the
+        cross-attention K / V^T of every decoder layer."""
         mdl, s, cfg = self.m, self.m.shape, self.cfg
         dev, dt = mdl.dev, mdl.dt
         st = self.stream.cuda_stream
@@ -114,15 +134,10 @@ class NARSession:
         D, H, FF, K, Q = s.dim, s.dim // 64, s.dim_ff, s.n_quant, s.n_codebooks
         guided = cfg.guidance_w != 1
         nb = 2 if guided else 1
+        self.nb = nb
         with torch.cuda.stream(self.stream):
             c_text = c_text.to(dev)
             c_codes = c_codes.to(dev).contiguous()
-            self.x = x.to(dev).contiguous().clone()
-            self.x_known = x_known.to(dev).contiguous()
-            self.m_mask = m_mask.to(device=dev, dtype=torch.uint8).contiguous()
-            S = self.x.shape[0]
-            self.S, self.row_offset, self.nb = S, int(row_offset), nb
-            assert S <= mdl.pe.shape[0]
             Lt = int(c_text.shape[0])
             Le = Lt + 1
             # -- speaker vectors (t-independent) and timestep MLPs for every scheduled t
@@ -168,19 +183,25 @@ class NARSession:
                                   vt_bs=H * 64 * Lep, vt_hs=64 * Lep, vt_ds=Lep)
                 ops.gemm(mem, lw.ca_kv_w, None, L.EPI_QKV, bias=lw.ca_kv_b, scatter=sc, stream=st)
                 self.mems.append(CrossMemory(k, vt, Le, Lep, nb))
-            # -- loop-body buffers
+            self.consts = nar_step_consts(self.times, K).to(dev)
+            self._keep = [table, t_enc, mem]
+
+    def prepare_loop(self) -> None:
+        """Loop-body buffers of a single-utterance session."""
+        mdl, s = self.m, self.m.shape
+        dev, dt = mdl.dev, mdl.dt
+        D, FF, K, Q = s.dim, s.dim_ff, s.n_quant, s.n_codebooks
+        S, nb = self.S, self.nb
+        with torch.cuda.stream(self.stream):
             self.ws = SeqWorkspace(nb, S, D, FF, dt, dev, row_pad=64)
             self.Sr = Sr = self.ws.Sr
             self.h = torch.zeros(nb, Sr, D, dtype=torch.float32, device=dev)
             self.hf = torch.zeros(nb * Sr, D, dtype=torch.float32, device=dev)
-            self.s_out = S - self.row_offset
             self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
             self.Kp = round_up(K, 4)
             self.logits = torch.empty(nb * self.s_out, Q - 1, self.Kp, dtype=torch.float32, device=dev)
-            self.consts = nar_step_consts(self.times, K).to(dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
-            self._keep = [table, t_enc, mem]
         self.graph = None
 
     # ----------------------------------------------------------------------------- step
@@ -246,3 +267,122 @@ class NARSession:
         self.stream.synchronize()
         LAST_STATS.update(loop_ms=ev0.elapsed_ms(ev1), steps=n, S=self.S, s_out=self.s_out, Le=self.mems[0].Le, nb=self.nb)
         return self.x
+
+
+class NARBatchSession:
+    """U utterances of mixed lengths refined together (BASELINE config 3: a batch of independent
+    requests on one GPU).  The reference refines one utterance per ``tts()`` call; nothing couples
+    utterances, so batching is an exact re-ordering: per reverse step ONE decoder pass runs over the
+    2U row-concatenated (cond, uncond) sequences - every projection / SwiGLU / head GEMM sees
+    M = 2U * Sr rows instead of 2 * Sr, which is what fills the 256 CUs - self-attention masks each
+    sequence to its own length (``key_len``), cross-attention is launched per utterance against that
+    utterance's pre-projected memory, and the posterior/sample kernel runs per utterance with that
+    utterance's own uniforms, so every utterance consumes its RNG stream exactly as it would alone.
+    Rows between an utterance's length and the common padded length hold finite junk that no real
+    row ever attends to and that is never sampled."""
+
+    def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None):
+        self.m, self.cfg = model, cfg
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=model.dev)
+        self.graph: Optional[ops.Graph] = None
+        self.subs: List[NARSession] = []
+
+    def prepare(self, items: List[dict], times: Optional[List[int]] = None) -> None:
+        """items: dicts with the arguments of ``NARSession.prepare`` (c_text, c_codes, x, x_known,
+        m_mask, row_offset), one per utterance."""
+        mdl, s = self.m, self.m.shape
+        dev, dt = mdl.dev, mdl.dt
+        D, FF, K, Q = s.dim, s.dim_ff, s.n_quant, s.n_codebooks
+        assert len(items) >= 1
+        self.subs = []
+        for it in items:
+            sub = NARSession(mdl, self.cfg, self.stream)
+            sub.prepare_state(it["x"], it["x_known"], it["m_mask"], it["row_offset"])
+            sub.prepare_cond(it["c_text"], it["c_codes"], times)
+            self.subs.append(sub)
+        self.times = self.subs[0].times
+        self.nb = nb = self.subs[0].nb
+        U = len(self.subs)
+        S_max = max(sub.S for sub in self.subs)
+        with torch.cuda.stream(self.stream):
+            self.ws = SeqWorkspace(U * nb, S_max, D, FF, dt, dev, row_pad=64)
+            self.Sr = Sr = self.ws.Sr
+            self.key_len = torch.tensor([sub.S for sub in self.subs for _ in range(nb)], dtype=torch.int32, device=dev)
+            self.h = torch.zeros(U * nb, Sr, D, dtype=torch.float32, device=dev)
+            self.hf = torch.zeros(U * nb * Sr, D, dtype=torch.float32, device=dev)
+            self.row0 = []
+            r = 0
+            for sub in self.subs:
+                self.row0.append(r)
+                r += nb * sub.s_out
+            self.R = r
+            self.hn = torch.empty(Q - 1, self.R, D, dtype=dt, device=dev)
+            self.Kp = round_up(K, 4)
+            self.logits = torch.empty(self.R, Q - 1, self.Kp, dtype=torch.float32, device=dev)
+            self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.step_i = 0
+        self.graph = None
+
+    def enqueue_forward(self, st: int) -> None:
+        mdl, s = self.m, self.m.shape
+        Sr, nb, D, Q = self.Sr, self.nb, s.dim, s.n_codebooks
+        t_dec = self.subs[0].t_dec                           # depends on the schedule only
+        for u, sub in enumerate(self.subs):
+            ops.chunked_embed(self.h[u * nb:(u + 1) * nb], mdl.res_tables, sub.x, None, mdl.pos_alpha, mdl.pe, add=t_dec,
+                              add_index=self.step_ptr, rows=sub.S, stream=st)
+        hx = self.h.view(-1, D)
+        for l, lw in enumerate(mdl.dec):
+            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len)
+        ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
+        for u, sub in enumerate(self.subs):
+            so = sub.s_out
+            for b in range(nb):
+                ops.layernorm(self.hf[(u * nb + b) * Sr + sub.row_offset:], mdl.head_g, mdl.head_b, 1e-5,
+                              self.hn[:, self.row0[u] + b * so:], n_affine=Q - 1, affine_stride=D, y_affine_stride=self.R * D, M=so,
+                              stream=st)
+        ops.gemm(self.hn[0], mdl.head_w[0], self.logits, L.EPI_F32, bias=mdl.head_bias, ldc=(Q - 1) * self.Kp, batch=Q - 1,
+                 sA=self.R * D, sW=s.n_quant * D, sC=self.Kp, sBias=s.n_quant, stream=st)
+
+    def step(self, uniforms: List[Callable[[tuple], torch.Tensor]], use_graph: bool = True) -> None:
+        st = self.stream.cuda_stream
+        s, cfg = self.m.shape, self.cfg
+        t = self.times[self.step_i]
+        if use_graph:
+            if self.graph is None:
+                self.stream.synchronize()
+                ops.Graph.begin(st)
+                self.enqueue_forward(st)
+                self.graph = ops.Graph().end(st)
+            self.graph.launch(st)
+        else:
+            self.enqueue_forward(st)
+        Q = s.n_codebooks
+        with torch.cuda.stream(self.stream):
+            for u, sub in enumerate(self.subs):
+                shape = (1, sub.S, Q, s.n_quant)
+                u1 = uniforms[u](shape)
+                u2 = uniforms[u](shape) if t > 0 else u1
+                lc = self.logits[self.row0[u]:]
+                lu = self.logits[self.row0[u] + sub.s_out:] if self.nb == 2 else None
+                a = L.NarSampleArgs(logits_c=lc.data_ptr(), logits_u=lu.data_ptr() if lu is not None else None,
+                                    ld_row=(Q - 1) * self.Kp, ld_q=self.Kp, S=sub.S, n_q=Q, K=s.n_quant, row_offset=sub.row_offset,
+                                    x=sub.x.data_ptr(), x_known=sub.x_known.data_ptr(), m=sub.m_mask.data_ptr(),
+                                    u1=u1.data_ptr(), u2=u2.data_ptr(), consts=sub.consts.data_ptr(),
+                                    step=self.step_ptr.data_ptr(), guidance_w=cfg.guidance_w, temperature=cfg.x_0_temp,
+                                    log_eps=log_eps(), div_mode=cfg.div_mode, q0_override_steps=cfg.q0_override_steps)
+                ops.nar_sample(a, stream=st)
+            ops.add_int(self.step_ptr, 1, stream=st)
+        self.step_i += 1
+
+    def run(self, uniforms: List[Callable[[tuple], torch.Tensor]], use_graph: bool = True, n_steps: Optional[int] = None) -> List[torch.Tensor]:
+        n = len(self.times) if n_steps is None else n_steps
+        st = self.stream.cuda_stream
+        ev0, ev1 = ops.Event(), ops.Event()
+        ev0.record(st)
+        for _ in range(n):
+            self.step(uniforms, use_graph)
+        ev1.record(st)
+        self.stream.synchronize()
+        LAST_STATS.update(loop_ms=ev0.elapsed_ms(ev1), steps=n, S=[sub.S for sub in self.subs], s_out=[sub.s_out for sub in self.subs],
+                          Le=[sub.mems[0].Le for sub in self.subs], nb=self.nb, batch=len(self.subs), rows=self.ws.M)
+        return [sub.x for sub in self.subs]

@@ -321,3 +321,128 @@ def test_full_size_goldens_f32(dev, gold_dir):
     n_bad = int((outn[0].cpu() != torch.from_numpy(fx["final"])).sum())
     print(f"full-size NAR: {n_bad}/{fx['final'].size} ids differ from the reference")
     assert n_bad <= 0.02 * fx["final"].size
+
+
+# ------------------------------------------------------------------------ batched requests (config 3)
+def _nar_batch_tuple(c_text, c_codes, x_l0):
+    _x = x_l0[None, :, None].repeat(1, 1, 8)
+    return (c_text[None], c_codes[None], torch.tensor([c_text.shape[0]]), torch.tensor([c_codes.shape[0]]), _x,
+            torch.zeros(1, _x.shape[1], dtype=torch.bool))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_nar_batch_mixed_lengths_equals_single(dev, tiny_bundle, gold_dir, dt):
+    """Config 3 (a batch of mixed-length requests on one GPU): the batched decoder pass must give every
+    utterance exactly the codes it gets alone (bit-exact: batching only re-orders independent work), and
+    the utterance that is the reference fixture must still match the reference's output."""
+    from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_batch_inference, perform_simple_inference
+    fx = np.load(os.path.join(gold_dir, "nar_tiny_deep.npz"))
+    nar = _nar(tiny_bundle, dt, dev)
+    T = int(fx["T_run"])
+    c_text, c_codes, x_l0 = torch.from_numpy(fx["c_text"]), torch.from_numpy(fx["c_codes"]), torch.from_numpy(fx["x_l0"])
+    gg = torch.Generator().manual_seed(123)
+    utts = [(c_text, c_codes, x_l0, int(fx["seed"])),                                       # the reference fixture itself
+            (c_text[: max(3, c_text.shape[0] // 2)], c_codes[: c_codes.shape[0] // 3], x_l0[: x_l0.shape[0] // 2], 41),
+            (torch.cat([c_text, c_text[1:-1]]), torch.randint(0, 1024, (c_codes.shape[0] + 37, 8), generator=gg),
+             torch.randint(0, 1024, (x_l0.shape[0] + 29,), generator=gg), 42),
+            (c_text[:5], c_codes[:70], x_l0[:9], 43)]
+    diff = MultinomialDiffusion(1025, timesteps=200, device="cpu")
+    dsh = DSH(last_greedy=True, x_0_temp=0.7, guidance_w=3, deep_clone=True, q0_override_steps=20)
+
+    def streams(seed):
+        g = torch.Generator().manual_seed(seed)
+        return (lambda shp: torch.rand(shp, generator=g).to(dev)), (lambda shp: torch.randint(0, 1025, shp, dtype=torch.long, generator=g))
+
+    singles = []
+    for ct, cc, xl, seed in utts:
+        uni, ri = streams(seed)
+        singles.append(perform_simple_inference(nar, _nar_batch_tuple(ct, cc, xl), diff, T, torch.float16, dsh=dsh, retain_quant0=True,
+                                                uniform=uni, randint=ri).cpu())
+    for use_graph in (False, True):
+        sr = [streams(seed) for *_, seed in utts]
+        outs = perform_batch_inference(nar, [_nar_batch_tuple(ct, cc, xl) for ct, cc, xl, _ in utts], diff, T, dsh=dsh,
+                                       uniforms=[s[0] for s in sr], randints=[s[1] for s in sr], use_graph=use_graph)
+        for i, (o, s) in enumerate(zip(outs, singles)):
+            assert o.shape == s.shape
+            assert torch.equal(o.cpu(), s), f"utterance {i} (graph={use_graph}): {int((o.cpu() != s).sum())} codes differ from the lone run"
+    if dt == torch.float32:
+        n_bad = int((outs[0][0].cpu() != torch.from_numpy(fx["final"])).sum())
+        assert n_bad <= 0.02 * fx["final"].size
+
+
+def _tiny_tts(tiny_bundle, dev, dt):
+    """A Mars5TTS around the tiny synthetic checkpoints (the constructor itself fixes the real geometry)."""
+    from inference import Mars5TTS
+    m = Mars5TTS.__new__(Mars5TTS)
+    m.device = dev
+    m.codec = m.vocos = False
+    m.texttok, m.speechtok = _toks(tiny_bundle)
+    m.n_vocab = len(m.texttok.vocab) + len(m.speechtok.vocab)
+    m.n_text_vocab = len(m.texttok.vocab) + 1
+    m.diffusion_n_classes = 1025
+    m.codeclm = _lm(tiny_bundle, dt, dev)
+    m.codecnar = _nar(tiny_bundle, dt, dev)
+    m.default_T, m.sr, m.latent_sr = 12, 24000, 75
+    m._expansion = m.speechtok.expansion_table()
+    return m
+
+
+def test_tts_batch_equals_sequential_seeded_calls(dev, tiny_bundle):
+    """``tts_batch_from_codes(seeds=[s_i])`` == ``torch.manual_seed(s_i); tts_from_codes(...)`` per request:
+    private per-request generators reproduce the global-generator streams (AR Exp(1) draws, generator
+    rewind after the decode, NAR randint / rand), independent of batch composition and order."""
+    from inference import InferenceConfig
+    from mars5_tts_amd import synth
+    m = _tiny_tts(tiny_bundle, dev, torch.bfloat16)
+    texts = ["The quick brown rat.", "Hi.", "A somewhat longer sentence, to vary the lengths.", "Rats!"]
+    trs = ["We meet.", "Demand is high, we hear.", "Ok.", "Yes yes."]
+    refs = [synth.make_ref_codes(n, seed=7 + i) for i, n in enumerate([60, 25, 90, 40])]
+    seeds = [1000, 1001, 1002, 1003]
+    cfgs = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
+                           generate_max_len_override=220)
+    seq = []
+    for i in range(4):
+        cfg_i = cfgs
+        torch.manual_seed(seeds[i])
+        seq.append(m.tts_from_codes(texts[i], refs[i], trs[i], cfg_i))
+    for nb in (4, 3):
+        out = m.tts_batch_from_codes(texts, refs, trs, cfgs, seeds=seeds, nar_batch=nb)
+        for i in range(4):
+            assert torch.equal(out[i][0].cpu(), seq[i][0].cpu()), f"request {i}: AR frames differ"
+            assert torch.equal(out[i][1].cpu(), seq[i][1].cpu()), f"request {i}: final codes differ (nar_batch={nb})"
+    print("generated frames per request:", [int(a.shape[0]) for a, _ in seq])
+
+
+def test_ar_generator_left_where_reference_leaves_it(dev, tiny_bundle):
+    """After ``ar_generate`` the device generator must sit where the reference leaves it: one
+    Exp(1) draw of (V,) per executed loop iteration (ar_generate.py:115), including the iteration that
+    samples EOS - not one per pre-drawn row."""
+    lm = _lm(tiny_bundle, torch.float32, dev)
+    tt, st = _toks(tiny_bundle)
+    from mars5_tts_amd import synth
+    from mars5_tts_amd.ar_generate import ar_generate
+    V = lm.engine().shape.n_vocab
+    n_text = len(tt.vocab)
+    eos = n_text + st.special_tokens['<|endofspeech|>']
+    ref = synth.make_ref_codes(40, seed=3)[0].T.contiguous()
+    prompt = torch.tensor(tt.encode("<|startoftext|>hello there<|endoftext|>", allowed_special='all'), dtype=torch.long)
+    seen_eos = seen_full = False
+    for seed in range(16):
+        max_len = prompt.shape[0] + (40 if seed % 2 == 0 else 600)
+        torch.manual_seed(seed)
+        out = ar_generate(tt, st, lm, prompt, ref, prompt.shape[0] + 1, max_len=max_len, fp16=False, temperature=1.5 if seed % 2 == 0 else 40.0, topk=0, top_p=1.0,
+                          n_phones_gen=None, vocode=False)
+        after = torch.rand(16, device=dev).cpu()
+        n_gen = out.shape[0] - prompt.shape[0]
+        ended = out.shape[0] < max_len
+        torch.manual_seed(seed)
+        for _ in range(n_gen + (1 if ended else 0)):
+            torch.empty(V, device=dev).exponential_(1)
+        expect = torch.rand(16, device=dev).cpu()
+        assert torch.equal(after, expect), f"seed {seed}: generator offset wrong (n_gen {n_gen}, ended_by_eos {ended})"
+        assert eos not in out.tolist()
+        seen_eos |= ended
+        seen_full |= not ended
+        if seen_eos and seen_full:
+            break
+    assert seen_full and seen_eos, f"max_len run seen: {seen_full}, EOS-terminated run seen: {seen_eos}"
