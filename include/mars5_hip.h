@@ -158,9 +158,27 @@ typedef struct {
     float* part; const int32_t* state;
     int32_t n_heads, w_alloc, window, nsplit;
     float scale;
+    /* batched decode (several sequences per launch; 0 / 1 = one sequence, strides ignored):
+     * sequence b uses qbuf + b*q_bs, k/vcache + b*cache_bs (elements), part + b*part_bs (floats),
+     * state + b*state_bs (int32 words). */
+    int32_t batch, state_bs;
+    int64_t q_bs, cache_bs, part_bs;
 } M5AttnDecodeArgs;
 /* nn_future.py:257-272 decode branch: q . K[:min(pos+1,W)] softmax . V, split over keys. */
 int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream);
+
+/* Batched decode step (BASELINE config 3: B sequences advance one token per step; the projections run
+ * as M = B row GEMMs through m5_gemm, whose M <= 32 path streams every weight once for the whole batch).
+ * Per-sequence state words as above at state + b*state_bs; finished sequences (ST_DONE) are skipped.
+ *  - m5_ar_rope_cache_batch: row b of the [B][3D] qkv buffer is rotated at ITS position (state POS),
+ *    q -> qbuf + b*q_bs ([h][64]), k / v -> this layer's cache of sequence b at slot pos % window
+ *    (same arithmetic as m5_rope_cache, nn_future.py:181-191,249-252).
+ *  - m5_ar_attn_combine_batch: merges the split-KV partials of m5_ar_attn_decode into out[b][D] (dtype). */
+int m5_ar_rope_cache_batch(int dtype, const void* qkv, int B, int n_heads, const float* rope, const int32_t* state,
+                           int32_t state_bs, void* qbuf, int64_t q_bs, void* kcache, void* vcache, int64_t cache_bs,
+                           int64_t cache_hs, int window, void* stream);
+int m5_ar_attn_combine_batch(int dtype, const float* part, int64_t part_bs, int B, int n_heads, int nsplit,
+                             const int32_t* state, int32_t state_bs, void* out, int64_t out_bs, void* stream);
 
 /* Sampler chain of ar_generate.py:74-115 + samplers.py:20-93 on device, then the
  * multinomial draw argmax(p / q) with caller-supplied Exp(1) noise, EOS / max_len
@@ -176,6 +194,12 @@ typedef struct {
     float typical_p;                             /* samplers.py:96-122; > 0.999 disables (reference default 1.0) */
     const float* noise; int64_t noise_stride;    /* Exp(1) draws [step][V]                    */
     const float* embed; int32_t dim; float* xres;
+    /* batched decode: one workgroup per sequence (0 / 1 = one sequence).  Sequence b uses
+     * logits + b*logits_bs, state + b*state_bs, tokens + b*tokens_bs, noise + b*noise_bs,
+     * xres + b*xres_bs, eos_table + b*eos_table_bs, and n_est_b[b] / max_len_b[b] when given. */
+    int32_t batch, state_bs;
+    int64_t logits_bs, tokens_bs, noise_bs, xres_bs, eos_table_bs;
+    const int32_t* n_est_b; const int32_t* max_len_b;
 } M5SampleArgs;
 int m5_ar_sample(const M5SampleArgs* a, void* stream);
 

@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
-from mars5_tts_amd.ar_generate import ar_generate
+from mars5_tts_amd.ar_generate import ar_generate, ar_generate_batch
 from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_batch_inference, perform_simple_inference
 from mars5_tts_amd.minbpe import GPT4_SPLIT_PATTERN, CodebookTokenizer, RegexTokenizer
 from mars5_tts_amd.model import CodecLM, ResidualTransformer
@@ -124,10 +124,8 @@ class Mars5TTS:
         return self.codeclm.get_spk_embedding(spk_reference)
 
     # ------------------------------------------------------------------ the hot path
-    def _ar_stage(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str], cfg: InferenceConfig,
-                  ar_noise: Optional[Tensor] = None, generator: Optional[torch.Generator] = None):
-        """Prompt construction + AR decode + BPE expansion (reference inference.py:222-285).
-        Returns (L0 frames (G,), the ``perform_simple_inference`` batch tuple, frames to skip in front)."""
+    def _prompt(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str], cfg: InferenceConfig) -> dict:
+        """Prompt construction of reference inference.py:222-258."""
         text_tokens = self.texttok.encode("<|startoftext|>" + text.strip() + "<|endoftext|>", allowed_special='all')
         text_tokens_full = self.texttok.encode("<|startoftext|>" + ref_transcript + ' ' + str(text).strip() + "<|endoftext|>",
                                                allowed_special='all')
@@ -136,7 +134,6 @@ class Mars5TTS:
         q0_str = ' '.join([str(t) for t in prompt_codec[0, 0].tolist()])
         speech_tokens = self.speechtok.encode(q0_str.strip())
         spk_ref_codec = prompt_codec[0, :, :].T
-        raw_prompt_acoustic_len = prompt_codec.shape[-1]
         n_text = len(self.texttok.vocab)
         offset_speech_codes = [p + n_text for p in speech_tokens]
         if not cfg.deep_clone:
@@ -145,32 +142,43 @@ class Mars5TTS:
             text_tokens = text_tokens_full
             n_speech_inp = len(offset_speech_codes)
         prompt = torch.tensor(text_tokens + offset_speech_codes, dtype=torch.long, device=self.device)
-        first_codec_idx = prompt.shape[-1] - n_speech_inp + 1
+        return dict(prompt=prompt, first_codec_idx=prompt.shape[-1] - n_speech_inp + 1, spk_ref_codec=spk_ref_codec,
+                    text_tokens=text_tokens, prompt_codec=prompt_codec, n_text=n_text, n_phones_gen=round(cfg.eos_estimated_gen_length_factor * len(text)))
 
-        ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, prompt, spk_ref_codec, first_codec_idx,
-                               max_len=cfg.generate_max_len_override if cfg.generate_max_len_override > 1 else 2000,
-                               fp16=True if torch.cuda.is_available() else False,
-                               temperature=cfg.temperature, topk=cfg.top_k, top_p=cfg.top_p, typical_p=cfg.typical_p,
-                               alpha_frequency=cfg.freq_penalty, alpha_presence=cfg.presence_penalty,
-                               penalty_window=cfg.rep_penalty_window, eos_penalty_decay=cfg.eos_penalty_decay,
-                               eos_penalty_factor=cfg.eos_penalty_factor, beam_width=cfg.beam_width, beam_length_penalty=1,
-                               n_phones_gen=round(cfg.eos_estimated_gen_length_factor * len(text)), vocode=False,
-                               use_kv_cache=cfg.use_kv_cache, noise=ar_noise, generator=generator)
+    def _ar_kwargs(self, cfg: InferenceConfig) -> dict:
+        return dict(max_len=cfg.generate_max_len_override if cfg.generate_max_len_override > 1 else 2000,
+                    temperature=cfg.temperature, topk=cfg.top_k, top_p=cfg.top_p, typical_p=cfg.typical_p,
+                    alpha_frequency=cfg.freq_penalty, alpha_presence=cfg.presence_penalty,
+                    penalty_window=cfg.rep_penalty_window, eos_penalty_decay=cfg.eos_penalty_decay,
+                    eos_penalty_factor=cfg.eos_penalty_factor)
 
-        # AR -> NAR hand-off: token ids -> L0 frames through the BPE expansion table
-        # (same result as speechtok.decode_int on the id list, inference.py:272-275)
-        output_tokens = (ar_codes - n_text).clamp(min=0)[first_codec_idx:].cpu().tolist()
+    def _handoff(self, pr: dict, ar_codes: Tensor, cfg: InferenceConfig):
+        """AR -> NAR hand-off (reference inference.py:262-285): token ids -> L0 frames through the BPE
+        expansion table (same result as speechtok.decode_int on the id list, inference.py:272-275), then
+        the ``perform_simple_inference`` batch tuple."""
+        output_tokens = (ar_codes - pr["n_text"]).clamp(min=0)[pr["first_codec_idx"]:].cpu().tolist()
         frames = [c for tk in output_tokens for c in self._expansion[tk]]
         gen_codes_decoded = torch.tensor(frames, dtype=torch.long, device=self.device)
-
+        text_tokens, prompt_codec = pr["text_tokens"], pr["prompt_codec"]
         c_text = torch.tensor(text_tokens, dtype=torch.long, device=self.device)[None]
         c_codes = prompt_codec.permute(0, 2, 1)
         c_texts_lengths = torch.tensor([len(text_tokens)], dtype=torch.long, device=self.device)
         c_codes_lengths = torch.tensor([c_codes.shape[1]], dtype=torch.long, device=self.device)
         _x = gen_codes_decoded[None, :, None].repeat(1, 1, 8)
         x_padding_mask = torch.zeros((1, _x.shape[1]), dtype=torch.bool, device=_x.device)
-        skip_front = raw_prompt_acoustic_len if cfg.deep_clone else 0
+        skip_front = prompt_codec.shape[-1] if cfg.deep_clone else 0
         return gen_codes_decoded, (c_text, c_codes, c_texts_lengths, c_codes_lengths, _x, x_padding_mask), skip_front
+
+    def _ar_stage(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str], cfg: InferenceConfig,
+                  ar_noise: Optional[Tensor] = None, generator: Optional[torch.Generator] = None):
+        """Prompt construction + AR decode + BPE expansion (reference inference.py:222-285).
+        Returns (L0 frames (G,), the ``perform_simple_inference`` batch tuple, frames to skip in front)."""
+        pr = self._prompt(text, prompt_codec, ref_transcript, cfg)
+        ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
+                               fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
+                               n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
+                               generator=generator, **self._ar_kwargs(cfg))
+        return self._handoff(pr, ar_codes, cfg)
 
     def _dsh(self, cfg: InferenceConfig) -> DSH:
         return DSH(last_greedy=True, x_0_temp=cfg.x_0_temp, guidance_w=cfg.nar_guidance_w, deep_clone=cfg.deep_clone,
@@ -194,12 +202,16 @@ class Mars5TTS:
     @torch.inference_mode()
     def tts_batch_from_codes(self, texts: List[str], prompt_codecs: List[Tensor], ref_transcripts: List[Optional[str]],
                              cfg: InferenceConfig = InferenceConfig(), seeds: Optional[List[int]] = None,
-                             nar_batch: int = 8) -> List[Tuple[Tensor, Tensor]]:
+                             nar_batch: int = 8, ar_batch: int = 1) -> List[Tuple[Tensor, Tensor]]:
         """Several independent requests on one GPU (BASELINE config 3).  Request i gets a private
-        device generator seeded ``seeds[i]``, so its result equals ``torch.manual_seed(seeds[i]);
-        tts_from_codes(...)`` whatever else is in the batch.  The AR stage runs request by request
-        (its decode step is a batch-1 weight stream); the NAR stage refines up to `nar_batch` requests
-        of similar length per decoder pass (``perform_batch_inference``)."""
+        device generator seeded ``seeds[i]`` and consumes it as a lone call would.
+        NAR: up to `nar_batch` requests of similar length are refined per decoder pass
+        (``perform_batch_inference``) - exact: result i equals ``torch.manual_seed(seeds[i]);
+        tts_from_codes(...)`` whatever else is in the batch.
+        AR: `ar_batch` = 1 decodes request by request (the batch-1 weight-streaming GEMV path, bit-equal to
+        the lone call); `ar_batch` > 1 decodes that many requests per step (``ar_generate_batch``: the weights
+        are read once per step for all of them; logits then differ from the lone call by GEMM summation
+        order, like any batch-size change does in the reference)."""
         n = len(texts)
         assert len(prompt_codecs) == n and len(ref_transcripts) == n
         gens = []
@@ -207,7 +219,21 @@ class Mars5TTS:
             g = torch.Generator(device=self.device)
             g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.seed()))
             gens.append(g)
-        staged = [self._ar_stage(texts[i], prompt_codecs[i], ref_transcripts[i], cfg, None, gens[i]) for i in range(n)]
+        if ar_batch <= 1:
+            staged = [self._ar_stage(texts[i], prompt_codecs[i], ref_transcripts[i], cfg, None, gens[i]) for i in range(n)]
+        else:
+            assert cfg.beam_width == 1, "Only beam size of 1 is currently supported."
+            prs = [self._prompt(texts[i], prompt_codecs[i], ref_transcripts[i], cfg) for i in range(n)]
+            staged = [None] * n
+            order = sorted(range(n), key=lambda i: prs[i]["prompt"].shape[0])
+            for g0 in range(0, n, min(ar_batch, 32)):
+                grp = order[g0:g0 + min(ar_batch, 32)]
+                outs = ar_generate_batch(self.texttok, self.speechtok, self.codeclm, [prs[i]["prompt"] for i in grp],
+                                         [prs[i]["spk_ref_codec"] for i in grp], [prs[i]["first_codec_idx"] for i in grp],
+                                         n_phones_gens=[prs[i]["n_phones_gen"] for i in grp], generators=[gens[i] for i in grp],
+                                         **self._ar_kwargs(cfg))
+                for i, o in zip(grp, outs):
+                    staged[i] = self._handoff(prs[i], o, cfg)
         T = self.default_T
         diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
         # group requests of similar total NAR length: the batch is padded to its longest member

@@ -67,7 +67,8 @@ class GemvArgs(C.Structure):
 
 class AttnDecodeArgs(C.Structure):
     _fields_ = [("qbuf", vp), ("kcache", vp), ("vcache", vp), ("part", vp), ("state", vp),
-                ("n_heads", i32), ("w_alloc", i32), ("window", i32), ("nsplit", i32), ("scale", f32)]
+                ("n_heads", i32), ("w_alloc", i32), ("window", i32), ("nsplit", i32), ("scale", f32),
+                ("batch", i32), ("state_bs", i32), ("q_bs", i64), ("cache_bs", i64), ("part_bs", i64)]
 
 
 class SampleArgs(C.Structure):
@@ -79,7 +80,10 @@ class SampleArgs(C.Structure):
                 ("temperature", f32), ("div_mode", i32),
                 ("top_k", i32), ("top_p", f32), ("typical_p", f32),
                 ("noise", vp), ("noise_stride", i64),
-                ("embed", vp), ("dim", i32), ("xres", vp)]
+                ("embed", vp), ("dim", i32), ("xres", vp),
+                ("batch", i32), ("state_bs", i32),
+                ("logits_bs", i64), ("tokens_bs", i64), ("noise_bs", i64), ("xres_bs", i64), ("eos_table_bs", i64),
+                ("n_est_b", vp), ("max_len_b", vp)]
 
 
 class NarSampleArgs(C.Structure):
@@ -107,6 +111,8 @@ PROTOTYPES = {
     "m5_ar_gemv": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(GemvArgs), vp]),
     "m5_ar_attn_decode": (C.c_int, [C.c_int, C.POINTER(AttnDecodeArgs), vp]),
     "m5_ar_sample": (C.c_int, [C.POINTER(SampleArgs), vp]),
+    "m5_ar_rope_cache_batch": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, i32, vp, i64, vp, vp, i64, i64, C.c_int, vp]),
+    "m5_ar_attn_combine_batch": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, vp, i32, vp, i64, vp]),
     "m5_nar_sample": (C.c_int, [C.POINTER(NarSampleArgs), vp]),
     "m5_add_int": (C.c_int, [vp, i32, vp]),
     "m5_graph_begin": (C.c_int, [vp]),

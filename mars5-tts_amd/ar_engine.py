@@ -85,27 +85,32 @@ class ARModel:
 class ARSession:
     """One utterance: prefill + decode.  Owns KV cache and step buffers (caller = this host code)."""
 
-    def __init__(self, model: ARModel, max_len: int, stream: Optional[torch.cuda.Stream] = None):
+    def __init__(self, model: ARModel, max_len: int, stream: Optional[torch.cuda.Stream] = None,
+                 w_alloc: Optional[int] = None, buffers: Optional[Dict[str, torch.Tensor]] = None):
+        """`buffers` (kc, vc, xdec, logits, state, tokens): views into a batch session's arrays, so the same
+        prefill code fills sequence b of a batch; `w_alloc` then is the batch's common cache allocation."""
         self.m = model
         s, dev, dt = model.shape, model.dev, model.dt
         self.max_len = max_len
         self.window = s.sliding_window
-        self.w_alloc = min(s.sliding_window, max_len + 1)
+        self.w_alloc = min(s.sliding_window, max_len + 1) if w_alloc is None else w_alloc
         assert max_len + 1 <= model.max_pos
         H, D, F, V = s.nhead, s.dim, s.hidden_dim, s.n_vocab
-        self.kc = torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
-        self.vc = torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
-        self.xdec = torch.zeros(D, dtype=torch.float32, device=dev)
+        bf = buffers or {}
+        self.kc = bf["kc"] if "kc" in bf else torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
+        self.vc = bf["vc"] if "vc" in bf else torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
+        self.xdec = bf["xdec"] if "xdec" in bf else torch.zeros(D, dtype=torch.float32, device=dev)
         self.qbuf = torch.zeros(D, dtype=dt, device=dev)
         self.hbuf = torch.zeros(F, dtype=dt, device=dev)
         self.part = torch.zeros(H, NSPLIT, L.ATTN_PART, dtype=torch.float32, device=dev)
-        self.logits = torch.zeros(V, dtype=torch.float32, device=dev)
-        self.state = torch.zeros(L.ST_WORDS, dtype=torch.int32, device=dev)
-        self.tokens = torch.zeros(max_len + 1, dtype=torch.int64, device=dev)
+        self.logits = bf["logits"] if "logits" in bf else torch.zeros(V, dtype=torch.float32, device=dev)
+        self.state = bf["state"] if "state" in bf else torch.zeros(L.ST_WORDS, dtype=torch.int32, device=dev)
+        self.tokens = bf["tokens"] if "tokens" in bf else torch.zeros(max_len + 1, dtype=torch.int64, device=dev)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.graph: Optional[ops.Graph] = None
         self._sample_args: Optional[L.SampleArgs] = None
         self._keep: List[torch.Tensor] = []
+        self.ended_on_eos = False
 
     # ------------------------------------------------------------------ prefill
     def prefill(self, prompt: torch.Tensor, ref_codes: torch.Tensor) -> None:
@@ -250,3 +255,145 @@ class ARSession:
         LAST_STATS.update(decode_ms=ev0.elapsed_ms(ev1), decode_steps_launched=done, n_generated=n_tok - self.P,
                           prefill_len=self.P + 1, final_len=n_tok)
         return self.tokens[:n_tok].clone()
+
+
+class ARBatchSession:
+    """B independent sequences decoded together (BASELINE config 3).  The decode step is HBM-bound on the
+    1.36 GB of weights, so advancing B sequences per step reads them once for all: the projections become
+    M = B row GEMMs (``m5_gemm``'s M <= 32 weight-streaming path), while everything per sequence -- RoPE
+    position, KV cache, cache scan, sampler chain, EOS / max_len, RNG rows -- keeps its own device state,
+    so sequence b produces what it would produce alone up to the summation order of the GEMMs.  Prefill
+    runs sequence by sequence through ``ARSession.prefill`` on views of the batch arrays.  One captured
+    hipGraph (9 launches per layer + head + sampler) serves every step; finished sequences idle."""
+
+    def __init__(self, model: ARModel, max_lens: List[int], stream: Optional[torch.cuda.Stream] = None):
+        self.m = model
+        s, dev, dt = model.shape, model.dev, model.dt
+        self.B = B = len(max_lens)
+        assert 1 <= B <= 32, "the skinny GEMM path covers up to 32 sequences per step"
+        self.max_lens = list(max_lens)
+        self.window = s.sliding_window
+        self.w_alloc = min(s.sliding_window, max(max_lens) + 1)
+        assert max(max_lens) + 1 <= model.max_pos
+        H, D, F, V, Lr = s.nhead, s.dim, s.hidden_dim, s.n_vocab, s.n_layers
+        self.kc = torch.zeros(B, Lr, H, self.w_alloc, 64, dtype=dt, device=dev)
+        self.vc = torch.zeros(B, Lr, H, self.w_alloc, 64, dtype=dt, device=dev)
+        self.x = torch.zeros(B, D, dtype=torch.float32, device=dev)
+        self.xn = torch.zeros(B, D, dtype=dt, device=dev)
+        self.qkv = torch.zeros(B, 3 * D, dtype=dt, device=dev)
+        self.qbuf = torch.zeros(B, D, dtype=dt, device=dev)
+        self.att = torch.zeros(B, D, dtype=dt, device=dev)
+        self.hbuf = torch.zeros(B, F, dtype=dt, device=dev)
+        self.part = torch.zeros(B, H, NSPLIT, L.ATTN_PART, dtype=torch.float32, device=dev)
+        self.logits = torch.zeros(B, V, dtype=torch.float32, device=dev)
+        self.state = torch.zeros(B, L.ST_WORDS, dtype=torch.int32, device=dev)
+        self.tokens = torch.zeros(B, max(max_lens) + 1, dtype=torch.int64, device=dev)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.subs = [ARSession(model, max_lens[b], self.stream, w_alloc=self.w_alloc,
+                               buffers=dict(kc=self.kc[b], vc=self.vc[b], xdec=self.x[b], logits=self.logits[b], state=self.state[b],
+                                            tokens=self.tokens[b])) for b in range(B)]
+        self.graph: Optional[ops.Graph] = None
+        self.P: List[int] = [0] * B
+
+    def prefill(self, prompts: List[torch.Tensor], ref_codes: List[torch.Tensor]) -> None:
+        for b, sub in enumerate(self.subs):
+            sub.prefill(prompts[b], ref_codes[b])
+            self.P[b] = sub.P
+
+    def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: torch.Tensor,
+                          n_phones_gen: Optional[List[Optional[int]]] = None) -> None:
+        """noise (B, n_steps, V) fp32 device: row [b][i] feeds sequence b's i-th sampler call.
+        n_phones_gen: per-sequence EOS-penalty length estimates (``cfg.n_phones_gen`` for all when None)."""
+        m, s, B = self.m, self.m.shape, self.B
+        assert noise.dtype == torch.float32 and noise.shape[0] == B and noise.shape[2] == s.n_vocab and noise.is_contiguous()
+        ests = n_phones_gen if n_phones_gen is not None else [cfg.n_phones_gen] * B
+        eos_tab = n_est_b = None
+        if any(e is not None for e in ests):
+            assert all(e is not None for e in ests)
+            n_max = max(int(e) for e in ests)
+            eos_tab = torch.zeros(B, n_max + 1, dtype=torch.float32)
+            for b, e in enumerate(ests):
+                eos_tab[b, : int(e) + 1] = eos_penalty_table(int(e), cfg.eos_penalty_decay, cfg.eos_penalty_factor)
+            eos_tab = eos_tab.to(m.dev)
+            n_est_b = torch.tensor([int(e) for e in ests], dtype=torch.int32, device=m.dev)
+        max_len_b = torch.tensor(self.max_lens, dtype=torch.int32, device=m.dev)
+        self._keep = [eos_tab, n_est_b, max_len_b, noise]
+        self.eos_idx = eos_idx
+        self.n_noise = noise.shape[1]
+        self._sample_args = L.SampleArgs(
+            logits=self.logits.data_ptr(), V=s.n_vocab, state=self.state.data_ptr(), tokens=self.tokens.data_ptr(), max_len=max(self.max_lens),
+            alpha_frequency=cfg.alpha_frequency, alpha_presence=cfg.alpha_presence, penalty_window=cfg.penalty_window, n_text=n_text,
+            eos_idx=eos_idx, n_est=0, eos_table=eos_tab.data_ptr() if eos_tab is not None else None, temperature=cfg.temperature,
+            div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, typical_p=float(cfg.typical_p), noise=noise.data_ptr(),
+            noise_stride=s.n_vocab, embed=m.embed.data_ptr(), dim=s.dim, xres=self.x.data_ptr(),
+            batch=B, state_bs=L.ST_WORDS, logits_bs=s.n_vocab, tokens_bs=self.tokens.stride(0), noise_bs=noise.stride(0), xres_bs=s.dim,
+            eos_table_bs=eos_tab.stride(0) if eos_tab is not None else 0,
+            n_est_b=n_est_b.data_ptr() if n_est_b is not None else None, max_len_b=max_len_b.data_ptr())
+
+    def enqueue_head_and_sample(self, st: int) -> None:
+        m, s = self.m, self.m.shape
+        ops.rmsnorm(self.x, m.final_norm, s.norm_eps, self.xn, stream=st)
+        ops.gemm(self.xn, m.w_out, self.logits, L.EPI_F32, stream=st)
+        ops.ar_sample(self._sample_args, stream=st)
+
+    def enqueue_layers(self, st: int) -> None:
+        m, s, B = self.m, self.m.shape, self.B
+        D, H = s.dim, s.nhead
+        cache_hs = self.w_alloc * 64
+        cache_bs = s.n_layers * H * cache_hs
+        for l in range(s.n_layers):
+            ops.rmsnorm(self.x, m.attn_norm[l], s.norm_eps, self.xn, stream=st)
+            ops.gemm(self.xn, m.wqkv[l], self.qkv, L.EPI_DT, stream=st)
+            ops.ar_rope_cache_batch(self.qkv, H, m.rope, self.state, self.qbuf, self.kc[0, l], self.vc[0, l], cache_bs, cache_hs,
+                                    self.window, stream=st)
+            d = L.AttnDecodeArgs(qbuf=self.qbuf.data_ptr(), kcache=self.kc[0, l].data_ptr(), vcache=self.vc[0, l].data_ptr(),
+                                 part=self.part.data_ptr(), state=self.state.data_ptr(), n_heads=H, w_alloc=self.w_alloc,
+                                 window=self.window, nsplit=NSPLIT, scale=64 ** -0.5, batch=B, state_bs=L.ST_WORDS, q_bs=D,
+                                 cache_bs=cache_bs, part_bs=self.part.stride(0))
+            ops.ar_attn_decode(m.dt, d, stream=st)
+            ops.ar_attn_combine_batch(self.part, H, NSPLIT, self.state, self.att, stream=st)
+            ops.gemm(self.att, m.wo[l], self.x, L.EPI_RESIDUAL, stream=st)
+            ops.rmsnorm(self.x, m.ffn_norm[l], s.norm_eps, self.xn, stream=st)
+            ops.gemm(self.xn, m.w13[l], self.hbuf, L.EPI_SWIGLU, stream=st)
+            ops.gemm(self.hbuf, m.w2[l], self.x, L.EPI_RESIDUAL, stream=st)
+
+    def decode(self, use_graph: bool = True, poll: int = 32) -> List[torch.Tensor]:
+        """Sampler for the prefill logits of every sequence, then batched steps until every sequence has hit
+        EOS or its max_len.  Returns the B token sequences (prompt + generated, EOS not appended)."""
+        st = self.stream.cuda_stream
+        self.enqueue_head_and_sample(st)
+        budget = min(max(ml - p - 1 for ml, p in zip(self.max_lens, self.P)), self.n_noise - 1)
+        if use_graph and self.graph is None and budget > 0:
+            self.stream.synchronize()
+            ops.Graph.begin(st)
+            self.enqueue_layers(st)
+            self.enqueue_head_and_sample(st)
+            self.graph = ops.Graph().end(st)
+        ev0, ev1 = ops.Event(), ops.Event()
+        ev0.record(st)
+        done = 0
+        while done < budget:
+            n = min(poll, budget - done)
+            for _ in range(n):
+                if use_graph:
+                    self.graph.launch(st)
+                else:
+                    self.enqueue_layers(st)
+                    self.enqueue_head_and_sample(st)
+            done += n
+            with torch.cuda.stream(self.stream):
+                flags = self.state.cpu()                       # syncs this stream only
+            if bool((flags[:, L.ST_DONE] != 0).all()):
+                break
+        ev1.record(st)
+        self.stream.synchronize()
+        final = self.state.cpu()
+        outs = []
+        self.ended_on_eos = []
+        for b in range(self.B):
+            n_tok = int(final[b, L.ST_NTOK])
+            outs.append(self.tokens[b, :n_tok].clone())
+            self.ended_on_eos.append(bool(int(final[b, L.ST_DONE])) and int(final[b, L.ST_LAST]) == int(self.eos_idx))
+        LAST_STATS.update(decode_ms=ev0.elapsed_ms(ev1), decode_steps_launched=done, batch=self.B,
+                          n_generated=[int(final[b, L.ST_NTOK]) - self.P[b] for b in range(self.B)])
+        return outs

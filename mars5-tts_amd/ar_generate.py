@@ -3,12 +3,12 @@ and error behaviour; the token loop runs on the MI355X engine (``ar_engine``).""
 from __future__ import annotations
 
 import logging
-from typing import Optional
+from typing import List, Optional
 
 import torch
 from torch import Tensor
 
-from .ar_engine import ARSamplingConfig, ARSession
+from .ar_engine import ARBatchSession, ARSamplingConfig, ARSession
 
 
 @torch.inference_mode()
@@ -75,3 +75,58 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
     if out.shape[-1] >= max_len - 1:
         logging.warning(f"[autoregressive generation] output length = {out.shape[-1]} -- inference likely failed or input too long!")
     return out
+
+
+@torch.inference_mode()
+def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: List[Tensor], first_codex_idxs: List[int],
+                      max_len: int = 1500, temperature: float = 1.0, topk: int = None, top_p=1.0, alpha_frequency=0,
+                      alpha_presence=0, penalty_window=100, typical_p=1.0, eos_penalty_factor=1.0, eos_penalty_decay=0,
+                      n_phones_gens: Optional[List[Optional[int]]] = None, generators: Optional[List[Optional[torch.Generator]]] = None,
+                      noises: Optional[List[Tensor]] = None, use_graph: bool = True, div_mode: int = 0) -> List[Tensor]:
+    """``ar_generate`` for B <= 32 independent requests decoded together (BASELINE config 3): request i
+    completes prompt ``xxs[i]`` with speaker reference ``ss_gens[i]`` exactly as a lone call would, drawing
+    its Exp(1) noise from ``generators[i]`` (or ``noises[i]``, (n_steps, V)); the decode step reads the
+    weights once for all requests.  Returns the B full sequences (prompt + generated, EOS not appended)."""
+    B = len(xxs)
+    assert len(ss_gens) == B and len(first_codex_idxs) == B
+    eng = codeclm.engine()
+    dev = eng.dev
+    n_text = len(texttok.vocab)
+    n_vocab = n_text + len(speechtok.vocab)
+    assert n_vocab == eng.shape.n_vocab, (n_vocab, eng.shape.n_vocab)
+    eos_idx = n_text + speechtok.special_tokens['<|endofspeech|>']
+    Ps = [int(x.shape[-1]) for x in xxs]
+    for x, P in zip(xxs, Ps):
+        assert x.dim() == 1 and P < max_len, "every request needs room to generate (a lone call just returns the prompt)"
+    sess = ARBatchSession(eng, [max_len] * B)
+    n_steps = max(max_len - P for P in Ps)
+    gens, offs, pers = [], [], []
+    with torch.cuda.stream(sess.stream):
+        noise_d = torch.ones(B, n_steps, n_vocab, dtype=torch.float32, device=dev)
+        for b in range(B):
+            nb = max_len - Ps[b]
+            if noises is not None:
+                noise_d[b, :nb] = noises[b].to(device=dev, dtype=torch.float32)[:nb]
+                gens.append(None)
+                offs.append(0)
+                pers.append(0)
+                continue
+            g = generators[b] if generators is not None and generators[b] is not None else torch.cuda.default_generators[dev.index]
+            off0 = g.get_offset()
+            for i in range(nb):
+                noise_d[b, i].exponential_(1, generator=g)
+            gens.append(g)
+            offs.append(off0)
+            pers.append((g.get_offset() - off0) // nb)
+    cfg = ARSamplingConfig(temperature=float(temperature), topk=topk, top_p=float(top_p), alpha_frequency=float(alpha_frequency),
+                           alpha_presence=float(alpha_presence), penalty_window=int(penalty_window), typical_p=float(typical_p),
+                           eos_penalty_factor=float(eos_penalty_factor), eos_penalty_decay=float(eos_penalty_decay),
+                           n_phones_gen=None, div_mode=div_mode)
+    sess.configure_sampler(cfg, n_text, eos_idx, noise_d, n_phones_gen=n_phones_gens)
+    sess.prefill(xxs, ss_gens)
+    outs = sess.decode(use_graph=use_graph)
+    for b in range(B):                      # leave every generator where a lone reference call leaves it
+        if gens[b] is not None:
+            n_iter = (int(outs[b].shape[-1]) - Ps[b]) + (1 if sess.ended_on_eos[b] else 0)
+            gens[b].set_offset(offs[b] + n_iter * pers[b])
+    return outs

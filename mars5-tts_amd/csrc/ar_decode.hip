@@ -435,6 +435,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
     constexpr int LPP = 64 / EPL;          // lanes per position: 8 (16-bit) or 16 (f32)
     constexpr int PPW = 64 / LPP;          // positions per wave instruction
     __shared__ float sm[4][LPP][EPL + 2];
+    {   // batched decode: blockIdx.z = sequence (all strides are 0 for a single sequence)
+        const int64_t b = blockIdx.z;
+        a.state += b * a.state_bs;
+        a.qbuf = reinterpret_cast<const st*>(a.qbuf) + b * a.q_bs;
+        a.kcache = reinterpret_cast<const st*>(a.kcache) + b * a.cache_bs;
+        a.vcache = reinterpret_cast<const st*>(a.vcache) + b * a.cache_bs;
+        a.part += b * a.part_bs;
+    }
     const int done = a.state[M5_ST_DONE];          // consumed before the only global write (a finished sequence just idles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, split = blockIdx.y;
@@ -578,6 +586,17 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
     __shared__ float red[16];
     __shared__ int sh_i[4];
     __shared__ float sh_f[2];
+    {   // batched decode: blockIdx.x = sequence (all strides are 0 for a single sequence)
+        const int64_t b = blockIdx.x;
+        a.logits += b * a.logits_bs;
+        a.state += b * a.state_bs;
+        a.tokens += b * a.tokens_bs;
+        a.noise += b * a.noise_bs;
+        a.xres += b * a.xres_bs;
+        if (a.eos_table) a.eos_table += b * a.eos_table_bs;
+        if (a.n_est_b) a.n_est = a.n_est_b[b];
+        if (a.max_len_b) a.max_len = a.max_len_b[b];
+    }
     int32_t* st = a.state;
     if (st[M5_ST_DONE]) return;
     const int tid = threadIdx.x;
@@ -898,7 +917,7 @@ extern "C" int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void
 
 extern "C" int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream) {
     if (!a || !a->qbuf || !a->kcache || !a->vcache || !a->part || !a->state || a->n_heads <= 0 || a->nsplit <= 0) return M5_ERR_ARG;
-    dim3 grid(a->n_heads, a->nsplit);
+    dim3 grid(a->n_heads, a->nsplit, a->batch > 1 ? a->batch : 1);
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case M5_F32: hipLaunchKernelGGL(attn_decode_kernel<F32T>, grid, dim3(256), 0, s, *a); break;
@@ -923,7 +942,7 @@ extern "C" int m5_ar_sample(const M5SampleArgs* a, void* stream) {
         (void)hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);   // = 4096 * 24 >= 4096 * 20
         attr_set = true;
     }
-    hipLaunchKernelGGL(sample_kernel, dim3(1), dim3(1024), sm, (hipStream_t)stream, *a, V2);
+    hipLaunchKernelGGL(sample_kernel, dim3(a->batch > 1 ? a->batch : 1), dim3(1024), sm, (hipStream_t)stream, *a, V2);
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

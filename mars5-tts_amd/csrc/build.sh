@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
 mkdir -p obj
 pids=()
-for f in gemm gemm16 attention attention16 rowops ar_decode nar_sample util; do
+for f in gemm gemm16 gemm_skinny attention attention16 rowops ar_decode ar_batch nar_sample util; do
   if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ ../../include/mars5_hip.h -nt obj/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o obj/$f.o &
     pids+=($!)

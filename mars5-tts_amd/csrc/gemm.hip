@@ -226,6 +226,9 @@ int launch_gemm(int epi, const GemmParams& p, dim3 grid, hipStream_t s) {
 int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc, const int* sec_kind,
                        int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s);   // gemm16.hip
+bool m5_gemm_skinny_fits(int dtype, int M, int N, int K, int epi, int batch, int64_t lda, int64_t ldw);   // gemm_skinny.hip
+int m5_gemm_skinny_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                            void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s);
 
 static bool use_v1_gemm() {   // M5_GEMM_V1=1: A/B the first-generation register-staged kernel
     static const bool v = [] { const char* e = getenv("M5_GEMM_V1"); return e && e[0] == '1'; }();
@@ -259,6 +262,8 @@ extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int
         p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (m5_gemm_skinny_fits(dtype, M, N, K, epi, batch, lda, ldw))          // batched decode step: M <= 32 rows
+        return m5_gemm_skinny_dispatch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, s);
     if (dtype != M5_F32 && !use_v1_gemm())
         return m5_gemm16_dispatch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, epi == M5_EPI_QKV ? &p.sc : nullptr,
                                   p.sec_kind, batch, sA, sW, sC, sBias, s);

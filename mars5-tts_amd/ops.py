@@ -103,6 +103,25 @@ def ar_gemv(dtype: torch.dtype, pro: int, epi: int, args: L.GemvArgs, stream: Op
     check(lib.m5_ar_gemv(DT_CODE[dtype], pro, epi, C.byref(args), _s(stream)), "m5_ar_gemv")
 
 
+def ar_rope_cache_batch(qkv: torch.Tensor, n_heads: int, rope: torch.Tensor, state: torch.Tensor, qbuf: torch.Tensor,
+                        kcache: torch.Tensor, vcache: torch.Tensor, cache_bs: int, cache_hs: int, window: int,
+                        stream: Optional[int] = None) -> None:
+    """qkv (B, 3D) dtype; state (B, ST_WORDS) int32; qbuf (B, D); k/vcache: this layer's [h][W][64] block of
+    sequence 0, sequence b at + b*cache_bs elements."""
+    B = qkv.shape[0]
+    check(lib.m5_ar_rope_cache_batch(DT_CODE[qkv.dtype], _p(qkv), B, n_heads, _p(rope), _p(state), state.stride(0), _p(qbuf),
+                                     qbuf.stride(0), _p(kcache), _p(vcache), cache_bs, cache_hs, window, _s(stream)),
+          "m5_ar_rope_cache_batch")
+
+
+def ar_attn_combine_batch(part: torch.Tensor, n_heads: int, nsplit: int, state: torch.Tensor, out: torch.Tensor,
+                          stream: Optional[int] = None) -> None:
+    """part (B, H, nsplit, ATTN_PART) fp32 -> out (B, D) dtype."""
+    B = part.shape[0]
+    check(lib.m5_ar_attn_combine_batch(DT_CODE[out.dtype], _p(part), part.stride(0), B, n_heads, nsplit, _p(state), state.stride(0),
+                                       _p(out), out.stride(0), _s(stream)), "m5_ar_attn_combine_batch")
+
+
 def ar_attn_decode(dtype: torch.dtype, args: L.AttnDecodeArgs, stream: Optional[int] = None) -> None:
     check(lib.m5_ar_attn_decode(DT_CODE[dtype], C.byref(args), _s(stream)), "m5_ar_attn_decode")
 

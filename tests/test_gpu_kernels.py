@@ -61,6 +61,54 @@ def test_gemm_epilogues(dev, dt, M, N, K):
     assert _rel(out3.float().cpu(), torch.nn.functional.silu(ref)) < max(TOL[dt], 8e-3 if dt != torch.float32 else 0)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [1, 5, 16, 17, 32])
+def test_gemm_skinny_decode_shapes(dev, dt, M):
+    """The M <= 32 weight-streaming path of m5_gemm (batched AR decode step) at the real projection shapes:
+    every epilogue against fp32 torch on the dtype-rounded operands, and against the wide-tile kernel
+    (M5_GEMM_SKINNY=0) to catch layout mistakes that a tolerance could hide."""
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.blocks import interleave_rows
+    tol = max(TOL[dt], 8e-3)
+    for (N, K, epi) in [(4608, 1536, L.EPI_DT), (1536, 1536, L.EPI_RESIDUAL), (7168, 1536, L.EPI_SWIGLU), (1536, 3584, L.EPI_RESIDUAL),
+                        (4096, 1536, L.EPI_F32), (48, 64, L.EPI_F32), (160, 4096, L.EPI_DT)]:
+        a = _q(_rand((M, K), 1 + M), dt)
+        sc = 1.0 / math.sqrt(K)
+        if epi == L.EPI_SWIGLU:
+            w1, w3 = _q(_rand((N // 2, K), 2, sc * 4), dt), _q(_rand((N // 2, K), 3, sc * 4), dt)
+            w = interleave_rows(w1, w3)
+            ref = torch.nn.functional.silu(a @ w1.T) * (a @ w3.T)
+        else:
+            w = _q(_rand((N, K), 2, sc * 4), dt)
+            ref = a @ w.T
+        bias = _rand((N,), 4) if epi in (L.EPI_DT, L.EPI_F32) else None
+        if bias is not None:
+            ref = ref + bias
+        ad, wd = a.to(dev, dt), w.to(dev, dt)
+        bd = bias.to(dev) if bias is not None else None
+        outs = []
+        for skinny in ("1", "0"):
+            os.environ["M5_GEMM_SKINNY"] = skinny
+            if epi == L.EPI_RESIDUAL:
+                res0 = _rand((M, N), 5).to(dev)
+                o = res0.clone()
+                ops.gemm(ad, wd, o, epi)
+                torch.cuda.synchronize()
+                o = (o - res0).cpu()
+            else:
+                No = N // 2 if epi == L.EPI_SWIGLU else N
+                o = torch.zeros(M + 2, No, device=dev, dtype=torch.float32 if epi == L.EPI_F32 else dt)   # 2 guard rows
+                ops.gemm(ad, wd, o[:M], epi, bias=bd)
+                torch.cuda.synchronize()
+                assert float(o[M:].float().abs().max()) == 0.0, "rows >= M must not be written"
+                o = o[:M].float().cpu()
+            outs.append(o)
+        os.environ.pop("M5_GEMM_SKINNY", None)
+        r = _rel(outs[0], ref)
+        assert r < tol * (2 if epi == L.EPI_SWIGLU else 1), f"M={M} N={N} K={K} epi={epi}: rel err {r}"
+        assert _rel(outs[0], outs[1]) < tol, f"M={M} N={N} K={K} epi={epi}: skinny vs wide-tile kernel"
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_gemm_swiglu_and_qkv(dev, dt):
     from mars5_tts_amd import _lib as L, ops
