@@ -177,6 +177,12 @@ int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream);
 int m5_ar_rope_cache_batch(int dtype, const void* qkv, int B, int n_heads, const float* rope, const int32_t* state,
                            int32_t state_bs, void* qbuf, int64_t q_bs, void* kcache, void* vcache, int64_t cache_bs,
                            int64_t cache_hs, int window, void* stream);
+/*  - m5_ar_qkv_rope_batch: the QKV projection of the batched step with that rotation and the cache write fused
+ *    into its epilogue: xn [B][K] (dtype) x wqkv [3D][K] -> qbuf / caches; qkv_tmp [B][3D] is scratch for the fp32
+ *    (parity mode) path, which runs m5_gemm + m5_ar_rope_cache_batch. */
+int m5_ar_qkv_rope_batch(int dtype, const void* xn, int64_t lda, const void* wqkv, int64_t ldw, int B, int n_heads, int K,
+                         const float* rope, const int32_t* state, int32_t state_bs, void* qbuf, int64_t q_bs,
+                         void* kcache, void* vcache, int64_t cache_bs, int64_t cache_hs, int window, void* qkv_tmp, void* stream);
 int m5_ar_attn_combine_batch(int dtype, const float* part, int64_t part_bs, int B, int n_heads, int nsplit,
                              const int32_t* state, int32_t state_bs, void* out, int64_t out_bs, void* stream);
 

@@ -112,6 +112,8 @@ PROTOTYPES = {
     "m5_ar_attn_decode": (C.c_int, [C.c_int, C.POINTER(AttnDecodeArgs), vp]),
     "m5_ar_sample": (C.c_int, [C.POINTER(SampleArgs), vp]),
     "m5_ar_rope_cache_batch": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, i32, vp, i64, vp, vp, i64, i64, C.c_int, vp]),
+    "m5_ar_qkv_rope_batch": (C.c_int, [C.c_int, vp, i64, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, i32, vp, i64, vp, vp, i64, i64,
+                                        C.c_int, vp, vp]),
     "m5_ar_attn_combine_batch": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, vp, i32, vp, i64, vp]),
     "m5_nar_sample": (C.c_int, [C.POINTER(NarSampleArgs), vp]),
     "m5_add_int": (C.c_int, [vp, i32, vp]),

@@ -264,7 +264,7 @@ class ARBatchSession:
     position, KV cache, cache scan, sampler chain, EOS / max_len, RNG rows -- keeps its own device state,
     so sequence b produces what it would produce alone up to the summation order of the GEMMs.  Prefill
     runs sequence by sequence through ``ARSession.prefill`` on views of the batch arrays.  One captured
-    hipGraph (9 launches per layer + head + sampler) serves every step; finished sequences idle."""
+    hipGraph (8 launches per layer + head + sampler) serves every step; finished sequences idle."""
 
     def __init__(self, model: ARModel, max_lens: List[int], stream: Optional[torch.cuda.Stream] = None):
         self.m = model
@@ -284,7 +284,9 @@ class ARBatchSession:
         self.qbuf = torch.zeros(B, D, dtype=dt, device=dev)
         self.att = torch.zeros(B, D, dtype=dt, device=dev)
         self.hbuf = torch.zeros(B, F, dtype=dt, device=dev)
-        self.part = torch.zeros(B, H, NSPLIT, L.ATTN_PART, dtype=torch.float32, device=dev)
+        # key-range splits of the cache scan: enough workgroups to fill the chip, no more (each costs a partial + merge)
+        self.nsplit = max(1, min(NSPLIT, 1 << max(0, (1024 // (H * B)).bit_length() - 1)))
+        self.part = torch.zeros(B, H, self.nsplit, L.ATTN_PART, dtype=torch.float32, device=dev)
         self.logits = torch.zeros(B, V, dtype=torch.float32, device=dev)
         self.state = torch.zeros(B, L.ST_WORDS, dtype=torch.int32, device=dev)
         self.tokens = torch.zeros(B, max(max_lens) + 1, dtype=torch.int64, device=dev)
@@ -343,15 +345,14 @@ class ARBatchSession:
         cache_bs = s.n_layers * H * cache_hs
         for l in range(s.n_layers):
             ops.rmsnorm(self.x, m.attn_norm[l], s.norm_eps, self.xn, stream=st)
-            ops.gemm(self.xn, m.wqkv[l], self.qkv, L.EPI_DT, stream=st)
-            ops.ar_rope_cache_batch(self.qkv, H, m.rope, self.state, self.qbuf, self.kc[0, l], self.vc[0, l], cache_bs, cache_hs,
-                                    self.window, stream=st)
+            ops.ar_qkv_rope_batch(self.xn, m.wqkv[l], H, m.rope, self.state, self.qbuf, self.kc[0, l], self.vc[0, l], cache_bs, cache_hs,
+                                  self.window, self.qkv, stream=st)
             d = L.AttnDecodeArgs(qbuf=self.qbuf.data_ptr(), kcache=self.kc[0, l].data_ptr(), vcache=self.vc[0, l].data_ptr(),
                                  part=self.part.data_ptr(), state=self.state.data_ptr(), n_heads=H, w_alloc=self.w_alloc,
-                                 window=self.window, nsplit=NSPLIT, scale=64 ** -0.5, batch=B, state_bs=L.ST_WORDS, q_bs=D,
+                                 window=self.window, nsplit=self.nsplit, scale=64 ** -0.5, batch=B, state_bs=L.ST_WORDS, q_bs=D,
                                  cache_bs=cache_bs, part_bs=self.part.stride(0))
             ops.ar_attn_decode(m.dt, d, stream=st)
-            ops.ar_attn_combine_batch(self.part, H, NSPLIT, self.state, self.att, stream=st)
+            ops.ar_attn_combine_batch(self.part, H, self.nsplit, self.state, self.att, stream=st)
             ops.gemm(self.att, m.wo[l], self.x, L.EPI_RESIDUAL, stream=st)
             ops.rmsnorm(self.x, m.ffn_norm[l], s.norm_eps, self.xn, stream=st)
             ops.gemm(self.xn, m.w13[l], self.hbuf, L.EPI_SWIGLU, stream=st)

@@ -48,26 +48,59 @@ __global__ __launch_bounds__(256) void rope_cache_batch_kernel(const typename T:
 
 // out[b][h*64 + d] = sum_s w_s o_s[d] / sum_s w_s l_s, w_s = exp(m_s - max m): the merge the batch-1
 // path does in the Wo GEMV's prologue (ar_decode.hip, M5_PRO_ATTN), sequential over splits.
-template <typename T>
-__global__ __launch_bounds__(256) void attn_combine_batch_kernel(const float* part, int64_t part_bs, int H, int nsplit,
-                                                                 const int32_t* state, int state_bs,
-                                                                 typename T::storage* out, int64_t out_bs) {
-    const int64_t b = blockIdx.x;
+template <typename T, int NS>
+__global__ __launch_bounds__(64) void attn_combine_batch_kernel(const float* part, int64_t part_bs, int H, int nsplit,
+                                                                const int32_t* state, int state_bs,
+                                                                typename T::storage* out, int64_t out_bs) {
+    // grid (H, B), one wave per (sequence, head), lane = d.  NS > 0: nsplit is NS and every partial is loaded before
+    // the first use (the merge itself is a handful of flops; the launch is the round trip of its loads).
+    const int64_t b = blockIdx.y;
+    const int h = blockIdx.x, d = threadIdx.x;
     if (state[b * state_bs + M5_ST_DONE]) return;
-    const float* pb = part + b * part_bs;
-    for (int i = threadIdx.x; i < H * 64; i += 256) {
-        const int h = i >> 6, d = i & 63;
-        const float* pp = pb + (int64_t)h * nsplit * M5_ATTN_PART;
+    const float* pp = part + b * part_bs + (int64_t)h * nsplit * M5_ATTN_PART;
+    float o = 0.f, l = 0.f;
+    if constexpr (NS > 0) {
+        float pm[NS], pl[NS], po[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            pm[s] = pp[s * M5_ATTN_PART + 64];
+            pl[s] = pp[s * M5_ATTN_PART + 65];
+            po[s] = pp[s * M5_ATTN_PART + d];
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, pm[s]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float w = expf(pm[s] - mx);
+            o += w * po[s];
+            l += w * pl[s];
+        }
+    } else {
         float mx = -INFINITY;
         for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, pp[s * M5_ATTN_PART + 64]);
-        float o = 0.f, l = 0.f;
         for (int s = 0; s < nsplit; ++s) {
             const float w = expf(pp[s * M5_ATTN_PART + 64] - mx);
             o += w * pp[s * M5_ATTN_PART + d];
             l += w * pp[s * M5_ATTN_PART + 65];
         }
-        out[b * out_bs + i] = T::from_f32(o / l);
     }
+    out[b * out_bs + h * 64 + d] = T::from_f32(o / l);
+}
+
+template <typename T>
+void launch_combine(const float* part, int64_t part_bs, int B, int H, int nsplit, const int32_t* state, int state_bs, void* out,
+                    int64_t out_bs, hipStream_t s) {
+    using st = typename T::storage;
+#define M5_CMB(NS) hipLaunchKernelGGL((attn_combine_batch_kernel<T, NS>), dim3(H, B), dim3(64), 0, s, part, part_bs, H, nsplit, state, state_bs, (st*)out, out_bs)
+    switch (nsplit) {
+        case 8: M5_CMB(8); break;
+        case 4: M5_CMB(4); break;
+        case 2: M5_CMB(2); break;
+        case 1: M5_CMB(1); break;
+        default: M5_CMB(0); break;
+    }
+#undef M5_CMB
 }
 
 }  // namespace
@@ -92,9 +125,9 @@ extern "C" int m5_ar_attn_combine_batch(int dtype, const float* part, int64_t pa
     if (!part || !state || !out || B <= 0 || n_heads <= 0 || nsplit <= 0) return M5_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
-        case M5_F32: hipLaunchKernelGGL(attn_combine_batch_kernel<F32T>, dim3(B), dim3(256), 0, s, part, part_bs, n_heads, nsplit, state, state_bs, (float*)out, out_bs); break;
-        case M5_F16: hipLaunchKernelGGL(attn_combine_batch_kernel<F16T>, dim3(B), dim3(256), 0, s, part, part_bs, n_heads, nsplit, state, state_bs, (_Float16*)out, out_bs); break;
-        case M5_BF16: hipLaunchKernelGGL(attn_combine_batch_kernel<BF16T>, dim3(B), dim3(256), 0, s, part, part_bs, n_heads, nsplit, state, state_bs, (uint16_t*)out, out_bs); break;
+        case M5_F32: launch_combine<F32T>(part, part_bs, B, n_heads, nsplit, state, state_bs, out, out_bs, s); break;
+        case M5_F16: launch_combine<F16T>(part, part_bs, B, n_heads, nsplit, state, state_bs, out, out_bs, s); break;
+        case M5_BF16: launch_combine<BF16T>(part, part_bs, B, n_heads, nsplit, state, state_bs, out, out_bs, s); break;
         default: return M5_ERR_ARG;
     }
     M5_CHECK_LAUNCH();

@@ -5,9 +5,9 @@
 // step, now shared by all B sequences), so the kernel is a weight STREAMER that happens to use
 // MFMA for the dot products:
 //   * one workgroup per 16 weight rows, its 8 waves split K; a wave issues its WHOLE weight share
-//     (<= 16 non-temporal 16-byte loads per lane, straight into MFMA operand layout: lane = (row
+//     (<= 14 16-byte loads per lane, straight into MFMA operand layout: lane = (row
 //     l & 15, k-chunk l >> 4)) before anything else, then the matching activation fragments (L2
-//     hits), then runs its <= 16 x MT MFMAs -- no LDS staging, nothing between HBM and the matrix
+//     hits), then runs its <= 14 x MT MFMAs -- no LDS staging, nothing between HBM and the matrix
 //     core but registers;
 //   * the 8 K-partials are summed through LDS in a fixed order (deterministic), and the epilogue
 //     (bias / dtype / fp32 / residual add / SwiGLU on interleaved rows) runs on the reduced tile.
@@ -41,12 +41,19 @@ struct SkinnyParams {
     const unsigned char* A; const unsigned char* W; const float* bias; unsigned char* C;
     int64_t lda, ldw, ldc;      // elements
     int M, N, K;
+    // SK_EPI_QKV_ROPE (batched decode QKV projection): rotate q, k at each sequence's own position and write
+    // q -> qbuf + m*q_bs, k / v -> cache + m*cache_bs + h*cache_hs + slot*64 (slot = pos % window)
+    const float* rope; const int32_t* state; int state_bs;
+    unsigned char* qbuf; unsigned char* kcache; unsigned char* vcache;
+    int64_t q_bs, cache_bs, cache_hs;
+    int dim, window;
 };
+constexpr int SK_EPI_QKV_ROPE = 100;
 
 constexpr int SK_NW = 8;        // waves per workgroup (K split)
-constexpr int SK_KSW = 16;      // 32-deep K steps per wave, at most  ->  K <= 4096
+constexpr int SK_KSW = 14;      // 32-deep K steps per wave, at most  ->  K <= 3584 (<= 128 VGPRs at MT = 1: two workgroups per CU)
 
-template <typename T, int EPI, int MT>
+template <typename T, int EPI, int MT, bool NT>
 __global__ __launch_bounds__(SK_NW * 64) void skinny_gemm_kernel(SkinnyParams p) {
     using st = typename T::storage;
     __shared__ f4_t red[SK_NW][MT][64];
@@ -64,7 +71,10 @@ __global__ __launch_bounds__(SK_NW * 64) void skinny_gemm_kernel(SkinnyParams p)
     u32x4 wf[SK_KSW];
 #pragma unroll
     for (int s = 0; s < SK_KSW; ++s)
-        if (s < nst) wf[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + s * 64));
+        if (s < nst) {
+            if constexpr (NT) wf[s] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + s * 64));
+            else wf[s] = *reinterpret_cast<const u32x4*>(wp + s * 64);
+        }
     uint4 xf[MT][SK_KSW];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -89,7 +99,37 @@ __global__ __launch_bounds__(SK_NW * 64) void skinny_gemm_kernel(SkinnyParams p)
     for (int mt = 0; mt < MT; ++mt) red[wave][mt][lane] = acc[mt];
     __syncthreads();
 
-    if constexpr (EPI == M5_EPI_SWIGLU) {
+    if constexpr (EPI == SK_EPI_QKV_ROPE) {
+        // thread = (sequence m, pair pi): columns n0 + 2 pi, + 1 are one RoPE pair of one head of q, k or v.
+        // The sums are rounded to the operand type first, then rotated -- the arithmetic of EPI_DT followed by
+        // rope_cache_kernel (prefill) / rope_cache_batch_kernel.
+        const int pi = tid & 7, m = tid >> 3;
+        if (m < MT * 16 && m < p.M && !p.state[(int64_t)m * p.state_bs + M5_ST_DONE]) {
+            float v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int n = 2 * pi + h;
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < SK_NW; ++w) s += red[w][m >> 4][(n >> 2) * 16 + (m & 15)][n & 3];
+                v[h] = round_dt<T>(s + (p.bias ? p.bias[n0 + n] : 0.f));
+            }
+            const int sec = n0 / p.dim, c = (n0 - sec * p.dim) + 2 * pi, hd = c >> 6, d = c & 63;
+            const int pos = p.state[(int64_t)m * p.state_bs + M5_ST_POS];
+            const int slot = pos % p.window;
+            st* dst;
+            if (sec == 0) dst = reinterpret_cast<st*>(p.qbuf) + (int64_t)m * p.q_bs + c;
+            else dst = reinterpret_cast<st*>(sec == 1 ? p.kcache : p.vcache) + (int64_t)m * p.cache_bs + hd * p.cache_hs + (int64_t)slot * 64 + d;
+            if (sec < 2) {
+                const float cs = p.rope[((int64_t)pos * 32 + (d >> 1)) * 2], sn = p.rope[((int64_t)pos * 32 + (d >> 1)) * 2 + 1];
+                dst[0] = T::from_f32(v[0] * cs - v[1] * sn);
+                dst[1] = T::from_f32(v[0] * sn + v[1] * cs);
+            } else {
+                dst[0] = T::from_f32(v[0]);
+                dst[1] = T::from_f32(v[1]);
+            }
+        }
+    } else if constexpr (EPI == M5_EPI_SWIGLU) {
         // rows of W interleaved (W_i, V_i): n = 2 pi is the gate, n = 2 pi + 1 the value
         const int pi = tid & 7, m = tid >> 3;
         if (m < MT * 16 && m < p.M) {
@@ -125,18 +165,30 @@ __global__ __launch_bounds__(SK_NW * 64) void skinny_gemm_kernel(SkinnyParams p)
     }
 }
 
-template <typename T, int MT>
+template <typename T, int MT, bool NT>
 int launch_skinny(int epi, const SkinnyParams& p, hipStream_t s) {
     dim3 grid(p.N / 16), block(SK_NW * 64);
     switch (epi) {
-        case M5_EPI_F32: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_F32, MT>), grid, block, 0, s, p); break;
-        case M5_EPI_DT: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_DT, MT>), grid, block, 0, s, p); break;
-        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_RESIDUAL, MT>), grid, block, 0, s, p); break;
-        case M5_EPI_SWIGLU: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_SWIGLU, MT>), grid, block, 0, s, p); break;
+        case M5_EPI_F32: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_F32, MT, NT>), grid, block, 0, s, p); break;
+        case M5_EPI_DT: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_DT, MT, NT>), grid, block, 0, s, p); break;
+        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_RESIDUAL, MT, NT>), grid, block, 0, s, p); break;
+        case M5_EPI_SWIGLU: hipLaunchKernelGGL((skinny_gemm_kernel<T, M5_EPI_SWIGLU, MT, NT>), grid, block, 0, s, p); break;
+        case SK_EPI_QKV_ROPE: hipLaunchKernelGGL((skinny_gemm_kernel<T, SK_EPI_QKV_ROPE, MT, NT>), grid, block, 0, s, p); break;
         default: return M5_ERR_UNSUPPORTED;
     }
     M5_CHECK_LAUNCH();
     return M5_OK;
+}
+
+template <typename T>
+int launch_skinny_mt(int epi, const SkinnyParams& p, hipStream_t s) {
+    // Non-temporal loads lose ~4 % here (measured, tools/ar_batch_bench.py): a wave instruction covers 64 bytes of
+    // each of its 16 rows, so the two halves of a 128-byte line are fetched by consecutive instructions and the
+    // line should stay in L2 in between.  M5_SKINNY_NT=1 re-enables them for A/B runs.
+    const char* e = getenv("M5_SKINNY_NT");
+    const bool nt = (e && e[0] == '1');
+    if (p.M <= 16) return nt ? launch_skinny<T, 1, true>(epi, p, s) : launch_skinny<T, 1, false>(epi, p, s);
+    return nt ? launch_skinny<T, 2, true>(epi, p, s) : launch_skinny<T, 2, false>(epi, p, s);
 }
 
 }  // namespace
@@ -153,7 +205,33 @@ bool m5_gemm_skinny_fits(int dtype, int M, int N, int K, int epi, int batch, int
 
 int m5_gemm_skinny_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                             void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s) {
-    SkinnyParams p{(const unsigned char*)A, (const unsigned char*)W, bias, (unsigned char*)C, lda, ldw, ldc, M, N, K};
-    if (dtype == M5_F16) return M <= 16 ? launch_skinny<F16T, 1>(epi, p, s) : launch_skinny<F16T, 2>(epi, p, s);
-    return M <= 16 ? launch_skinny<BF16T, 1>(epi, p, s) : launch_skinny<BF16T, 2>(epi, p, s);
+    SkinnyParams p{};
+    p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
+    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    if (dtype == M5_F16) return launch_skinny_mt<F16T>(epi, p, s);
+    return launch_skinny_mt<BF16T>(epi, p, s);
+}
+
+// Batched decode QKV projection with fused RoPE + KV-cache write (include/mars5_hip.h).  16-bit operands run the
+// skinny kernel with the rotation in its epilogue; fp32 (parity mode) runs m5_gemm into `qkv_tmp` followed by
+// m5_ar_rope_cache_batch -- the same arithmetic in two launches.
+extern "C" int m5_ar_qkv_rope_batch(int dtype, const void* xn, int64_t lda, const void* wqkv, int64_t ldw, int B, int n_heads, int K,
+                                    const float* rope, const int32_t* state, int32_t state_bs, void* qbuf, int64_t q_bs,
+                                    void* kcache, void* vcache, int64_t cache_bs, int64_t cache_hs, int window, void* qkv_tmp,
+                                    void* stream) {
+    if (!xn || !wqkv || !rope || !state || !qbuf || !kcache || !vcache || B <= 0 || n_heads <= 0 || K <= 0 || window <= 0) return M5_ERR_ARG;
+    const int D = n_heads * 64, N = 3 * D;
+    if (m5_gemm_skinny_fits(dtype, B, N, K, M5_EPI_DT, 1, lda, ldw) && !(((uintptr_t)xn | (uintptr_t)wqkv) & 15)) {
+        SkinnyParams p{};
+        p.A = (const unsigned char*)xn; p.W = (const unsigned char*)wqkv; p.lda = lda; p.ldw = ldw; p.M = B; p.N = N; p.K = K;
+        p.rope = rope; p.state = state; p.state_bs = state_bs; p.qbuf = (unsigned char*)qbuf; p.kcache = (unsigned char*)kcache;
+        p.vcache = (unsigned char*)vcache; p.q_bs = q_bs; p.cache_bs = cache_bs; p.cache_hs = cache_hs; p.dim = D; p.window = window;
+        if (dtype == M5_F16) return launch_skinny_mt<F16T>(SK_EPI_QKV_ROPE, p, (hipStream_t)stream);
+        return launch_skinny_mt<BF16T>(SK_EPI_QKV_ROPE, p, (hipStream_t)stream);
+    }
+    if (!qkv_tmp) return M5_ERR_ARG;
+    const int st = m5_gemm(dtype, xn, lda, wqkv, ldw, nullptr, qkv_tmp, N, B, N, K, M5_EPI_DT, nullptr, 1, 0, 0, 0, 0, stream);
+    if (st != M5_OK) return st;
+    return m5_ar_rope_cache_batch(dtype, qkv_tmp, B, n_heads, rope, state, state_bs, qbuf, q_bs, kcache, vcache, cache_bs, cache_hs,
+                                  window, stream);
 }

@@ -121,8 +121,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
     float v[MAXI];
     float s = 0.f;
 #pragma unroll
+    for (int i = 0; i < MAXI; ++i) v[i] = xr[min(lane + 64 * i, D - 1)];     // all loads in flight before the first use
+#pragma unroll
     for (int i = 0; i < MAXI; ++i)
-        if (i < ni) { v[i] = xr[lane + 64 * i]; s += v[i] * v[i]; }
+        if (i < ni) s += v[i] * v[i];
     const float rstd = rsqrtf(wave_sum(s) / (float)D + eps);
     typename T::storage* yr = y + (int64_t)row * ldy;
 #pragma unroll
@@ -132,6 +134,61 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, int64_t ld
             const float n = v[i] * rstd;          // (x * rsqrt(...)).type_as(x)
             yr[c] = T::from_f32(n * w[c]);        // ... * weight, then cast to the GEMM dtype
         }
+}
+
+// Vector form (D = 256 NV): NV 16-byte loads per lane issued back to back, 8-byte stores of the 16-bit output.
+// Same arithmetic and summation order per lane as the scalar kernel up to the order of the per-lane partial sums.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rmsnorm_vec_kernel(const float* x, int64_t ldx, const float* w, float eps,
+                                                          typename T::storage* y, int64_t ldy, int M) {
+    using st = typename T::storage;
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * ldx;
+    float4 v[NV], g[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) g[i] = *reinterpret_cast<const float4*>(w + (lane + 64 * i) * 4);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    const float rstd = rsqrtf(wave_sum(s) / (float)D + eps);
+    st* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        const float o[4] = {(v[i].x * rstd) * g[i].x, (v[i].y * rstd) * g[i].y, (v[i].z * rstd) * g[i].z, (v[i].w * rstd) * g[i].w};
+        if constexpr (sizeof(st) == 4) {
+            *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            st t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = T::from_f32(o[e]);
+            *reinterpret_cast<uint2*>(yr + c) = *reinterpret_cast<const uint2*>(t);
+        }
+    }
+}
+
+template <typename T>
+bool launch_rms_vec(const float* x, int64_t ldx, const float* w, float eps, void* y, int64_t ldy, int M, int D, hipStream_t s) {
+    using st = typename T::storage;
+    const int es = sizeof(st);
+    if (D % 256 || (ldx % 4) || (ldy * es % (es == 4 ? 16 : 8)) || (((uintptr_t)x | (uintptr_t)w) & 15) || ((uintptr_t)y & (es == 4 ? 15 : 7)))
+        return false;
+    dim3 grid((M + 3) / 4);
+#define M5_RMV(NV) hipLaunchKernelGGL((rmsnorm_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, w, eps, (st*)y, ldy, M)
+    switch (D / 256) {
+        case 1: M5_RMV(1); break;
+        case 2: M5_RMV(2); break;
+        case 4: M5_RMV(4); break;
+        case 6: M5_RMV(6); break;
+        case 8: M5_RMV(8); break;
+        default: return false;
+    }
+#undef M5_RMV
+    return true;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(float* out, int64_t ldo, int R, int D, const float* table,
@@ -246,6 +303,13 @@ extern "C" int m5_rmsnorm(int out_dtype, const float* x, int64_t ldx, const floa
     if (D % 64 || D > 64 * MAXI) return M5_ERR_UNSUPPORTED;
     dim3 grid((M + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
+    {
+        bool done = false;
+        if (out_dtype == M5_F32) done = launch_rms_vec<F32T>(x, ldx, w, eps, y, ldy, M, D, s);
+        else if (out_dtype == M5_F16) done = launch_rms_vec<F16T>(x, ldx, w, eps, y, ldy, M, D, s);
+        else if (out_dtype == M5_BF16) done = launch_rms_vec<BF16T>(x, ldx, w, eps, y, ldy, M, D, s);
+        if (done) { M5_CHECK_LAUNCH(); return M5_OK; }
+    }
     switch (out_dtype) {
         case M5_F32: hipLaunchKernelGGL(rmsnorm_kernel<F32T>, grid, dim3(256), 0, s, x, ldx, w, eps, (float*)y, ldy, M, D); break;
         case M5_F16: hipLaunchKernelGGL(rmsnorm_kernel<F16T>, grid, dim3(256), 0, s, x, ldx, w, eps, (_Float16*)y, ldy, M, D); break;

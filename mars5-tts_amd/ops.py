@@ -114,6 +114,15 @@ def ar_rope_cache_batch(qkv: torch.Tensor, n_heads: int, rope: torch.Tensor, sta
           "m5_ar_rope_cache_batch")
 
 
+def ar_qkv_rope_batch(xn: torch.Tensor, wqkv: torch.Tensor, n_heads: int, rope: torch.Tensor, state: torch.Tensor, qbuf: torch.Tensor,
+                      kcache: torch.Tensor, vcache: torch.Tensor, cache_bs: int, cache_hs: int, window: int, qkv_tmp: torch.Tensor,
+                      stream: Optional[int] = None) -> None:
+    """Batched decode QKV projection + RoPE + cache write: xn (B, K) dtype, wqkv (3D, K)."""
+    check(lib.m5_ar_qkv_rope_batch(DT_CODE[xn.dtype], _p(xn), xn.stride(0), _p(wqkv), wqkv.stride(0), xn.shape[0], n_heads, xn.shape[1],
+                                   _p(rope), _p(state), state.stride(0), _p(qbuf), qbuf.stride(0), _p(kcache), _p(vcache), cache_bs,
+                                   cache_hs, window, _p(qkv_tmp), _s(stream)), "m5_ar_qkv_rope_batch")
+
+
 def ar_attn_combine_batch(part: torch.Tensor, n_heads: int, nsplit: int, state: torch.Tensor, out: torch.Tensor,
                           stream: Optional[int] = None) -> None:
     """part (B, H, nsplit, ATTN_PART) fp32 -> out (B, D) dtype."""

@@ -390,6 +390,53 @@ def test_attn_decode_and_combine(dev, dt, pos, W, window):
     assert r < max(TOL[dt], 5e-3 if dt != torch.float32 else 1e-5), f"decode attention rel err {r}"
 
 
+@pytest.mark.parametrize("dt", DTS)
+def test_ar_qkv_rope_batch(dev, dt):
+    """Batched decode QKV projection with fused RoPE + cache write (16-bit: skinny-GEMM epilogue; fp32: GEMM +
+    rope kernel) vs torch: every sequence rotates at ITS position and writes ITS cache slot (pos % window,
+    wrapped for one of them); a finished sequence writes nothing."""
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.tables import rope_table
+    B, H, K, W, window = 5, 24, 1536, 128, 100
+    D = H * 64
+    nL = 2                                          # cache layout [B][layers][H][W][64]; layer 1 is the one written
+    xn = _q(_rand((B, K), 1), dt)
+    w = _q(_rand((3 * D, K), 2, 4.0 / math.sqrt(K)), dt)
+    pos = [0, 37, 99, 250, 64]
+    done = [0, 0, 0, 0, 1]
+    rope = rope_table(64, 512)
+    qkv = _q(xn @ w.T, dt).view(B, 3, H, 32, 2)
+    cs, sn = rope[pos, :, 0], rope[pos, :, 1]        # (B, 32)
+    def rot(t):
+        a, b = t[..., 0], t[..., 1]
+        return torch.stack([a * cs[:, None, :] - b * sn[:, None, :], a * sn[:, None, :] + b * cs[:, None, :]], -1).reshape(B, H, 64)
+    q_ref, k_ref, v_ref = rot(qkv[:, 0]), rot(qkv[:, 1]), qkv[:, 2].reshape(B, H, 64)
+    state = torch.zeros(B, L.ST_WORDS, dtype=torch.int32)
+    state[:, L.ST_POS] = torch.tensor(pos, dtype=torch.int32)
+    state[:, L.ST_DONE] = torch.tensor(done, dtype=torch.int32)
+    state = state.to(dev)
+    qbuf = torch.full((B, D), 7.0, device=dev, dtype=dt)
+    kc = torch.full((B, nL, H, W, 64), 7.0, device=dev, dtype=dt)
+    vc = torch.full((B, nL, H, W, 64), 7.0, device=dev, dtype=dt)
+    tmp = torch.zeros(B, 3 * D, device=dev, dtype=dt)
+    ops.ar_qkv_rope_batch(xn.to(dev, dt), w.to(dev, dt), H, rope.to(dev), state, qbuf, kc[0, 1], vc[0, 1], nL * H * W * 64, W * 64, window, tmp)
+    torch.cuda.synchronize()
+    tol = max(TOL[dt], 1e-2 if dt != torch.float32 else 0)
+    scale = float(q_ref.abs().max())
+    for b in range(B):
+        slot = pos[b] % window
+        if done[b]:
+            assert float((qbuf[b].float() - 7.0).abs().max()) == 0.0 and float((kc[b].float() - 7.0).abs().max()) == 0.0
+            continue
+        assert float((qbuf[b].float().cpu().view(H, 64) - q_ref[b]).abs().max()) / scale < tol
+        assert float((kc[b, 1, :, slot].float().cpu() - k_ref[b]).abs().max()) / scale < tol
+        assert float((vc[b, 1, :, slot].float().cpu() - v_ref[b]).abs().max()) / scale < tol
+        untouched = torch.ones(W, dtype=torch.bool)
+        untouched[slot] = False
+        assert float((kc[b, 1][:, untouched].float() - 7.0).abs().max()) == 0.0 and float((kc[b, 0].float() - 7.0).abs().max()) == 0.0
+        assert float((vc[b, 1][:, untouched].float() - 7.0).abs().max()) == 0.0
+
+
 def test_ar_sampler_golden_cases(dev, gold_dir):
     """Device sampler chain vs the reference function chain (fixtures from the reference)."""
     import mars5_oracle as O
