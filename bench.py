@@ -43,7 +43,93 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2 (default): BASELINE configs[1], one utterance per step.  c3: configs[2], one step = a batch of "
+                         "--batch mixed-length requests through tts_batch_from_codes")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--ar-batch", type=int, default=32)
+    ap.add_argument("--nar-batch", type=int, default=8)
     return ap.parse_args()
+
+
+WORDS = ("the quick brown rat jumped over lazy dogs twice while seven silver foxes watched from behind a quiet river bank and "
+         "nobody in town could say why this year demand was never met").split()
+
+
+def c3_requests(m, n: int, n_gen: int, seed: int = 11):
+    """`n` requests, reference length uniform in [2 s, 12 s] (150-900 frames), text and
+    transcript of 10-60 tokens together, output length forced to n_gen frames per request."""
+    from mars5_tts_amd import synth
+    g = torch.Generator().manual_seed(seed)
+    texts, trs, refs, max_lens = [], [], [], []
+    for i in range(n):
+        frames = int(torch.randint(150, 901, (1,), generator=g))
+        nw = int(torch.randint(3, 16, (1,), generator=g))
+        w0 = int(torch.randint(0, len(WORDS), (1,), generator=g))
+        words = [WORDS[(w0 + j) % len(WORDS)] for j in range(2 * nw)]
+        texts.append(" ".join(words[:nw]).capitalize() + ".")
+        trs.append(" ".join(words[nw:]).capitalize() + ".")
+        ref = synth.make_ref_codes(frames, seed=100 + i)
+        refs.append(ref)
+        tt = m.texttok.encode("<|startoftext|>" + trs[-1] + ' ' + texts[-1].strip() + "<|endoftext|>", allowed_special='all')
+        st = m.speechtok.encode(' '.join(str(t) for t in ref[0, 0].tolist()))
+        max_lens.append(len(tt) + len(st) + n_gen)
+    return texts, trs, refs, max_lens
+
+
+def main_c3(args, m, dev, world, rank, barrier):
+    """One step = `--batch` mixed-length requests: AR decoded --ar-batch at a time (weights read once per step for
+    all of them), NAR refined --nar-batch at a time.  value = generated audio seconds / wall second."""
+    from inference import InferenceConfig
+    from mars5_tts_amd import ar_engine, nar_engine
+    texts, trs, refs, max_lens = c3_requests(m, args.batch, args.n_gen, seed=11 + rank)
+    refs = [r.to(dev) for r in refs]
+    cfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
+                          eos_estimated_gen_length_factor=100.0, eos_penalty_factor=50.0, eos_penalty_decay=0.5)
+
+    def step(i):
+        t0 = time.perf_counter()
+        out = m.tts_batch_from_codes(texts, refs, trs, cfg, seeds=[1000 + rank * 10007 + i * args.batch + j for j in range(args.batch)],
+                                     nar_batch=args.nar_batch, ar_batch=args.ar_batch, max_lens=max_lens)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, sum(int(f.shape[0]) for _, f in out)
+
+    for i in range(args.warmup):
+        step(-1 - i)
+    barrier()
+    t0 = time.perf_counter()
+    lat, frames = [], 0
+    for i in range(args.steps):
+        dt, nf = step(i)
+        lat.append(dt)
+        frames += nf
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, frames = float(tmax[0]), float(t[1])
+    if rank != 0:
+        return
+    ref_frames = [int(r.shape[-1]) for r in refs]
+    out = {
+        "metric": "generated audio seconds/sec (RTF), deep-clone", "value": round(frames / 75.0 / elapsed, 4), "unit": "audio_s/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "p50_batch_latency_s": round(statistics.median(lat), 3),
+        "config": {"workload": f"BASELINE configs[2]: batch of {args.batch} mixed-length requests per GPU, deep-clone, temperature=0.7 "
+                               f"top_k=100, reference 150-900 frames (2-12 s), text+transcript 10-60 tokens, {args.n_gen} generated frames "
+                               "each, 200 DDPM steps x CFG, seeded random weights of the real geometry",
+                   "requests_per_step": args.batch, "ar_batch": args.ar_batch, "nar_batch": args.nar_batch,
+                   "reference_frames_min_mean_max": [min(ref_frames), round(sum(ref_frames) / len(ref_frames), 1), max(ref_frames)],
+                   "parallelism": f"replicas x{world} (requests sharded by rank, no data-path collective)"},
+        "last_ar_batch": {k: ar_engine.LAST_STATS.get(k) for k in ("decode_ms", "decode_steps_launched", "batch")},
+        "last_nar_batch": {k: nar_engine.LAST_STATS.get(k) for k in ("loop_ms", "steps", "batch", "rows")},
+    }
+    print(json.dumps(out), flush=True)
 
 
 def build_model(dtype_name: str, dev):
@@ -242,13 +328,19 @@ def main():
         ae.ARSession.decode = lambda self, use_graph=True, poll=32: _d(self, False, poll)
         ne.NARSession.run = lambda self, uniform, use_graph=True, n_steps=None: _r(self, uniform, False, n_steps)
 
-    for i in range(args.warmup):
-        run_utterance(m, ref_codes, cfg, 500 + i)
-
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.workload == "c3":
+        main_c3(args, m, dev, world, rank, barrier)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    for i in range(args.warmup):
+        run_utterance(m, ref_codes, cfg, 500 + i)
 
     barrier()
     t0 = time.perf_counter()

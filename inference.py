@@ -7,6 +7,7 @@ audio-in / audio-out methods, and injectable for hosts where they are not instal
 """
 from __future__ import annotations
 
+import dataclasses
 import io
 import logging
 from dataclasses import dataclass
@@ -202,7 +203,7 @@ class Mars5TTS:
     @torch.inference_mode()
     def tts_batch_from_codes(self, texts: List[str], prompt_codecs: List[Tensor], ref_transcripts: List[Optional[str]],
                              cfg: InferenceConfig = InferenceConfig(), seeds: Optional[List[int]] = None,
-                             nar_batch: int = 8, ar_batch: int = 1) -> List[Tuple[Tensor, Tensor]]:
+                             nar_batch: int = 8, ar_batch: int = 1, max_lens: Optional[List[int]] = None) -> List[Tuple[Tensor, Tensor]]:
         """Several independent requests on one GPU (BASELINE config 3).  Request i gets a private
         device generator seeded ``seeds[i]`` and consumes it as a lone call would.
         NAR: up to `nar_batch` requests of similar length are refined per decoder pass
@@ -219,8 +220,11 @@ class Mars5TTS:
             g = torch.Generator(device=self.device)
             g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.seed()))
             gens.append(g)
+        def cfg_of(i):
+            return cfg if max_lens is None else dataclasses.replace(cfg, generate_max_len_override=int(max_lens[i]))
+
         if ar_batch <= 1:
-            staged = [self._ar_stage(texts[i], prompt_codecs[i], ref_transcripts[i], cfg, None, gens[i]) for i in range(n)]
+            staged = [self._ar_stage(texts[i], prompt_codecs[i], ref_transcripts[i], cfg_of(i), None, gens[i]) for i in range(n)]
         else:
             assert cfg.beam_width == 1, "Only beam size of 1 is currently supported."
             prs = [self._prompt(texts[i], prompt_codecs[i], ref_transcripts[i], cfg) for i in range(n)]
@@ -228,10 +232,11 @@ class Mars5TTS:
             order = sorted(range(n), key=lambda i: prs[i]["prompt"].shape[0])
             for g0 in range(0, n, min(ar_batch, 32)):
                 grp = order[g0:g0 + min(ar_batch, 32)]
+                kw = self._ar_kwargs(cfg)
+                kw["max_len"] = [self._ar_kwargs(cfg_of(i))["max_len"] for i in grp]
                 outs = ar_generate_batch(self.texttok, self.speechtok, self.codeclm, [prs[i]["prompt"] for i in grp],
                                          [prs[i]["spk_ref_codec"] for i in grp], [prs[i]["first_codec_idx"] for i in grp],
-                                         n_phones_gens=[prs[i]["n_phones_gen"] for i in grp], generators=[gens[i] for i in grp],
-                                         **self._ar_kwargs(cfg))
+                                         n_phones_gens=[prs[i]["n_phones_gen"] for i in grp], generators=[gens[i] for i in grp], **kw)
                 for i, o in zip(grp, outs):
                     staged[i] = self._handoff(prs[i], o, cfg)
         T = self.default_T

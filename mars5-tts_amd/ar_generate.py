@@ -3,7 +3,7 @@ and error behaviour; the token loop runs on the MI355X engine (``ar_engine``).""
 from __future__ import annotations
 
 import logging
-from typing import List, Optional
+from typing import List, Optional, Union
 
 import torch
 from torch import Tensor
@@ -79,15 +79,18 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
 
 @torch.inference_mode()
 def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: List[Tensor], first_codex_idxs: List[int],
-                      max_len: int = 1500, temperature: float = 1.0, topk: int = None, top_p=1.0, alpha_frequency=0,
+                      max_len: Union[int, List[int]] = 1500, temperature: float = 1.0, topk: int = None, top_p=1.0, alpha_frequency=0,
                       alpha_presence=0, penalty_window=100, typical_p=1.0, eos_penalty_factor=1.0, eos_penalty_decay=0,
                       n_phones_gens: Optional[List[Optional[int]]] = None, generators: Optional[List[Optional[torch.Generator]]] = None,
                       noises: Optional[List[Tensor]] = None, use_graph: bool = True, div_mode: int = 0) -> List[Tensor]:
     """``ar_generate`` for B <= 32 independent requests decoded together (BASELINE config 3): request i
     completes prompt ``xxs[i]`` with speaker reference ``ss_gens[i]`` exactly as a lone call would, drawing
     its Exp(1) noise from ``generators[i]`` (or ``noises[i]``, (n_steps, V)); the decode step reads the
-    weights once for all requests.  Returns the B full sequences (prompt + generated, EOS not appended)."""
+    weights once for all requests.  `max_len` may be a list (one cap per request).
+    Returns the B full sequences (prompt + generated, EOS not appended)."""
     B = len(xxs)
+    max_lens = [int(max_len)] * B if not isinstance(max_len, (list, tuple)) else [int(v) for v in max_len]
+    assert len(max_lens) == B
     assert len(ss_gens) == B and len(first_codex_idxs) == B
     eng = codeclm.engine()
     dev = eng.dev
@@ -96,15 +99,15 @@ def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: L
     assert n_vocab == eng.shape.n_vocab, (n_vocab, eng.shape.n_vocab)
     eos_idx = n_text + speechtok.special_tokens['<|endofspeech|>']
     Ps = [int(x.shape[-1]) for x in xxs]
-    for x, P in zip(xxs, Ps):
-        assert x.dim() == 1 and P < max_len, "every request needs room to generate (a lone call just returns the prompt)"
-    sess = ARBatchSession(eng, [max_len] * B)
-    n_steps = max(max_len - P for P in Ps)
+    for x, P, ml in zip(xxs, Ps, max_lens):
+        assert x.dim() == 1 and P < ml, "every request needs room to generate (a lone call just returns the prompt)"
+    sess = ARBatchSession(eng, max_lens)
+    n_steps = max(ml - P for ml, P in zip(max_lens, Ps))
     gens, offs, pers = [], [], []
     with torch.cuda.stream(sess.stream):
         noise_d = torch.ones(B, n_steps, n_vocab, dtype=torch.float32, device=dev)
         for b in range(B):
-            nb = max_len - Ps[b]
+            nb = max_lens[b] - Ps[b]
             if noises is not None:
                 noise_d[b, :nb] = noises[b].to(device=dev, dtype=torch.float32)[:nb]
                 gens.append(None)
