@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
                     help="c2 (default): BASELINE configs[1], one utterance per step.  c3: configs[2], one step = a batch of "
-                         "--batch mixed-length requests through tts_batch_from_codes")
+                         "--batch mixed-length requests through tts_batch_from_codes.  c5: configs[4], one long-form utterance "
+                         "per step (60 s = 4500 generated frames: the AR context passes the 3000-slot rotating KV window)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ar-batch", type=int, default=32)
     ap.add_argument("--nar-batch", type=int, default=8)
@@ -252,7 +253,9 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     ae = m.codeclm.engine()
     es = 2 if dtype_name != "f32" else 4
     kv_per_pos = ae.shape.n_layers * ae.shape.nhead * 64 * 2 * es
-    avg_len = (ars["prefill_len"] + ars["final_len"]) / 2.0
+    W = ae.shape.sliding_window                 # cached positions actually read per step: min(length, window)
+    lens = range(int(ars["prefill_len"]), int(ars["final_len"]) + 1)
+    avg_len = sum(min(t, W) for t in lens) / max(len(lens), 1)
     bytes_tok = ae.weight_bytes_per_token() + kv_per_pos * (avg_len + 1)
     tok_ms = ars["decode_ms"] / max(ars["n_generated"] - 1, 1)
     gbs = bytes_tok / tok_ms / 1e6
@@ -317,6 +320,16 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
     from mars5_tts_amd import synth
+    global TEXT
+    workload_name = ("BASELINE configs[1]: single utterance deep-clone, temperature=0.7 top_k=100, 6 s / 450-frame synthetic "
+                     "reference, ~20-token text + transcript, 450 generated frames, 200 DDPM steps x CFG, seeded random weights "
+                     "(AR 1536d x 26L n_vocab 4096, NAR 1024d 8+16L)")
+    if args.workload == "c5":
+        args.n_gen = 4500
+        TEXT = " ".join(WORDS[(7 * i) % len(WORDS)] for i in range(150)).capitalize() + "."
+        workload_name = ("BASELINE configs[4]: long-form single utterance deep-clone, 60 s target (4500 generated frames, ~150-word "
+                         "text), 6 s / 450-frame synthetic reference, temperature=0.7 top_k=100, hipGraph AR decode step over the "
+                         "3000-slot rotating KV window, 200 DDPM steps x CFG at S = 5399, seeded random weights of the real geometry")
     m, bundle = build_model(args.dtype, dev)
     ref_codes = synth.make_ref_codes(args.ref_frames, seed=7).to(dev)
     p_len, n_text_tok = prompt_len(m, ref_codes)
@@ -370,9 +383,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "p50_latency_s": round(statistics.median(lat), 4),
-        "config": {"workload": "BASELINE configs[1]: single utterance deep-clone, temperature=0.7 top_k=100, 6 s / 450-frame synthetic "
-                               "reference, ~20-token text + transcript, 450 generated frames, 200 DDPM steps x CFG, seeded random weights "
-                               "(AR 1536d x 26L n_vocab 4096, NAR 1024d 8+16L)",
+        "config": {"workload": workload_name,
                    "ar_prompt_tokens": p_len, "generated_frames_per_utterance": frames / (args.steps * world),
                    "parallelism": f"replicas x{world} (one utterance stream per GPU, no data-path collective)",
                    "hipgraph": not args.no_graph},
