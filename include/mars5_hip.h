@@ -249,6 +249,11 @@ int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int 
  * buf[0] per launch) on `stream` -- measures the per-launch floor, eager vs hipGraph.  tools/launch_floor.py. */
 int m5_debug_launch_chain(int32_t* buf, int n, int blocks, int threads, int touch, void* stream);
 
+/* Diagnostics: ONE launch of `blocks` co-resident workgroups that cross `iters` device-wide barriers (agent-scope
+ * atomic arrive + bounded acquire spin; mode 1 also passes one word per workgroup across each barrier).
+ * scratch: blocks + 4 words; after the run scratch[1] = spin timeouts, scratch[2] = stale reads.  tools/grid_barrier.py. */
+int m5_debug_grid_barrier(uint32_t* scratch, int blocks, int threads, int iters, int mode, void* stream);
+
 /* Diagnostics: subsequent 16-bit m5_gemm launches record {shader clock, 100 MHz wall clock} at the entry
  * and at the end of the main loop of workgroup 0 into buf[0..3] (device memory); NULL disables. */
 int m5_debug_gemm_clock(unsigned long long* buf);

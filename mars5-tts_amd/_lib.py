@@ -129,6 +129,7 @@ PROTOTYPES = {
     "m5_debug_gemm_clock": (C.c_int, [vp]),
     "m5_debug_feed_probe": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "m5_debug_launch_chain": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "m5_debug_grid_barrier": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
 }
 
 

@@ -54,7 +54,7 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
             # (ar_generate.py:115).  All max_len - P rows are drawn up front so the decode loop never
             # touches the host; the generator is then rewound to where the reference leaves it (one
             # draw per executed loop iteration), so what follows (the NAR stage) sees the same stream.
-            gen = generator if generator is not None else torch.cuda.default_generators[dev.index]
+            gen = generator if generator is not None else torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
             off0 = gen.get_offset()
             noise_d = torch.empty(n_steps, n_vocab, dtype=torch.float32, device=dev)
             for i in range(n_steps):
@@ -114,7 +114,8 @@ def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: L
                 offs.append(0)
                 pers.append(0)
                 continue
-            g = generators[b] if generators is not None and generators[b] is not None else torch.cuda.default_generators[dev.index]
+            g = generators[b] if generators is not None and generators[b] is not None else \
+                torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
             off0 = g.get_offset()
             for i in range(nb):
                 noise_d[b, i].exponential_(1, generator=g)

@@ -156,3 +156,43 @@ extern "C" int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int ite
     M5_CHECK_LAUNCH();
     return M5_OK;
 }
+
+// ---- grid-barrier probe (diagnostics; tools/grid_barrier.py): what does a device-wide barrier between the
+// co-resident workgroups of ONE launch cost on this part (agent-scope atomic arrive + acquire spin), against the
+// 1.6 us dependent-launch floor?  That number decides whether a persistent decode-step kernel can beat one launch
+// per stage.  mode 1 adds a produce/consume of one word per workgroup across the barrier (visibility check).
+// Spins are bounded: a workgroup that waits more than 2^20 polls counts an error and moves on (never hangs).
+namespace {
+__global__ void grid_barrier_kernel(unsigned* ctr, unsigned* data, unsigned* err, int iters, int mode) {
+    const unsigned nb = gridDim.x;
+    for (int it = 0; it < iters; ++it) {
+        if (mode && threadIdx.x == 0)
+            __hip_atomic_store(&data[blockIdx.x], (unsigned)it * nb + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (unsigned)(it + 1) * nb;
+            int spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++spins > (1 << 20)) { atomicAdd(err, 1u); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+        if (mode && threadIdx.x == 0) {
+            const unsigned nbr = (blockIdx.x + 1) % nb;
+            const unsigned v = __hip_atomic_load(&data[nbr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (v != (unsigned)it * nb + nbr) atomicAdd(err + 1, 1u);
+        }
+    }
+}
+}  // namespace
+extern "C" int m5_debug_grid_barrier(uint32_t* scratch, int blocks, int threads, int iters, int mode, void* stream) {
+    // scratch: >= blocks + 4 words; [0] arrive counter, [1..2] error counts (timeouts, stale reads), [4..] data
+    if (!scratch || blocks <= 0 || blocks > 1024 || threads <= 0 || threads > 1024 || iters <= 0) return M5_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(scratch, 0, sizeof(uint32_t) * (blocks + 4), s) != hipSuccess) return M5_ERR_ARG;
+    hipLaunchKernelGGL(grid_barrier_kernel, dim3(blocks), dim3(threads), 0, s, scratch, scratch + 4, scratch + 1, iters, mode);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
