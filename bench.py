@@ -88,6 +88,30 @@ def main_c3(args, m, dev, world, rank, barrier):
     cfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
                           eos_estimated_gen_length_factor=100.0, eos_penalty_factor=50.0, eos_penalty_decay=0.5)
 
+    import inference as inf
+    split = {"ar_total_s": 0.0, "ar_decode_s": 0.0, "nar_total_s": 0.0, "nar_loop_s": 0.0}
+    _ar, _nar = inf.ar_generate_batch, inf.perform_batch_inference
+
+    def ar_timed(*a, **k):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = _ar(*a, **k)
+        torch.cuda.synchronize()
+        split["ar_total_s"] += time.perf_counter() - t
+        split["ar_decode_s"] += ar_engine.LAST_STATS["decode_ms"] / 1e3
+        return r
+
+    def nar_timed(*a, **k):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = _nar(*a, **k)
+        torch.cuda.synchronize()
+        split["nar_total_s"] += time.perf_counter() - t
+        split["nar_loop_s"] += nar_engine.LAST_STATS["loop_ms"] / 1e3
+        return r
+
+    inf.ar_generate_batch, inf.perform_batch_inference = ar_timed, nar_timed
+
     def step(i):
         t0 = time.perf_counter()
         out = m.tts_batch_from_codes(texts, refs, trs, cfg, seeds=[1000 + rank * 10007 + i * args.batch + j for j in range(args.batch)],
@@ -97,6 +121,8 @@ def main_c3(args, m, dev, world, rank, barrier):
 
     for i in range(args.warmup):
         step(-1 - i)
+    for k in split:
+        split[k] = 0.0
     barrier()
     t0 = time.perf_counter()
     lat, frames = [], 0
@@ -127,6 +153,7 @@ def main_c3(args, m, dev, world, rank, barrier):
                    "requests_per_step": args.batch, "ar_batch": args.ar_batch, "nar_batch": args.nar_batch,
                    "reference_frames_min_mean_max": [min(ref_frames), round(sum(ref_frames) / len(ref_frames), 1), max(ref_frames)],
                    "parallelism": f"replicas x{world} (requests sharded by rank, no data-path collective)"},
+        "time_split_s_per_step": {k: round(v / args.steps, 3) for k, v in split.items()},
         "last_ar_batch": {k: ar_engine.LAST_STATS.get(k) for k in ("decode_ms", "decode_steps_launched", "batch")},
         "last_nar_batch": {k: nar_engine.LAST_STATS.get(k) for k in ("loop_ms", "steps", "batch", "rows")},
     }

@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from mars5_tts_amd.ar_generate import ar_generate, ar_generate_batch
-from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_batch_inference, perform_simple_inference
+from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, begin_inference, perform_batch_inference, perform_simple_inference
 from mars5_tts_amd.minbpe import GPT4_SPLIT_PATTERN, CodebookTokenizer, RegexTokenizer
 from mars5_tts_amd.model import CodecLM, ResidualTransformer
 from mars5_tts_amd.trim import trim
@@ -192,11 +192,20 @@ class Mars5TTS:
                        generator: Optional[torch.Generator] = None) -> Tuple[Tensor, Tensor]:
         """``tts`` between the codec and the vocoder (reference inference.py:222-301):
         prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out."""
-        gen_codes_decoded, batch, skip_front = self._ar_stage(text, prompt_codec, ref_transcript, cfg, ar_noise, generator)
         T = self.default_T
         diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
+        pr = self._prompt(text, prompt_codec, ref_transcript, cfg)
+        # the NAR stage's conditioning work (text encoder for all 200 steps, cross-attention K / V) does not depend on the
+        # AR output: enqueue it on the NAR stream now, it runs beside the AR decode
+        nar_sess = begin_inference(self.codecnar, torch.tensor(pr["text_tokens"], dtype=torch.long, device=self.device)[None],
+                                   pr["prompt_codec"].permute(0, 2, 1), diff.num_timesteps, dsh=self._dsh(cfg))
+        ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
+                               fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
+                               n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
+                               generator=generator, **self._ar_kwargs(cfg))
+        gen_codes_decoded, batch, skip_front = self._handoff(pr, ar_codes, cfg)
         final_output = perform_simple_inference(self.codecnar, batch, diff, diff.num_timesteps, torch.float16, dsh=self._dsh(cfg),
-                                                retain_quant0=True, generator=generator)
+                                                retain_quant0=True, generator=generator, session=nar_sess)
         final_output = final_output[0, skip_front:].to(self.device)
         return gen_codes_decoded, final_output
 

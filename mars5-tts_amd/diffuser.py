@@ -97,16 +97,31 @@ def _nar_config(T, dsh, div_mode: int) -> NARConfig:
 
 
 @torch.inference_mode()
+def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode: int = 0) -> NARSession:
+    """Start the part of ``perform_simple_inference`` that depends only on the conditioning (text ids (1,Lt),
+    reference codes (1,Lc,8)) and the schedule -- speaker vector, text encoder for every step and guidance branch,
+    cross-attention K / V -- on the session's own stream and return without waiting.  ``tts()`` calls this BEFORE the
+    AR decode (which leaves most of the chip idle) and hands the session to ``perform_simple_inference``."""
+    cfg = _nar_config(T, dsh, div_mode)
+    eng = model.engine()
+    times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
+    sess = NARSession(eng, cfg)
+    sess.prepare_cond(c_text[0], c_codes[0].to(eng.dev), times)
+    return sess
+
+
+@torch.inference_mode()
 def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T, dtype=torch.float16,
                              retain_quant0: bool = True, dsh=DSH,
                              uniform: Optional[Callable[[tuple], Tensor]] = None, randint: Optional[Callable] = None,
                              use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None,
-                             generator: Optional[torch.Generator] = None) -> Tensor:
+                             generator: Optional[torch.Generator] = None, session: Optional[NARSession] = None) -> Tensor:
     """batch = (c_text (1,Lt), c_codes (1,Lc,8), c_text_lengths, c_codes_lengths, x (1,Lx,8),
     x_padding_mask); returns (1, S - offset, 8) int64.  RNG draws follow the reference order:
     randint(0,K,(1,Lx,8)) then per step rand (1,S,8,K) x2 (x1 at t = 0).
     `uniform(shape)` / `randint(shape)` override the device generator (parity tests);
-    `generator` draws from a private device generator instead of the global one."""
+    `generator` draws from a private device generator instead of the global one; `session`: the result of
+    ``begin_inference`` for the same conditioning, T and dsh (its conditioning work is then not repeated)."""
     c_text, c_codes = batch[0], batch[1]
     assert retain_quant0, "retain_quant0=False is not a shipped configuration (inference.py:298)"
     cfg = _nar_config(T, dsh, div_mode)
@@ -115,12 +130,17 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
     K = diff.num_classes
     assert K == eng.shape.n_quant
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
-    sess = NARSession(eng, cfg)
+    sess = session if session is not None else NARSession(eng, cfg)
     with torch.cuda.stream(sess.stream):
         xr, x_known, m, offset = _inpaint_state(batch, K, dsh, dev, randint, generator)
         if uniform is None:
             uniform = lambda shape: torch.rand(shape, dtype=torch.float32, device=dev, generator=generator)   # noqa: E731
-    sess.prepare(c_text[0], c_codes[0].to(dev), xr, x_known, m, offset, times)
+    if session is None:
+        sess.prepare(c_text[0], c_codes[0].to(dev), xr, x_known, m, offset, times)
+    else:
+        assert sess.times == list(times) and sess.cfg == cfg, "session was begun with a different schedule / DSH"
+        sess.prepare_state(xr, x_known, m, offset)
+        sess.prepare_loop()
     out = sess.run(uniform, use_graph=use_graph, n_steps=n_steps)
     return out[None, offset:].clone()
 

@@ -22,6 +22,7 @@ like the reference on the same device.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
 
@@ -29,8 +30,8 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .blocks import (LAYERNORM_EPS, CrossMemory, SeqWorkspace, SpeakerEncoder, decoder_layer, encoder_layer,
-                     pack_layer, round_up)
+from .blocks import (LAYERNORM_EPS, CrossMemory, SeqWorkspace, SpeakerEncoder, cross_attn_block, decoder_layer, encoder_layer,
+                     ff_block, pack_layer, round_up, self_attn_block)
 from .synth import NARShape
 from .tables import log_eps, nar_step_consts, reverse_schedule, sine_pe, timestep_inputs
 
@@ -62,6 +63,32 @@ class NARModel:
         self.spk = SpeakerEncoder(sd, "ref_embedder", "ref_pos_embedding.alpha", shape.n_spk_layers, dt, dev)
         self.pe = sine_pe(max_frames, D).to(dev)
         self.spk_uncond: Optional[torch.Tensor] = None      # model constant, computed on first use
+        self._tvec_cache: Dict[tuple, tuple] = {}           # schedule -> (t_enc, t_dec): both timestep MLPs over every scheduled t
+
+    def timestep_vectors(self, times: List[int], stream: torch.cuda.Stream) -> tuple:
+        """(t_enc, t_dec), each (len(times), D) fp32: timestep_embedding -> Linear -> SiLU -> Linear (model.py:18-35,
+        :281-283) for every scheduled t.  Depends on the schedule only, so it is computed once per schedule."""
+        key = tuple(times)
+        hit = self._tvec_cache.get(key)
+        if hit is not None:
+            return hit
+        s, dev, dt = self.shape, self.dev, self.dt
+        T, D = len(times), s.dim
+        st = stream.cuda_stream
+        with torch.cuda.stream(stream):
+            tin = timestep_inputs(list(times), s.t_emb_dim).to(device=dev, dtype=dt)
+            tvec = []
+            for (w0, b0, w2, b2) in self.te:
+                h = torch.empty(T, D, dtype=dt, device=dev)
+                o = torch.empty(T, D, dtype=torch.float32, device=dev)
+                ops.gemm(tin, w0, h, L.EPI_SILU_DT, bias=b0, stream=st)
+                ops.gemm(h, w2, o, L.EPI_F32, bias=b2, stream=st)
+                tvec.append(o)
+            stream.synchronize()                 # cached across sessions (and their streams): make it plainly complete
+        if len(self._tvec_cache) > 8:
+            self._tvec_cache.clear()
+        self._tvec_cache[key] = (tvec[0], tvec[1])
+        return self._tvec_cache[key]
 
     def uncond_speaker(self, stream=None) -> torch.Tensor:
         if self.spk_uncond is None:
@@ -145,15 +172,7 @@ class NARSession:
             rows = [spk_c]
             if guided:
                 rows.append(mdl.uncond_speaker(stream=st))
-            tin = timestep_inputs(self.times, s.t_emb_dim).to(device=dev, dtype=dt)
-            tvec = []
-            for (w0, b0, w2, b2) in mdl.te:
-                h = torch.empty(T, D, dtype=dt, device=dev)
-                o = torch.empty(T, D, dtype=torch.float32, device=dev)
-                ops.gemm(tin, w0, h, L.EPI_SILU_DT, bias=b0, stream=st)
-                ops.gemm(h, w2, o, L.EPI_F32, bias=b2, stream=st)
-                tvec.append(o)
-            t_enc, self.t_dec = tvec
+            t_enc, self.t_dec = mdl.timestep_vectors(self.times, self.stream)
             # -- encoder input for every (step, cond/uncond): [spk, text] + pos + t_enc[step]
             table = torch.cat([mdl.text_embed] + [r[None] for r in rows], dim=0)
             nt = mdl.text_embed.shape[0]
@@ -195,6 +214,10 @@ class NARSession:
         with torch.cuda.stream(self.stream):
             self.ws = SeqWorkspace(nb, S, D, FF, dt, dev, row_pad=64)
             self.Sr = Sr = self.ws.Sr
+            # the two guidance branches enter the decoder with the SAME rows (x_t embedding + timestep vector) and first
+            # differ in layer 0's cross-attention, so layer 0's self-attention block runs once (one-sequence workspace)
+            share0 = os.environ.get("M5_NAR_SHARE0", "1") != "0"          # A/B knob (tools/nar_step_bench.py)
+            self.ws0 = SeqWorkspace(1, S, D, FF, dt, dev, row_pad=64) if (nb == 2 and share0) else None
             self.h = torch.zeros(nb, Sr, D, dtype=torch.float32, device=dev)
             self.hf = torch.zeros(nb * Sr, D, dtype=torch.float32, device=dev)
             self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
@@ -209,10 +232,22 @@ class NARSession:
         """x_t -> logits for both guidance branches (the loop body's GEMM/attention work)."""
         mdl, s = self.m, self.m.shape
         S, Sr, nb, D, Q = self.S, self.Sr, self.nb, s.dim, s.n_codebooks
-        ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
-                          rows=S, stream=st)
         hx = self.h.view(nb * Sr, D)
-        for lw, mem in zip(mdl.dec, self.mems):
+        layers = list(zip(mdl.dec, self.mems))
+        if self.ws0 is not None:
+            ops.chunked_embed(self.h[:1], mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
+                              rows=S, stream=st)
+            lw, mem = layers[0]
+            self_attn_block(hx[:Sr], lw, self.ws0, None, st)
+            with torch.cuda.stream(self.stream):
+                self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
+            cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st)
+            ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st)
+            layers = layers[1:]
+        else:
+            ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
+                              rows=S, stream=st)
+        for lw, mem in layers:
             decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st)
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         so = self.s_out
