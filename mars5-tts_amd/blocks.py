@@ -78,7 +78,7 @@ class SeqWorkspace:
     B > 1.  The pad rows are ordinary finite rows (zero-initialised, never attended to: keys >= S
     are masked and never loaded); V^T rows are padded to whole 64-key tiles."""
 
-    def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev, row_pad: int = 1):
+    def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev, row_pad: int = 1, fuse_ln: bool = False):
         self.B, self.S, self.D, self.FF, self.dt = B, S, D, FF, dt
         self.H = D // 64
         self.Sr = round_up(S, row_pad)
@@ -91,6 +91,11 @@ class SeqWorkspace:
         self.vt = torch.zeros(B, self.H, 64, self.Sp, dtype=dt, device=dev)
         self.att = torch.zeros(M, D, dtype=dt, device=dev)
         self.hff = torch.zeros(M, FF, dtype=dt, device=dev)
+        # scratch of the fused residual + LayerNorm GEMM (partials + counters, zero between launches); None = never fuse
+        self.ln_scratch = None
+        if fuse_ln and dt != torch.float32:
+            tiles_m = (M + 95) // 96
+            self.ln_scratch = torch.zeros(256 + 8 * tiles_m + 768 * tiles_m * 16 + 1024, dtype=torch.uint8, device=dev)
 
     def scatter(self, q=True, k=True, v=True) -> L.QkvScatter:
         H, S, Sp = self.H, self.Sr, self.Sp
@@ -109,19 +114,36 @@ class SeqWorkspace:
                           scale=64 ** -0.5, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0)
 
 
-def self_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, key_len: Optional[torch.Tensor], stream=None) -> None:
-    """x = x + out_proj(SDPA(in_proj(LN1(x))))   (x fp32 [B*S, D], updated in place)."""
-    ops.layernorm(x, lw.n1_w, lw.n1_b, LAYERNORM_EPS, ws.xn, stream=stream)
+def residual_gemm(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], ws: SeqWorkspace,
+                  next_ln, stream=None) -> bool:
+    """x += a @ w^T + bias.  With `next_ln` = (gamma, beta) of the LayerNorm that consumes x next, the fused kernel
+    also leaves ws.xn = LayerNorm(x) when the shape is eligible; returns whether ws.xn was produced."""
+    if next_ln is not None and ws.ln_scratch is not None:
+        if ops.gemm_residual_ln(a, w, x, bias, next_ln[0], next_ln[1], LAYERNORM_EPS, ws.xn, ws.ln_scratch, stream=stream):
+            return True
+    ops.gemm(a, w, x, L.EPI_RESIDUAL, bias=bias, stream=stream)
+    return False
+
+
+def self_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, key_len: Optional[torch.Tensor], stream=None,
+                    normed: bool = False, next_ln=None) -> bool:
+    """x = x + out_proj(SDPA(in_proj(LN1(x))))   (x fp32 [B*S, D], updated in place).
+    normed: ws.xn already holds LN1(x) (left there by the previous block's fused epilogue).  Returns whether ws.xn
+    holds next_ln(x) on exit."""
+    if not normed:
+        ops.layernorm(x, lw.n1_w, lw.n1_b, LAYERNORM_EPS, ws.xn, stream=stream)
     ops.gemm(ws.xn, lw.in_w, None, L.EPI_QKV, bias=lw.in_b, scatter=ws.scatter(), stream=stream)
     ops.attention(ws.dt, ws.self_attn_args(key_len), stream=stream)
-    ops.gemm(ws.att, lw.out_w, x, L.EPI_RESIDUAL, bias=lw.out_b, stream=stream)
+    return residual_gemm(ws.att, lw.out_w, x, lw.out_b, ws, next_ln, stream)
 
 
-def ff_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, norm_w: torch.Tensor, norm_b: torch.Tensor, stream=None) -> None:
+def ff_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, norm_w: torch.Tensor, norm_b: torch.Tensor, stream=None,
+             normed: bool = False, next_ln=None) -> bool:
     """x = x + linear2(silu(W LN(x)) * (V LN(x)))."""
-    ops.layernorm(x, norm_w, norm_b, LAYERNORM_EPS, ws.xn, stream=stream)
+    if not normed:
+        ops.layernorm(x, norm_w, norm_b, LAYERNORM_EPS, ws.xn, stream=stream)
     ops.gemm(ws.xn, lw.act_w, ws.hff, L.EPI_SWIGLU, stream=stream)
-    ops.gemm(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, bias=lw.l2_b, stream=stream)
+    return residual_gemm(ws.hff, lw.l2_w, x, lw.l2_b, ws, next_ln, stream)
 
 
 def encoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, key_len: Optional[torch.Tensor], stream=None) -> None:
@@ -140,13 +162,15 @@ class CrossMemory:
     Bm: int          # memory batch entries per step (2 = cond, uncond)
 
 
-def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None) -> None:
+def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
+                     normed: bool = False, next_ln=None) -> bool:
     """x = x + out_proj(SDPA(q_proj(LN2(x)), memory K/V of step *step_ptr)).
     `mems`: one CrossMemory covering all ws.B sequences, or a list of them (one per utterance, each
     covering its Bm consecutive sequences of the workspace; memories of different utterances have
     different lengths, so the attention is launched per utterance while the projections stay batched)."""
     H, S, Sr, D = ws.H, ws.S, ws.Sr, ws.D
-    ops.layernorm(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, stream=stream)
+    if not normed:
+        ops.layernorm(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, stream=stream)
     ops.gemm(ws.xn, lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=ws.scatter(True, False, False), stream=stream)
     if isinstance(mems, CrossMemory):
         mems = [mems]
@@ -162,14 +186,17 @@ def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, ste
         ops.attention(ws.dt, a, stream=stream)
         b0 += mem.Bm
     assert b0 == ws.B
-    ops.gemm(ws.att, lw.ca_out_w, x, L.EPI_RESIDUAL, bias=lw.ca_out_b, stream=stream)
+    return residual_gemm(ws.att, lw.ca_out_w, x, lw.ca_out_b, ws, next_ln, stream)
 
 
 def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
-                  key_len: Optional[torch.Tensor] = None) -> None:
-    self_attn_block(x, lw, ws, key_len, stream)
-    cross_attn_block(x, lw, ws, mems, step_ptr, stream)
-    ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream)
+                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None) -> bool:
+    """One pre-LN decoder layer.  Each residual GEMM tries to leave the NEXT LayerNorm's output in ws.xn (fused
+    epilogue); `normed` says the caller (previous layer) already did that for norm1, the return value says whether
+    `next_ln` (the following layer's norm1) has been applied on exit."""
+    n = self_attn_block(x, lw, ws, key_len, stream, normed=normed, next_ln=(lw.n2_w, lw.n2_b))
+    n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b))
+    return ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream, normed=n, next_ln=next_ln)
 
 
 class SpeakerEncoder:

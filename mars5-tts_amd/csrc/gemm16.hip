@@ -45,7 +45,14 @@ struct Gemm16Params {
     int vt_vec;                      // V^T scatter may store 4 consecutive s as one 8-byte vector
     M5QkvScatter sc;
     int sec_kind[3];
+    // EPI_RESIDUAL_LN: LayerNorm of the updated rows fused behind the residual add (see the epilogue)
+    const float* ln_g; const float* ln_b; float ln_eps;
+    unsigned char* xn; int64_t ld_xn;            // normalised rows, operand type
+    float* ln_part;                              // [tilesM][tilesN][BM][2] per-tile (mean, M2) of each row
+    unsigned int* ln_sync;                       // [tilesM][2] arrive / depart counters, zero between launches
+    unsigned int* ln_err;                        // += 1 if a wait timed out (never hangs)
 };
+constexpr int EPI_RESIDUAL_LN = 101;
 
 template <typename T>
 __device__ inline f4_t mfma16(const uint4& a, const uint4& b, f4_t c);
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 
     // in-place residual: the old C values of this wave's tile are requested BEFORE the K loop (they come
     // from HBM: 11.5 MB of fp32 per 2816 x 1024 launch) and consumed after it -- the epilogue then only writes
-    constexpr bool PRELOAD_C = (EPI == M5_EPI_RESIDUAL) && (TM * TN <= 16);
+    constexpr bool PRELOAD_C = (EPI == M5_EPI_RESIDUAL || EPI == EPI_RESIDUAL_LN) && (TM * TN <= 16);
     float4 oldpre[PRELOAD_C ? TM : 1][PRELOAD_C ? TN : 1];
     if constexpr (PRELOAD_C) {
         const float* Cr = reinterpret_cast<const float*>(p.C) + (int64_t)bz * p.sC;
@@ -263,9 +270,136 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     if (dbg_on) { dbg[2] = clock64(); dbg[3] = wall_clock64(); }
     // ---- epilogue.  swapped layout: acc[i][j][r] = C[mw + 16 i + l15][nw + 16 j + 4 lg + r]
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
-    constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL);
+    constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL || EPI == EPI_RESIDUAL_LN);
     unsigned char* Cb = p.C + (int64_t)bz * p.sC * (F32OUT ? 4 : 2);
     const int mw = m0 + wm * TM * 16, nw = n0 + wn * TN * 16;
+
+    // ---- residual add + LayerNorm of the updated rows (NAR decoder: every LayerNorm but the first follows a
+    // residual GEMM).  A row is spread over the tilesN workgroups of its row tile, so they exchange per-tile
+    // (mean, M2) partials through memory and meet at a per-row-tile counter: each then normalises the values it
+    // still holds in registers and writes its 128 columns of xn -- the separate LayerNorm launch (6 us, a read of
+    // x and a round trip of xn) disappears.  Requirements checked by the host: the whole grid is co-resident
+    // (one workgroup per CU, nblk <= CUs), N = tilesN * BN exactly, batch 1.  The partials and the counter travel
+    // as agent-scope relaxed atomics (write-through / L2-bypassing on this multi-XCD part), ordered by explicit
+    // waits -- no release fence, which would write back the whole L2.  Waits are bounded (error flag, no hang).
+    if constexpr (EPI == EPI_RESIDUAL_LN) {
+        static_assert(PRELOAD_C && WN == 2, "fused LayerNorm epilogue: two waves per row, preloaded residual");
+        float v[TM][TN][4];
+        float* Cf = reinterpret_cast<float*>(Cb);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = nw + j * 16 + lg * 4;
+            float bv4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv4[r] = bias ? bias[col + r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float4 o = oldpre[i][j];
+                v[i][j][0] = o.x + (acc[i][j][0] + bv4[0]); v[i][j][1] = o.y + (acc[i][j][1] + bv4[1]);
+                v[i][j][2] = o.z + (acc[i][j][2] + bv4[2]); v[i][j][3] = o.w + (acc[i][j][3] + bv4[3]);
+                const int row = mw + i * 16 + l15;
+                if (row < p.M) *reinterpret_cast<float4*>(Cf + (int64_t)row * p.ldc + col) = make_float4(v[i][j][0], v[i][j][1], v[i][j][2], v[i][j][3]);
+            }
+        }
+        // per-row (mean, M2) over this wave's 64 columns: lane sums, then the 4 lane groups
+        float mean_w[TM], m2_w[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) sm += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+            sm += __shfl_xor(sm, 16);
+            sm += __shfl_xor(sm, 32);
+            mean_w[i] = sm * (1.0f / (TN * 16));
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = v[i][j][r] - mean_w[i]; q += d * d; }
+            q += __shfl_xor(q, 16);
+            q += __shfl_xor(q, 32);
+            m2_w[i] = q;
+        }
+        __syncthreads();                                      // the stage buffers are free
+        float* sw = reinterpret_cast<float*>(lds);            // [NW][TM*16][2], then [BM][2] combined at +NW*TM*32
+        if (lg == 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                sw[((wave * TM + i) * 16 + l15) * 2] = mean_w[i];
+                sw[((wave * TM + i) * 16 + l15) * 2 + 1] = m2_w[i];
+            }
+        }
+        __syncthreads();
+        float* part = p.ln_part + ((int64_t)tm * p.tilesN + tn) * BM * 2;
+        if (tid < BM) {                                        // row tid of the tile: merge its two waves (64 columns each)
+            const int wmr = tid / (TM * 16), lr = tid - wmr * (TM * 16);
+            const float ma = sw[((wmr * WN + 0) * TM * 16 + lr) * 2], qa = sw[((wmr * WN + 0) * TM * 16 + lr) * 2 + 1];
+            const float mb = sw[((wmr * WN + 1) * TM * 16 + lr) * 2], qb = sw[((wmr * WN + 1) * TM * 16 + lr) * 2 + 1];
+            const float mt = 0.5f * (ma + mb);
+            const float qt = (qa + qb) + (float)(TN * 16) * ((ma - mt) * (ma - mt) + (mb - mt) * (mb - mt));
+            __hip_atomic_store(part + tid * 2, mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(part + tid * 2 + 1, qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's partials have left the CU
+        __syncthreads();
+        unsigned int* sync = p.ln_sync + tm * 2;
+        if (tid == 0) {
+            __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.tilesN) {
+                if (++spins > (1 << 22)) { atomicAdd(p.ln_err, 1u); break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        float* cmb = sw + NW * TM * 32;                       // [BM][2]: mean, rstd of the whole row
+        if (tid < BM) {
+            float mj[16], qj[16];
+            const float* pr = p.ln_part + (int64_t)tm * p.tilesN * BM * 2 + tid * 2;
+            const int nt = min(p.tilesN, 16);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                if (n < nt) {
+                    mj[n] = __hip_atomic_load(pr + (int64_t)n * BM * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    qj[n] = __hip_atomic_load(pr + (int64_t)n * BM * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            float msum = 0.f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) if (n < nt) msum += mj[n];
+            const float mean = msum / (float)nt;
+            float q = 0.f, dev = 0.f;
+#pragma unroll
+            for (int n = 0; n < 16; ++n) if (n < nt) { q += qj[n]; dev += (mj[n] - mean) * (mj[n] - mean); }
+            const float var = (q + (float)BN * dev) / (float)p.N;
+            cmb[tid * 2] = mean;
+            cmb[tid * 2 + 1] = 1.0f / sqrtf(var + p.ln_eps);
+        }
+        __syncthreads();
+        if (tid == 0) {                                        // every partial of this row tile has been read by this workgroup
+            const unsigned d = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == (unsigned)p.tilesN - 1) {                 // last one out re-arms the counters for the next launch
+                __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        st* Xn = reinterpret_cast<st*>(p.xn);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int lrow = wm * TM * 16 + i * 16 + l15, row = m0 + lrow;
+            const float mean = cmb[lrow * 2], rstd = cmb[lrow * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = nw + j * 16 + lg * 4;
+                const float4 g = *reinterpret_cast<const float4*>(p.ln_g + col), bb = *reinterpret_cast<const float4*>(p.ln_b + col);
+                float o[4] = {(v[i][j][0] - mean) * rstd * g.x + bb.x, (v[i][j][1] - mean) * rstd * g.y + bb.y,
+                              (v[i][j][2] - mean) * rstd * g.z + bb.z, (v[i][j][3] - mean) * rstd * g.w + bb.w};
+                if (row < p.M) *reinterpret_cast<uint2*>(Xn + (int64_t)row * p.ld_xn + col) = pack4<T>(o);
+            }
+        }
+        if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
+        return;
+    }
 
     // ---- Q / K / V^T scatter, one head (64 columns) per wave: stage through LDS, store 16-byte chunks.
     // Q, K: rows of 128 bytes ([s][64 d]) go out whole.  V^T: the unswapped accumulator layout gives each
@@ -620,7 +754,54 @@ int pick_config(int M, int N, int K, int batch, int span_div, int epi) {
 
 unsigned long long* g_gemm_dbg = nullptr;
 
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 }  // namespace
+
+// Residual GEMM with the following LayerNorm fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
+// (M5_ERR_UNSUPPORTED otherwise; the caller then runs m5_gemm + m5_layernorm): 16-bit operands, batch 1, region 96x128
+// tiling with the whole grid co-resident (one workgroup per CU), N a multiple of 128 and <= 2048.
+extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                   float* C, int64_t ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
+                                   float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (!A || !W || !C || !ln_gamma || !ln_beta || !xn || !scratch || M <= 0 || N <= 0 || K <= 0) return M5_ERR_ARG;
+    if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
+    constexpr int BM = 96, BN = 128;
+    const int tilesM = (M + BM - 1) / BM, tilesN = N / BN;
+    if ((N % BN) || tilesN > 16 || (K % 64) || (int64_t)tilesM * tilesN > num_cus()) return M5_ERR_UNSUPPORTED;
+    if ((lda % 8) || (ldw % 8) || (ldc % 4) || (ld_xn % 4) || (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) ||
+        ((uintptr_t)xn & 7)) return M5_ERR_UNSUPPORTED;
+    const int64_t need = 256 + (int64_t)tilesM * 8 + (int64_t)tilesM * tilesN * BM * 2 * 4;
+    if (scratch_bytes < need || ((uintptr_t)scratch & 15)) return M5_ERR_ARG;
+    const char* e = getenv("M5_GEMM_LN");                     // A/B knob: 0 = report unsupported (caller falls back)
+    if (e && e[0] == '0') return M5_ERR_UNSUPPORTED;
+    Gemm16Params p{};
+    p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
+    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
+    p.vec_c = 1;
+    p.dbg = g_gemm_dbg;
+    p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps; p.xn = (unsigned char*)xn; p.ld_xn = ld_xn;
+    p.ln_err = (unsigned int*)scratch;                                  // [0]: timeouts; counters from byte 256
+    p.ln_sync = (unsigned int*)((unsigned char*)scratch + 256);
+    p.ln_part = (float*)((unsigned char*)scratch + 256 + (int64_t)tilesM * 8);
+    p.tilesM = tilesM; p.tilesN = tilesN; p.nblk = tilesM * tilesN; p.group_m = max(1, GROUP_M * 128 / BM);
+    const dim3 grid(p.nblk), blk(256);
+    if (dtype == M5_F16) hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_RESIDUAL_LN, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm16_kernel<BF16T, EPI_RESIDUAL_LN, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, (hipStream_t)stream, p);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
 
 extern "C" int m5_debug_gemm_clock(unsigned long long* buf) {   // diagnostics (tools/gemm_clock.py); nullptr disables
     g_gemm_dbg = buf;

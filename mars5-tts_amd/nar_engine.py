@@ -212,7 +212,7 @@ class NARSession:
         D, FF, K, Q = s.dim, s.dim_ff, s.n_quant, s.n_codebooks
         S, nb = self.S, self.nb
         with torch.cuda.stream(self.stream):
-            self.ws = SeqWorkspace(nb, S, D, FF, dt, dev, row_pad=64)
+            self.ws = SeqWorkspace(nb, S, D, FF, dt, dev, row_pad=64, fuse_ln=True)
             self.Sr = Sr = self.ws.Sr
             # the two guidance branches enter the decoder with the SAME rows (x_t embedding + timestep vector) and first
             # differ in layer 0's cross-attention, so layer 0's self-attention block runs once (one-sequence workspace)
@@ -241,14 +241,19 @@ class NARSession:
             self_attn_block(hx[:Sr], lw, self.ws0, None, st)
             with torch.cuda.stream(self.stream):
                 self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
-            cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st)
-            ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st)
+            nxt = (mdl.dec[1].n1_w, mdl.dec[1].n1_b) if len(mdl.dec) > 1 else None
+            normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b))
+            normed = ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st, normed=normed, next_ln=nxt)
             layers = layers[1:]
+            l0 = 1
         else:
             ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
                               rows=S, stream=st)
-        for lw, mem in layers:
-            decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st)
+            normed, l0 = False, 0
+        for k, (lw, mem) in enumerate(layers):
+            l = l0 + k                                         # every LayerNorm but the first rides on the residual GEMM before it
+            nxt = (mdl.dec[l + 1].n1_w, mdl.dec[l + 1].n1_b) if l + 1 < len(mdl.dec) else None
+            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt)
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         so = self.s_out
         for b in range(nb):
@@ -300,6 +305,8 @@ class NARSession:
             self.step(uniform, use_graph)
         ev1.record(st)
         self.stream.synchronize()
+        if self.ws.ln_scratch is not None and int(self.ws.ln_scratch[:4].view(torch.int32)[0]) != 0:
+            raise RuntimeError("fused residual+LayerNorm GEMM: a row-tile wait timed out (grid not co-resident?)")
         LAST_STATS.update(loop_ms=ev0.elapsed_ms(ev1), steps=n, S=self.S, s_out=self.s_out, Le=self.mems[0].Le, nb=self.nb)
         return self.x
 

@@ -46,6 +46,20 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int
                       C.byref(scatter) if scatter is not None else None, batch, sA, sW, sC, sBias, _s(stream)), "m5_gemm")
 
 
+def gemm_residual_ln(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
+                     beta: torch.Tensor, eps: float, xn: torch.Tensor, scratch: torch.Tensor, stream: Optional[int] = None) -> bool:
+    """x += a @ w^T + bias and xn = LayerNorm(x) in one launch.  False if the shape is not eligible for the fused kernel
+    (nothing was launched; run gemm + layernorm instead)."""
+    assert a.dtype == w.dtype == xn.dtype and x.dtype == torch.float32 and scratch.dtype == torch.uint8
+    N, K = w.shape
+    st = lib.m5_gemm_residual_ln(DT_CODE[a.dtype], _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), x.stride(0), a.shape[0], N, K,
+                                 _p(gamma), _p(beta), eps, _p(xn), xn.stride(0), _p(scratch), scratch.numel(), _s(stream))
+    if st == L.M5_ERR_UNSUPPORTED:
+        return False
+    check(st, "m5_gemm_residual_ln")
+    return True
+
+
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor,
               n_affine: int = 1, affine_stride: int = 0, y_affine_stride: int = 0, M: Optional[int] = None,
               stream: Optional[int] = None) -> None:

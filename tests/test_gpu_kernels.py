@@ -109,6 +109,42 @@ def test_gemm_skinny_decode_shapes(dev, dt, M):
         assert _rel(outs[0], outs[1]) < tol, f"M={M} N={N} K={K} epi={epi}: skinny vs wide-tile kernel"
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_residual_layernorm_fused(dev, dt):
+    """m5_gemm_residual_ln: x += A W^T + bias and xn = LayerNorm(x) from ONE launch (row statistics exchanged between
+    the workgroups of a row tile) vs fp32 torch; repeated launches reuse the same scratch (self-resetting counters);
+    ineligible shapes report unsupported without launching."""
+    from mars5_tts_amd import ops
+    torch.manual_seed(0)
+    for (M, N, K) in [(2816, 1024, 1024), (1408, 1024, 3072), (100, 1024, 64), (2816, 256, 128)]:
+        a = _q(_rand((M, K), 1), dt)
+        w = _q(_rand((N, K), 2, 2.0 / math.sqrt(K)), dt)
+        bias, g, b = _rand((N,), 3), 1.0 + 0.3 * _rand((N,), 4), 0.2 * _rand((N,), 5)
+        x0 = _rand((M, N), 6, 3.0) + 5.0 * _rand((M, 1), 7)               # rows with very different means
+        scratch = torch.zeros(256 + 8 * 30 + 768 * 30 * 16 + 1024, dtype=torch.uint8, device=dev)
+        ad, wd = a.to(dev, dt), w.to(dev, dt)
+        x = x0.to(dev).clone()
+        xn = torch.zeros(M + 1, N, device=dev, dtype=dt)
+        ref_x = x0.clone()
+        for rep in range(3):                                                # the residual accumulates; counters re-arm
+            ok = ops.gemm_residual_ln(ad, wd, x, bias.to(dev), g.to(dev), b.to(dev), 4e-5, xn[:M], scratch)
+            assert ok, (M, N, K)
+            ref_x = ref_x + (a @ w.T + bias)
+        torch.cuda.synchronize()
+        ref_xn = torch.nn.functional.layer_norm(ref_x, (N,), g, b, 4e-5)
+        assert int(scratch[:4].view(torch.int32)[0]) == 0, "a row-tile wait timed out"
+        assert int(scratch[256:256 + 8 * 30].view(torch.int32).abs().sum()) == 0, "counters not re-armed"
+        assert _rel(x.cpu(), ref_x) < TOL[dt] * 2, (M, N, K, _rel(x.cpu(), ref_x))
+        r = float((xn[:M].float().cpu() - ref_xn).abs().max())
+        assert r < (2e-2 if dt == torch.float16 else 6e-2), f"{(M, N, K)}: xn max abs err {r}"   # |xn| ~ 3
+        assert float(xn[M].float().abs().max()) == 0.0
+    # more row tiles than CUs, or N not a multiple of the tile width: the caller must fall back
+    big = torch.zeros(96 * 40, 64, device=dev, dtype=dt)
+    assert not ops.gemm_residual_ln(big, torch.zeros(1024, 64, device=dev, dtype=dt), torch.zeros(96 * 40, 1024, device=dev), None,
+                                    torch.ones(1024, device=dev), torch.zeros(1024, device=dev), 4e-5,
+                                    torch.zeros(96 * 40, 1024, device=dev, dtype=dt), torch.zeros(2 ** 21, dtype=torch.uint8, device=dev))
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_gemm_swiglu_and_qkv(dev, dt):
     from mars5_tts_amd import _lib as L, ops
