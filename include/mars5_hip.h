@@ -121,14 +121,18 @@ int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos0, cons
 /* x[M][N] += A . W^T + bias (the RESIDUAL epilogue of m5_gemm) with the LayerNorm that follows it in every pre-LN
  * block (model.py:179-203: norm2 / norm3 / the next layer's norm1) fused into the same launch:
  * xn = LayerNorm(x_new; gamma, beta, eps) in the operand type.  The workgroups of a row tile exchange per-tile
- * (mean, M2) partials through `scratch` and meet at a counter, so the WHOLE grid must be co-resident: returns
- * M5_ERR_UNSUPPORTED (caller falls back to m5_gemm + m5_layernorm) unless 16-bit operands, N % 128 == 0, N <= 2048
- * and ceil(M/96) * N/128 <= number of CUs.  scratch: zero-initialised once by the caller, >= 256 + 8 ceil(M/96) +
- * 768 ceil(M/96) N/128 bytes, reusable by later calls on the same stream; scratch[0] (uint32) counts wait
- * timeouts (0 in a healthy run; waits are bounded, a launch never hangs). */
+ * (mean, M2) words through `scratch` (M2 carries an 8-bit launch tag in its low mantissa bits), so the WHOLE grid
+ * must be co-resident: returns M5_ERR_UNSUPPORTED (caller falls back to m5_gemm + m5_layernorm) unless 16-bit
+ * operands, N % 128 == 0, N <= 2048 and ceil(M/96) * N/128 <= number of CUs.
+ * scratch: zero-initialised once by the caller, >= 256 + 768 ceil(M/96) N/128 bytes, reusable by later calls on the
+ * same stream PROVIDED consecutive calls carry different launch tags: tag = 1 + (*tag_step * 64 + tag) % 255 with
+ * tag_step a device int32 (or NULL = 0) -- under hipGraph replay the kernel arguments are frozen, so the varying part
+ * must live in device memory (the DDPM step counter).  scratch[0] (uint32) counts wait timeouts (0 in a healthy run;
+ * waits are bounded, a launch never hangs). */
 int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                         float* C, int64_t ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
-                        float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes, void* stream);
+                        float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes,
+                        const int32_t* tag_step, int tag, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * AR decode step (one token, batch 1): weight-streaming GEMV with fused prologue/epilogue.

@@ -95,7 +95,9 @@ class SeqWorkspace:
         self.ln_scratch = None
         if fuse_ln and dt != torch.float32:
             tiles_m = (M + 95) // 96
-            self.ln_scratch = torch.zeros(256 + 8 * tiles_m + 768 * tiles_m * 16 + 1024, dtype=torch.uint8, device=dev)
+            self.ln_scratch = torch.zeros(256 + 768 * tiles_m * 16, dtype=torch.uint8, device=dev)
+        self.ln_tag = 0                    # launch tag of the next fused call (consecutive calls on ln_scratch must differ)
+        self.ln_tag_step = None            # device int32 that changes between graph replays (the DDPM step counter)
 
     def scatter(self, q=True, k=True, v=True) -> L.QkvScatter:
         H, S, Sp = self.H, self.Sr, self.Sp
@@ -119,7 +121,9 @@ def residual_gemm(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Optio
     """x += a @ w^T + bias.  With `next_ln` = (gamma, beta) of the LayerNorm that consumes x next, the fused kernel
     also leaves ws.xn = LayerNorm(x) when the shape is eligible; returns whether ws.xn was produced."""
     if next_ln is not None and ws.ln_scratch is not None:
-        if ops.gemm_residual_ln(a, w, x, bias, next_ln[0], next_ln[1], LAYERNORM_EPS, ws.xn, ws.ln_scratch, stream=stream):
+        if ops.gemm_residual_ln(a, w, x, bias, next_ln[0], next_ln[1], LAYERNORM_EPS, ws.xn, ws.ln_scratch, tag=ws.ln_tag,
+                                tag_step=ws.ln_tag_step, stream=stream):
+            ws.ln_tag = (ws.ln_tag + 1) % 64
             return True
     ops.gemm(a, w, x, L.EPI_RESIDUAL, bias=bias, stream=stream)
     return False

@@ -48,8 +48,8 @@ struct Gemm16Params {
     // EPI_RESIDUAL_LN: LayerNorm of the updated rows fused behind the residual add (see the epilogue)
     const float* ln_g; const float* ln_b; float ln_eps;
     unsigned char* xn; int64_t ld_xn;            // normalised rows, operand type
-    float* ln_part;                              // [tilesM][tilesN][BM][2] per-tile (mean, M2) of each row
-    unsigned int* ln_sync;                       // [tilesM][2] arrive / depart counters, zero between launches
+    float* ln_part;                              // [tilesM][BM][tilesN] 8-byte words {mean, M2 | launch tag}
+    const int* ln_tag_step; int ln_tag;          // launch tag = 1 + (*ln_tag_step * 64 + ln_tag) % 255
     unsigned int* ln_err;                        // += 1 if a wait timed out (never hangs)
 };
 constexpr int EPI_RESIDUAL_LN = 101;
@@ -279,9 +279,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     // (mean, M2) partials through memory and meet at a per-row-tile counter: each then normalises the values it
     // still holds in registers and writes its 128 columns of xn -- the separate LayerNorm launch (6 us, a read of
     // x and a round trip of xn) disappears.  Requirements checked by the host: the whole grid is co-resident
-    // (one workgroup per CU, nblk <= CUs), N = tilesN * BN exactly, batch 1.  The partials and the counter travel
-    // as agent-scope relaxed atomics (write-through / L2-bypassing on this multi-XCD part), ordered by explicit
-    // waits -- no release fence, which would write back the whole L2.  Waits are bounded (error flag, no hang).
+    // (one workgroup per CU, nblk <= CUs), N = tilesN * BN exactly, batch 1.  The partials travel as agent-scope
+    // relaxed 8-byte atomics (write-through / L2-bypassing on this multi-XCD part) -- no release fence, which would
+    // write back the whole L2.  Waits are bounded (error flag, no hang).
     if constexpr (EPI == EPI_RESIDUAL_LN) {
         static_assert(PRELOAD_C && WN == 2, "fused LayerNorm epilogue: two waves per row, preloaded residual");
         float v[TM][TN][4];
@@ -330,40 +330,42 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             }
         }
         __syncthreads();
-        float* part = p.ln_part + ((int64_t)tm * p.tilesN + tn) * BM * 2;
+        // exchange: one 8-byte word per (row, column tile) = {mean, M2 with the launch tag in its low 8 mantissa bits};
+        // a reader polls the tilesN words of its row until all carry this launch's tag.  Every launch overwrites every
+        // word it later reads and consecutive launches on one scratch carry different tags, so a word is either the
+        // previous launch's (other tag) or this launch's -- no counters, no store acknowledgement on the critical path.
+        const unsigned tag = 1u + (unsigned)(((p.ln_tag_step ? *p.ln_tag_step : 0) * 64 + p.ln_tag) % 255);
+        unsigned long long* words = reinterpret_cast<unsigned long long*>(p.ln_part) + ((int64_t)tm * BM) * p.tilesN;
+        float* cmb = sw + NW * TM * 32;                       // [BM][2]: mean, rstd of the whole row
         if (tid < BM) {                                        // row tid of the tile: merge its two waves (64 columns each)
             const int wmr = tid / (TM * 16), lr = tid - wmr * (TM * 16);
             const float ma = sw[((wmr * WN + 0) * TM * 16 + lr) * 2], qa = sw[((wmr * WN + 0) * TM * 16 + lr) * 2 + 1];
             const float mb = sw[((wmr * WN + 1) * TM * 16 + lr) * 2], qb = sw[((wmr * WN + 1) * TM * 16 + lr) * 2 + 1];
             const float mt = 0.5f * (ma + mb);
             const float qt = (qa + qb) + (float)(TN * 16) * ((ma - mt) * (ma - mt) + (mb - mt) * (mb - mt));
-            __hip_atomic_store(part + tid * 2, mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(part + tid * 2 + 1, qt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's partials have left the CU
-        __syncthreads();
-        unsigned int* sync = p.ln_sync + tm * 2;
-        if (tid == 0) {
-            __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int spins = 0;
-            while (__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.tilesN) {
-                if (++spins > (1 << 22)) { atomicAdd(p.ln_err, 1u); break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __syncthreads();
-        float* cmb = sw + NW * TM * 32;                       // [BM][2]: mean, rstd of the whole row
-        if (tid < BM) {
+            const unsigned long long wv = ((unsigned long long)__float_as_uint(mt) << 32) | ((__float_as_uint(qt) & 0xffffff00u) | tag);
+            unsigned long long* rw = words + (int64_t)tid * p.tilesN;
+            __hip_atomic_store(rw + tn, wv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             float mj[16], qj[16];
-            const float* pr = p.ln_part + (int64_t)tm * p.tilesN * BM * 2 + tid * 2;
-            const int nt = min(p.tilesN, 16);
+            const int nt = p.tilesN;
+            int spins = 0;
+            bool all;
+            do {
+                all = true;
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                if (n < nt) {
-                    mj[n] = __hip_atomic_load(pr + (int64_t)n * BM * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    qj[n] = __hip_atomic_load(pr + (int64_t)n * BM * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int n = 0; n < 16; ++n) {
+                    if (n < nt) {
+                        const unsigned long long u = __hip_atomic_load(rw + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        all = all && ((unsigned)(u & 0xffu) == tag);
+                        mj[n] = __uint_as_float((unsigned)(u >> 32));
+                        qj[n] = __uint_as_float((unsigned)(u & 0xffffff00u));
+                    }
                 }
-            }
+                if (!all) {
+                    if (++spins > (1 << 20)) { atomicAdd(p.ln_err, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            } while (!all);
             float msum = 0.f;
 #pragma unroll
             for (int n = 0; n < 16; ++n) if (n < nt) msum += mj[n];
@@ -376,13 +378,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             cmb[tid * 2 + 1] = 1.0f / sqrtf(var + p.ln_eps);
         }
         __syncthreads();
-        if (tid == 0) {                                        // every partial of this row tile has been read by this workgroup
-            const unsigned d = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == (unsigned)p.tilesN - 1) {                 // last one out re-arms the counters for the next launch
-                __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
         st* Xn = reinterpret_cast<st*>(p.xn);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -772,7 +767,8 @@ int num_cus() {
 // tiling with the whole grid co-resident (one workgroup per CU), N a multiple of 128 and <= 2048.
 extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                    float* C, int64_t ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
-                                   float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes, void* stream) {
+                                   float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes,
+                                   const int32_t* tag_step, int tag, void* stream) {
     if (!A || !W || !C || !ln_gamma || !ln_beta || !xn || !scratch || M <= 0 || N <= 0 || K <= 0) return M5_ERR_ARG;
     if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
     constexpr int BM = 96, BN = 128;
@@ -780,7 +776,7 @@ extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const 
     if ((N % BN) || tilesN > 16 || (K % 64) || (int64_t)tilesM * tilesN > num_cus()) return M5_ERR_UNSUPPORTED;
     if ((lda % 8) || (ldw % 8) || (ldc % 4) || (ld_xn % 4) || (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)ln_gamma | (uintptr_t)ln_beta) & 15) ||
         ((uintptr_t)xn & 7)) return M5_ERR_UNSUPPORTED;
-    const int64_t need = 256 + (int64_t)tilesM * 8 + (int64_t)tilesM * tilesN * BM * 2 * 4;
+    const int64_t need = 256 + (int64_t)tilesM * tilesN * BM * 8;
     if (scratch_bytes < need || ((uintptr_t)scratch & 15)) return M5_ERR_ARG;
     const char* e = getenv("M5_GEMM_LN");                     // A/B knob: 0 = report unsupported (caller falls back)
     if (e && e[0] == '0') return M5_ERR_UNSUPPORTED;
@@ -791,9 +787,9 @@ extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const 
     p.vec_c = 1;
     p.dbg = g_gemm_dbg;
     p.ln_g = ln_gamma; p.ln_b = ln_beta; p.ln_eps = ln_eps; p.xn = (unsigned char*)xn; p.ld_xn = ld_xn;
-    p.ln_err = (unsigned int*)scratch;                                  // [0]: timeouts; counters from byte 256
-    p.ln_sync = (unsigned int*)((unsigned char*)scratch + 256);
-    p.ln_part = (float*)((unsigned char*)scratch + 256 + (int64_t)tilesM * 8);
+    p.ln_err = (unsigned int*)scratch;                                  // [0]: timeouts; exchange words from byte 256
+    p.ln_part = (float*)((unsigned char*)scratch + 256);
+    p.ln_tag_step = tag_step; p.ln_tag = tag;
     p.tilesM = tilesM; p.tilesN = tilesN; p.nblk = tilesM * tilesN; p.group_m = max(1, GROUP_M * 128 / BM);
     const dim3 grid(p.nblk), blk(256);
     if (dtype == M5_F16) hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_RESIDUAL_LN, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, (hipStream_t)stream, p);

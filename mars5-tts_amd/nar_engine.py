@@ -234,6 +234,7 @@ class NARSession:
         S, Sr, nb, D, Q = self.S, self.Sr, self.nb, s.dim, s.n_codebooks
         hx = self.h.view(nb * Sr, D)
         layers = list(zip(mdl.dec, self.mems))
+        self.ws.ln_tag, self.ws.ln_tag_step = 0, self.step_ptr      # fused LN launches: tag = f(step counter, call index)
         if self.ws0 is not None:
             ops.chunked_embed(self.h[:1], mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
                               rows=S, stream=st)

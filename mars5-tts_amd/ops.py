@@ -47,13 +47,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int
 
 
 def gemm_residual_ln(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
-                     beta: torch.Tensor, eps: float, xn: torch.Tensor, scratch: torch.Tensor, stream: Optional[int] = None) -> bool:
+                     beta: torch.Tensor, eps: float, xn: torch.Tensor, scratch: torch.Tensor, tag: int = 0,
+                     tag_step: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> bool:
     """x += a @ w^T + bias and xn = LayerNorm(x) in one launch.  False if the shape is not eligible for the fused kernel
-    (nothing was launched; run gemm + layernorm instead)."""
+    (nothing was launched; run gemm + layernorm instead).  Consecutive calls on one `scratch` need different launch tags
+    (tag, or the device counter `tag_step` under graph replay): see include/mars5_hip.h."""
     assert a.dtype == w.dtype == xn.dtype and x.dtype == torch.float32 and scratch.dtype == torch.uint8
     N, K = w.shape
     st = lib.m5_gemm_residual_ln(DT_CODE[a.dtype], _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), x.stride(0), a.shape[0], N, K,
-                                 _p(gamma), _p(beta), eps, _p(xn), xn.stride(0), _p(scratch), scratch.numel(), _s(stream))
+                                 _p(gamma), _p(beta), eps, _p(xn), xn.stride(0), _p(scratch), scratch.numel(), _p(tag_step), tag, _s(stream))
     if st == L.M5_ERR_UNSUPPORTED:
         return False
     check(st, "m5_gemm_residual_ln")

@@ -112,7 +112,7 @@ def test_gemm_skinny_decode_shapes(dev, dt, M):
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gemm_residual_layernorm_fused(dev, dt):
     """m5_gemm_residual_ln: x += A W^T + bias and xn = LayerNorm(x) from ONE launch (row statistics exchanged between
-    the workgroups of a row tile) vs fp32 torch; repeated launches reuse the same scratch (self-resetting counters);
+    the workgroups of a row tile) vs fp32 torch; repeated launches reuse the same scratch (launch tags);
     ineligible shapes report unsupported without launching."""
     from mars5_tts_amd import ops
     torch.manual_seed(0)
@@ -121,19 +121,21 @@ def test_gemm_residual_layernorm_fused(dev, dt):
         w = _q(_rand((N, K), 2, 2.0 / math.sqrt(K)), dt)
         bias, g, b = _rand((N,), 3), 1.0 + 0.3 * _rand((N,), 4), 0.2 * _rand((N,), 5)
         x0 = _rand((M, N), 6, 3.0) + 5.0 * _rand((M, 1), 7)               # rows with very different means
-        scratch = torch.zeros(256 + 8 * 30 + 768 * 30 * 16 + 1024, dtype=torch.uint8, device=dev)
+        scratch = torch.zeros(256 + 768 * 30 * 16, dtype=torch.uint8, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
         ad, wd = a.to(dev, dt), w.to(dev, dt)
         x = x0.to(dev).clone()
         xn = torch.zeros(M + 1, N, device=dev, dtype=dt)
         ref_x = x0.clone()
         for rep in range(3):                                                # the residual accumulates; counters re-arm
-            ok = ops.gemm_residual_ln(ad, wd, x, bias.to(dev), g.to(dev), b.to(dev), 4e-5, xn[:M], scratch)
+            ok = ops.gemm_residual_ln(ad, wd, x, bias.to(dev), g.to(dev), b.to(dev), 4e-5, xn[:M], scratch, tag=rep % 2,
+                                      tag_step=step if rep else None)
             assert ok, (M, N, K)
+            step += 1
             ref_x = ref_x + (a @ w.T + bias)
         torch.cuda.synchronize()
         ref_xn = torch.nn.functional.layer_norm(ref_x, (N,), g, b, 4e-5)
         assert int(scratch[:4].view(torch.int32)[0]) == 0, "a row-tile wait timed out"
-        assert int(scratch[256:256 + 8 * 30].view(torch.int32).abs().sum()) == 0, "counters not re-armed"
         assert _rel(x.cpu(), ref_x) < TOL[dt] * 2, (M, N, K, _rel(x.cpu(), ref_x))
         r = float((xn[:M].float().cpu() - ref_xn).abs().max())
         assert r < (2e-2 if dt == torch.float16 else 6e-2), f"{(M, N, K)}: xn max abs err {r}"   # |xn| ~ 3
