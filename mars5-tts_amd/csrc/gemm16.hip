@@ -778,8 +778,12 @@ extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const 
         ((uintptr_t)xn & 7)) return M5_ERR_UNSUPPORTED;
     const int64_t need = 256 + (int64_t)tilesM * tilesN * BM * 8;
     if (scratch_bytes < need || ((uintptr_t)scratch & 15)) return M5_ERR_ARG;
-    const char* e = getenv("M5_GEMM_LN");                     // A/B knob: 0 = report unsupported (caller falls back)
-    if (e && e[0] == '0') return M5_ERR_UNSUPPORTED;
+    // OFF unless M5_GEMM_LN=1: measured SLOWER than GEMM + LayerNorm launches on MI355X (3.60 vs 3.50 ms per NAR step,
+    // tools/nar_step_bench.py): the exchange between the 8 workgroups of a row tile (write-through store, L2-bypassing
+    // polls, plus their start skew) costs ~8 us per launch against the 6 us LayerNorm launch it removes.  Kept as a
+    // tested opt-in and as the record of that measurement.
+    const char* e = getenv("M5_GEMM_LN");
+    if (!(e && e[0] == '1')) return M5_ERR_UNSUPPORTED;
     Gemm16Params p{};
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
