@@ -118,6 +118,17 @@ int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos0, cons
                   void* q_out, void* kcache, void* vcache, int64_t cache_hs, int window,
                   void* vt_out, int64_t vt_hs, int64_t vt_ds, void* stream);
 
+/* Cross-attention query projection with the attention fused into its epilogue (nn.MultiheadAttention of the NAR
+ * decoder against the text memory, model.py:179-203): out[M][H*64] = softmax(scale (A W^T + bias)_h K_h^T) V_h per head,
+ * for memories of at most 64 keys whose K / V^T were projected beforehand.  Rows are grouped in sequences of
+ * `rows_per_seq` (a multiple of 16); sequence s attends to the memory described by mem_table[s][6] (device int64):
+ * {K base address, V^T base address, Le, Lep, step stride of K, step stride of V^T (elements)} with K [H][Le][64] and
+ * V^T [H][64][Lep] inside the block selected by the device index *step (the DDPM step).  Returns M5_ERR_UNSUPPORTED
+ * (nothing launched; use m5_gemm(EPI_QKV) + m5_attention) unless 16-bit operands, max_le <= 64, even n_heads. */
+int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                         int M, int n_heads, int K, const int64_t* mem_table, int max_le, int rows_per_seq,
+                         const int32_t* step, float scale, void* out, int64_t ld_out, void* stream);
+
 /* x[M][N] += A . W^T + bias (the RESIDUAL epilogue of m5_gemm) with the LayerNorm that follows it in every pre-LN
  * block (model.py:179-203: norm2 / norm3 / the next layer's norm1) fused into the same launch:
  * xn = LayerNorm(x_new; gamma, beta, eps) in the operand type.  The workgroups of a row tile exchange per-tile

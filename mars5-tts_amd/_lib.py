@@ -102,6 +102,7 @@ PROTOTYPES = {
     "m5_build_info": (C.c_char_p, []),
     "m5_gemm": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.POINTER(QkvScatter), C.c_int, i64, i64, i64, i64, vp]),
+    "m5_gemm_q_cross_attn": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, f32, vp, i64, vp]),
     "m5_gemm_residual_ln": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, f32, vp, i64, vp, i64,
                                        vp, C.c_int, vp]),
     "m5_layernorm": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, C.c_int, i64, i64, vp]),

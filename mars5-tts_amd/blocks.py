@@ -166,8 +166,23 @@ class CrossMemory:
     Bm: int          # memory batch entries per step (2 = cond, uncond)
 
 
+def cross_memory_table(mems, dev) -> tuple:
+    """(table, max_le) for ops.gemm_q_cross_attn: one row {K base, V^T base, Le, Lep, K step stride, V^T step stride} per
+    sequence of the workspace, in workspace order (`mems`: one CrossMemory or a list, each covering Bm sequences)."""
+    if isinstance(mems, CrossMemory):
+        mems = [mems]
+    rows = []
+    for mem in mems:
+        H = mem.k.shape[1]
+        esz = mem.k.element_size()
+        for b in range(mem.Bm):
+            rows.append([mem.k.data_ptr() + b * H * mem.Le * 64 * esz, mem.vt.data_ptr() + b * H * 64 * mem.Lep * esz, mem.Le, mem.Lep,
+                         mem.Bm * H * mem.Le * 64, mem.Bm * H * 64 * mem.Lep])
+    return torch.tensor(rows, dtype=torch.int64).to(dev), max(m.Le for m in mems)
+
+
 def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
-                     normed: bool = False, next_ln=None) -> bool:
+                     normed: bool = False, next_ln=None, xa=None) -> bool:
     """x = x + out_proj(SDPA(q_proj(LN2(x)), memory K/V of step *step_ptr)).
     `mems`: one CrossMemory covering all ws.B sequences, or a list of them (one per utterance, each
     covering its Bm consecutive sequences of the workspace; memories of different utterances have
@@ -175,6 +190,10 @@ def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, ste
     H, S, Sr, D = ws.H, ws.S, ws.Sr, ws.D
     if not normed:
         ops.layernorm(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, stream=stream)
+    # xa = (memory table, longest memory) built before any graph capture: query projection + attention in one launch
+    if xa is not None and ws.dt != torch.float32 and \
+            ops.gemm_q_cross_attn(ws.xn, lw.ca_q_w, lw.ca_q_b, H, xa[0], xa[1], Sr, step_ptr, 64 ** -0.5, ws.att, stream=stream):
+        return residual_gemm(ws.att, lw.ca_out_w, x, lw.ca_out_b, ws, next_ln, stream)
     ops.gemm(ws.xn, lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=ws.scatter(True, False, False), stream=stream)
     if isinstance(mems, CrossMemory):
         mems = [mems]
@@ -194,12 +213,12 @@ def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, ste
 
 
 def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
-                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None) -> bool:
+                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None, xa=None) -> bool:
     """One pre-LN decoder layer.  Each residual GEMM tries to leave the NEXT LayerNorm's output in ws.xn (fused
     epilogue); `normed` says the caller (previous layer) already did that for norm1, the return value says whether
     `next_ln` (the following layer's norm1) has been applied on exit."""
     n = self_attn_block(x, lw, ws, key_len, stream, normed=normed, next_ln=(lw.n2_w, lw.n2_b))
-    n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b))
+    n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b), xa=xa)
     return ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream, normed=n, next_ln=next_ln)
 
 

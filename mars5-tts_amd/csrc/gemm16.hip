@@ -51,8 +51,15 @@ struct Gemm16Params {
     float* ln_part;                              // [tilesM][BM][tilesN] 8-byte words {mean, M2 | launch tag}
     const int* ln_tag_step; int ln_tag;          // launch tag = 1 + (*ln_tag_step * 64 + ln_tag) % 255
     unsigned int* ln_err;                        // += 1 if a wait timed out (never hangs)
+    // EPI_Q_CROSS: cross-attention against a short pre-projected memory fused behind its Q projection (see the epilogue)
+    const int64_t* xa_tab;                       // per sequence: {K base, V^T base, Le, Lep, step stride of K, of V^T} (elements)
+    const int* xa_step; int xa_rows_per_seq;     // memory block of step *xa_step; rows per sequence in A / out
+    unsigned char* xa_out; int64_t xa_ld_out;    // attention output [M][n_heads * 64], operand type
+    float xa_scale;
 };
 constexpr int EPI_RESIDUAL_LN = 101;
+constexpr int EPI_Q_CROSS = 102;
+constexpr int XA_MAX_KT = 4;                     // fused cross-attention: at most 4 key tiles of 16 (memory length <= 64)
 
 template <typename T>
 __device__ inline f4_t mfma16(const uint4& a, const uint4& b, f4_t c);
@@ -223,6 +230,48 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         }
     }
 
+    // EPI_Q_CROSS: this wave's 64 columns are ONE head; the memory of a sequence is short (<= 64 keys) and already
+    // projected, so its K / V^T fragments for this head are requested now (L2 hits, they land during the K loop).
+    // Fragment layouts (16x16x32 MFMA, lane = (l15, lg)): K as the first operand of S^T = K q^T: row = key 16 t + l15,
+    // d-chunk 4 ks + lg.  V^T as the first operand of O^T = V^T P^T: row = d 16 dt + l15, and its 8 k-slots of key step
+    // sp are keys {32 sp + 4 lg + 0..3, 32 sp + 16 + 4 lg + 0..3} -- exactly the keys whose probabilities lane
+    // (l15, lg) holds after S^T (rows 4 lg + r of key tiles 2 sp and 2 sp + 1), so P never leaves its registers.
+    uint4 xk[EPI == EPI_Q_CROSS ? XA_MAX_KT : 1][2], xv[EPI == EPI_Q_CROSS ? 4 : 1][EPI == EPI_Q_CROSS ? XA_MAX_KT / 2 : 1];
+    int xa_seq = -1, xa_le = 0;
+    auto xa_load = [&](int seq) {
+        const int64_t* tb = p.xa_tab + (int64_t)seq * 6;
+        const int le = (int)tb[2];
+        const int64_t lep = tb[3];
+        const int64_t stp = *p.xa_step;
+        const int hh = (n0 + wn * 64) >> 6;
+        const unsigned char* Kh = reinterpret_cast<const unsigned char*>(tb[0]) + (stp * tb[4] + (int64_t)hh * le * 64) * 2;
+        const unsigned char* Vh = reinterpret_cast<const unsigned char*>(tb[1]) + (stp * tb[5] + (int64_t)hh * 64 * lep) * 2;
+        const int nkt = (le + 15) >> 4;
+#pragma unroll
+        for (int t = 0; t < XA_MAX_KT; ++t) {
+            const int key = min(t * 16 + l15, le - 1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                xk[t][ks] = (t < nkt) ? *reinterpret_cast<const uint4*>(Kh + ((int64_t)key * 64 + (ks * 4 + lg) * 8) * 2) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int sp = 0; sp < XA_MAX_KT / 2; ++sp) {
+                uint4 u = make_uint4(0, 0, 0, 0);
+                if (2 * sp < nkt) {
+                    const unsigned char* vr = Vh + ((int64_t)(dt * 16 + l15) * lep + sp * 32 + lg * 4) * 2;
+                    const uint2 a0 = *reinterpret_cast<const uint2*>(vr);
+                    const uint2 a1 = (2 * sp + 1 < nkt) ? *reinterpret_cast<const uint2*>(vr + 32) : make_uint2(0, 0);
+                    u = make_uint4(a0.x, a0.y, a1.x, a1.y);
+                }
+                xv[dt][sp] = u;
+            }
+        xa_seq = seq;
+        xa_le = le;
+    };
+    if constexpr (EPI == EPI_Q_CROSS) xa_load(min(m0 + wm * TM * 16, p.M - 1) / p.xa_rows_per_seq);
+
     const int nk = p.K * 2 / BKB;
     const bool full_share = (NQ % NW == 0) || (wave < NQ % NW);     // this wave issues JN (else JN - 1) DMAs per stage
 #pragma unroll
@@ -273,6 +322,98 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL || EPI == EPI_RESIDUAL_LN);
     unsigned char* Cb = p.C + (int64_t)bz * p.sC * (F32OUT ? 4 : 2);
     const int mw = m0 + wm * TM * 16, nw = n0 + wn * TN * 16;
+
+    // ---- Q projection + cross-attention against a short memory (NAR decoder: 39-60 keys per sequence).  The wave owns
+    // 48 queries x one head of q: q goes to LDS in the operand type (the same rounding the separate kernels apply),
+    // then per 16-query tile S^T = K q^T (2 MFMAs per key tile), softmax over the keys (4 per lane and key tile, the
+    // rest across the 4 lane groups), O^T = V^T P^T with P taken from the S^T registers, and the 16 x 64 output tile
+    // is stored as 8-byte runs of d.  The separate attention launch (10 us for ~0.2 us of work) and the q round trip
+    // disappear.  A 16-query tile never straddles sequences (rows per sequence is a multiple of 16); a 48-row wave
+    // tile may, in which case the fragments are re-read for the tile that belongs to the next sequence.
+    if constexpr (EPI == EPI_Q_CROSS) {
+        static_assert(TN == 4, "one head per wave");
+        constexpr int RBQ = 128 + 16;
+        __syncthreads();                                      // the stage buffers are free
+        unsigned char* wsq = lds + wave * (TM * 16 * RBQ);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = nw + j * 16 + lg * 4;
+            float bv4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv4[r] = bias ? bias[col + r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                float vq[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vq[r] = acc[i][j][r] + bv4[r];
+                *reinterpret_cast<uint2*>(wsq + (i * 16 + l15) * RBQ + (j * 16 + lg * 4) * 2) = pack4<T>(vq);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        st* Out = reinterpret_cast<st*>(p.xa_out);
+        const int hh = (n0 + wn * 64) >> 6;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row0 = mw + i * 16;
+            if (row0 >= p.M) break;                            // wave-uniform
+            const int seq = row0 / p.xa_rows_per_seq;
+            if (seq != xa_seq) xa_load(seq);                   // wave-uniform, rare (tile on a sequence boundary)
+            const int le = xa_le, nkt = (le + 15) >> 4;
+            uint4 qf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(wsq + (i * 16 + l15) * RBQ + (ks * 4 + lg) * 16);
+            f4_t sc[XA_MAX_KT];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < XA_MAX_KT; ++t) {
+                sc[t] = f4_t{0.f, 0.f, 0.f, 0.f};
+                if (t < nkt) {
+                    sc[t] = mfma16<T>(xk[t][0], qf[0], sc[t]);
+                    sc[t] = mfma16<T>(xk[t][1], qf[1], sc[t]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                  // sc[t][r] = q_{l15} . k_{16 t + 4 lg + r}
+                    const float vs = (t * 16 + lg * 4 + r < le) ? sc[t][r] * p.xa_scale : -INFINITY;
+                    sc[t][r] = vs;
+                    mx = fmaxf(mx, vs);
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < XA_MAX_KT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = expf(sc[t][r] - mx); sc[t][r] = e; sum += e; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+            f4_t o[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[dt] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sp = 0; sp < XA_MAX_KT / 2; ++sp) {
+                if (2 * sp < nkt) {
+                    float p0[4] = {sc[2 * sp][0], sc[2 * sp][1], sc[2 * sp][2], sc[2 * sp][3]};
+                    float p1[4] = {sc[2 * sp + 1][0], sc[2 * sp + 1][1], sc[2 * sp + 1][2], sc[2 * sp + 1][3]};
+                    const uint2 u0 = pack4<T>(p0), u1 = pack4<T>(p1);
+                    const uint4 pf = make_uint4(u0.x, u0.y, u1.x, u1.y);
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) o[dt] = mfma16<T>(xv[dt][sp], pf, o[dt]);
+                }
+            }
+            const int row = row0 + l15;                        // o[dt][r] = O[query l15][d = 16 dt + 4 lg + r]
+            if (row < p.M) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    float ov[4] = {o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv};
+                    *reinterpret_cast<uint2*>(Out + (int64_t)row * p.xa_ld_out + hh * 64 + dt * 16 + lg * 4) = pack4<T>(ov);
+                }
+            }
+        }
+        if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
+        return;
+    }
 
     // ---- residual add + LayerNorm of the updated rows (NAR decoder: every LayerNorm but the first follows a
     // residual GEMM).  A row is spread over the tilesN workgroups of its row tile, so they exchange per-tile
@@ -761,6 +902,37 @@ int num_cus() {
 }
 
 }  // namespace
+
+// Q projection with the cross-attention it feeds fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
+// (M5_ERR_UNSUPPORTED otherwise; the caller then runs m5_gemm(EPI_QKV) + m5_attention): 16-bit operands, head_dim 64,
+// memory length <= 64, rows per sequence a multiple of 16.
+extern "C" int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                    int M, int n_heads, int K, const int64_t* mem_table, int max_le, int rows_per_seq,
+                                    const int32_t* step, float scale, void* out, int64_t ld_out, void* stream) {
+    if (!A || !W || !mem_table || !step || !out || M <= 0 || n_heads <= 0 || K <= 0 || rows_per_seq <= 0) return M5_ERR_ARG;
+    if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
+    if (max_le <= 0 || max_le > 16 * XA_MAX_KT || (rows_per_seq % 16) || (K % 64) || (n_heads % 2)) return M5_ERR_UNSUPPORTED;
+    if ((lda % 8) || (ldw % 8) || (ld_out % 4) || (((uintptr_t)A | (uintptr_t)W) & 15) || ((uintptr_t)out & 7)) return M5_ERR_UNSUPPORTED;
+    const char* e = getenv("M5_GEMM_XATTN");                  // A/B knob: 0 = report unsupported (caller falls back)
+    if (e && e[0] == '0') return M5_ERR_UNSUPPORTED;
+    constexpr int BM = 96, BN = 128;
+    Gemm16Params p{};
+    p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias;
+    p.lda = lda; p.ldw = ldw; p.M = M; p.N = n_heads * 64; p.K = K;
+    p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
+    p.dbg = g_gemm_dbg;
+    p.xa_tab = mem_table; p.xa_step = step; p.xa_rows_per_seq = rows_per_seq; p.xa_out = (unsigned char*)out; p.xa_ld_out = ld_out;
+    p.xa_scale = scale;
+    p.tilesM = (M + BM - 1) / BM; p.tilesN = p.N / BN;
+    const int64_t nblk = (int64_t)p.tilesM * p.tilesN;
+    if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
+    p.nblk = (int)nblk; p.group_m = max(1, GROUP_M * 128 / BM);
+    const dim3 grid(p.nblk), blk(256);
+    if (dtype == M5_F16) hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_Q_CROSS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm16_kernel<BF16T, EPI_Q_CROSS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, (hipStream_t)stream, p);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
 
 // Residual GEMM with the following LayerNorm fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
 // (M5_ERR_UNSUPPORTED otherwise; the caller then runs m5_gemm + m5_layernorm): 16-bit operands, batch 1, region 96x128

@@ -30,7 +30,8 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .blocks import (LAYERNORM_EPS, CrossMemory, SeqWorkspace, SpeakerEncoder, cross_attn_block, decoder_layer, encoder_layer,
+from .blocks import (LAYERNORM_EPS, CrossMemory, SeqWorkspace, SpeakerEncoder, cross_attn_block, cross_memory_table, decoder_layer,
+                     encoder_layer,
                      ff_block, pack_layer, round_up, self_attn_block)
 from .synth import NARShape
 from .tables import log_eps, nar_step_consts, reverse_schedule, sine_pe, timestep_inputs
@@ -225,6 +226,7 @@ class NARSession:
             self.logits = torch.empty(nb * self.s_out, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
+            self.xa = [cross_memory_table(mem, dev) for mem in self.mems]       # per layer, for the fused q-projection + cross-attention
         self.graph = None
 
     # ----------------------------------------------------------------------------- step
@@ -243,7 +245,7 @@ class NARSession:
             with torch.cuda.stream(self.stream):
                 self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
             nxt = (mdl.dec[1].n1_w, mdl.dec[1].n1_b) if len(mdl.dec) > 1 else None
-            normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b))
+            normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b), xa=self.xa[0])
             normed = ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st, normed=normed, next_ln=nxt)
             layers = layers[1:]
             l0 = 1
@@ -254,7 +256,7 @@ class NARSession:
         for k, (lw, mem) in enumerate(layers):
             l = l0 + k                                         # every LayerNorm but the first rides on the residual GEMM before it
             nxt = (mdl.dec[l + 1].n1_w, mdl.dec[l + 1].n1_b) if l + 1 < len(mdl.dec) else None
-            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt)
+            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l])
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         so = self.s_out
         for b in range(nb):
@@ -364,6 +366,7 @@ class NARBatchSession:
             self.logits = torch.empty(self.R, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
+            self.xa = [cross_memory_table([sub.mems[l] for sub in self.subs], dev) for l in range(len(mdl.dec))]
         self.graph = None
 
     def enqueue_forward(self, st: int) -> None:
@@ -375,7 +378,7 @@ class NARBatchSession:
                               add_index=self.step_ptr, rows=sub.S, stream=st)
         hx = self.h.view(-1, D)
         for l, lw in enumerate(mdl.dec):
-            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len)
+            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, xa=self.xa[l])
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         for u, sub in enumerate(self.subs):
             so = sub.s_out

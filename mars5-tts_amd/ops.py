@@ -46,6 +46,19 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int
                       C.byref(scatter) if scatter is not None else None, batch, sA, sW, sC, sBias, _s(stream)), "m5_gemm")
 
 
+def gemm_q_cross_attn(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], n_heads: int, mem_table: torch.Tensor, max_le: int,
+                      rows_per_seq: int, step: torch.Tensor, scale: float, out: torch.Tensor, stream: Optional[int] = None) -> bool:
+    """out = cross-attention of the projected queries a @ w^T + bias against short pre-projected memories, one launch.
+    mem_table (n_seq, 6) int64 device (include/mars5_hip.h).  False if the shape is not eligible (nothing launched)."""
+    assert a.dtype == w.dtype == out.dtype and mem_table.dtype == torch.int64 and mem_table.is_contiguous()
+    st = lib.m5_gemm_q_cross_attn(DT_CODE[a.dtype], _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), a.shape[0], n_heads, w.shape[1],
+                                  _p(mem_table), max_le, rows_per_seq, _p(step), scale, _p(out), out.stride(0), _s(stream))
+    if st == L.M5_ERR_UNSUPPORTED:
+        return False
+    check(st, "m5_gemm_q_cross_attn")
+    return True
+
+
 def gemm_residual_ln(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
                      beta: torch.Tensor, eps: float, xn: torch.Tensor, scratch: torch.Tensor, tag: int = 0,
                      tag_step: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> bool:

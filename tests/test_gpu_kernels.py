@@ -277,6 +277,45 @@ def test_attention_kv_index(dev):
     assert _rel(o.cpu(), ref) < 1e-4
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_q_cross_attention_fused(dev, dt):
+    """m5_gemm_q_cross_attn: query projection + cross-attention against short pre-projected memories in one launch,
+    vs fp32 torch.  Three sequences of 112 rows (not a multiple of the 96-row tile: tiles straddle sequences) attend
+    to memories of different lengths (39, 64, 17 keys) inside the block selected by a device step index."""
+    from mars5_tts_amd import ops
+    from mars5_tts_amd.blocks import CrossMemory, cross_memory_table
+    H, Kd, Sr, T, step_i = 16, 1024, 112, 3, 1
+    D = H * 64
+    les = [39, 64, 17]
+    M = Sr * len(les) - 5                                   # ragged tail: the last rows do not exist
+    a = _q(_rand((Sr * len(les), Kd), 1), dt)
+    w = _q(_rand((D, Kd), 2, 3.0 / math.sqrt(Kd)), dt)
+    bias = _rand((D,), 3, 0.5)
+    q = _q(a @ w.T + bias, dt).view(len(les), Sr, H, 64)    # the separate kernels round q to the operand type too
+    mems, ref = [], torch.zeros(len(les) * Sr, D)
+    for s_i, le in enumerate(les):
+        lep = (le + 63) // 64 * 64
+        k = _q(_rand((T, H, le, 64), 10 + s_i, 2.0), dt)
+        v = _q(_rand((T, H, le, 64), 20 + s_i), dt)
+        vt = torch.zeros(T, H, 64, lep)
+        vt[..., :le] = v.transpose(-1, -2)
+        mems.append(CrossMemory(k.to(dev, dt), vt.to(dev, dt), le, lep, 1))
+        sc = torch.einsum("shd,hnd->hsn", q[s_i], k[step_i]) * 0.125
+        o = torch.einsum("hsn,hnd->shd", torch.softmax(sc, -1), v[step_i])
+        ref[s_i * Sr:(s_i + 1) * Sr] = o.reshape(Sr, D)
+    tab, max_le = cross_memory_table(mems, dev)
+    out = torch.zeros(len(les) * Sr, D, device=dev, dtype=dt)
+    step = torch.tensor([step_i], dtype=torch.int32, device=dev)
+    ok = ops.gemm_q_cross_attn(a.to(dev, dt)[:M], w.to(dev, dt), bias.to(dev), H, tab, max_le, Sr, step, 0.125, out)
+    torch.cuda.synchronize()
+    assert ok
+    r = _rel(out[:M].float().cpu(), ref[:M])
+    assert r < (1e-2 if dt == torch.float16 else 4e-2), f"fused cross-attention rel err {r}"
+    assert float(out[M:].float().abs().max()) == 0.0, "rows >= M must not be written"
+    # memory longer than 64 keys: not eligible, nothing launched
+    assert not ops.gemm_q_cross_attn(a.to(dev, dt)[:M], w.to(dev, dt), bias.to(dev), H, tab, 65, Sr, step, 0.125, out)
+
+
 # ------------------------------------------------------------------------------ gathers / rope
 def test_gather_and_chunked(dev):
     from mars5_tts_amd import ops
