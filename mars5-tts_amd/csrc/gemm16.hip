@@ -352,6 +352,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         __builtin_amdgcn_wave_barrier();
         st* Out = reinterpret_cast<st*>(p.xa_out);
         const int hh = (n0 + wn * 64) >> 6;
+        const float sl2 = p.xa_scale * 1.4426950408889634f;   // softmax in the exp2 domain (v_exp_f32), like attn16
+        if (dbg_on) { dbg[6] = wall_clock64(); }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row0 = mw + i * 16;
@@ -372,8 +374,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     sc[t] = mfma16<T>(xk[t][1], qf[1], sc[t]);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {                  // sc[t][r] = q_{l15} . k_{16 t + 4 lg + r}
-                    const float vs = (t * 16 + lg * 4 + r < le) ? sc[t][r] * p.xa_scale : -INFINITY;
+                for (int r = 0; r < 4; ++r) {                  // sc[t][r] = q_{l15} . k_{16 t + 4 lg + r}, in log2 units
+                    const float vs = (t * 16 + lg * 4 + r < le) ? sc[t][r] * sl2 : -INFINITY;
                     sc[t][r] = vs;
                     mx = fmaxf(mx, vs);
                 }
@@ -384,10 +386,10 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
             for (int t = 0; t < XA_MAX_KT; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = expf(sc[t][r] - mx); sc[t][r] = e; sum += e; }
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(sc[t][r] - mx); sc[t][r] = e; sum += e; }
             sum += __shfl_xor(sum, 16);
             sum += __shfl_xor(sum, 32);
-            const float inv = 1.0f / sum;
+            const float inv = __builtin_amdgcn_rcpf(sum);
             f4_t o[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[dt] = f4_t{0.f, 0.f, 0.f, 0.f};
@@ -913,8 +915,13 @@ extern "C" int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const
     if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
     if (max_le <= 0 || max_le > 16 * XA_MAX_KT || (rows_per_seq % 16) || (K % 64) || (n_heads % 2)) return M5_ERR_UNSUPPORTED;
     if ((lda % 8) || (ldw % 8) || (ld_out % 4) || (((uintptr_t)A | (uintptr_t)W) & 15) || ((uintptr_t)out & 7)) return M5_ERR_UNSUPPORTED;
-    const char* e = getenv("M5_GEMM_XATTN");                  // A/B knob: 0 = report unsupported (caller falls back)
-    if (e && e[0] == '0') return M5_ERR_UNSUPPORTED;
+    // OFF unless M5_GEMM_XATTN=1.  Measured (tools/xattn_clock.py, tools/nar_step_bench.py): back to back on L2-hot data
+    // the fused launch takes 20.3 us against 24.8 us for projection + attention launches, but inside the NAR step (memory
+    // block of the step cold in HBM, weights streaming) the step gets 65 us SLOWER (3.76 vs 3.69 ms): the cold K / V^T
+    // fragments sit in front of the operand DMAs in the in-order load queue, and the region-96x128 tiling this epilogue
+    // needs (one head per wave) is slower for this GEMM than the 8-wave tiling the plain projection uses.
+    const char* e = getenv("M5_GEMM_XATTN");
+    if (!(e && e[0] == '1')) return M5_ERR_UNSUPPORTED;
     constexpr int BM = 96, BN = 128;
     Gemm16Params p{};
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias;

@@ -284,6 +284,7 @@ def test_gemm_q_cross_attention_fused(dev, dt):
     to memories of different lengths (39, 64, 17 keys) inside the block selected by a device step index."""
     from mars5_tts_amd import ops
     from mars5_tts_amd.blocks import CrossMemory, cross_memory_table
+    os.environ["M5_GEMM_XATTN"] = "1"       # opt-in path (off by default: no gain inside the NAR step, see gemm16.hip)
     H, Kd, Sr, T, step_i = 16, 1024, 112, 3, 1
     D = H * 64
     les = [39, 64, 17]
@@ -314,6 +315,7 @@ def test_gemm_q_cross_attention_fused(dev, dt):
     assert float(out[M:].float().abs().max()) == 0.0, "rows >= M must not be written"
     # memory longer than 64 keys: not eligible, nothing launched
     assert not ops.gemm_q_cross_attn(a.to(dev, dt)[:M], w.to(dev, dt), bias.to(dev), H, tab, 65, Sr, step, 0.125, out)
+    os.environ.pop("M5_GEMM_XATTN", None)
 
 
 # ------------------------------------------------------------------------------ gathers / rope
