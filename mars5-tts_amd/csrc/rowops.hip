@@ -55,10 +55,20 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
     float4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
-        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+    // the affine parameters of the (common) single-affine call are requested now, behind the row itself, so their L2
+    // round trip overlaps the two reductions instead of following them
+    float4 g0[NV], b0[NV];
+    const bool one = n_affine == 1;
+    if (one) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            g0[i] = *reinterpret_cast<const float4*>(gamma + (lane + 64 * i) * 4);
+            b0[i] = *reinterpret_cast<const float4*>(beta + (lane + 64 * i) * 4);
+        }
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
@@ -74,7 +84,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
-            const float4 gg = *reinterpret_cast<const float4*>(g + c), bb = *reinterpret_cast<const float4*>(bt + c);
+            const float4 gg = one ? g0[i] : *reinterpret_cast<const float4*>(g + c), bb = one ? b0[i] : *reinterpret_cast<const float4*>(bt + c);
             const float o[4] = {v[i].x * rstd * gg.x + bb.x, v[i].y * rstd * gg.y + bb.y,
                                 v[i].z * rstd * gg.z + bb.z, v[i].w * rstd * gg.w + bb.w};
             if constexpr (sizeof(st) == 4) {
