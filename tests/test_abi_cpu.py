@@ -73,3 +73,44 @@ def test_containers_take_reference_state_dict_names(tiny_bundle):
         bad = dict(tiny_bundle.ar_ckpt["model"])
         bad.pop("ar.norm.weight")
         lm.load_state_dict(bad)
+
+
+def test_cross_memory_table_layout():
+    """Host-side table for the fused / batched cross-attention: one row per workspace sequence, in order, with the
+    per-branch base addresses and per-step strides of that utterance's pre-projected memory."""
+    import torch
+    from mars5_tts_amd.blocks import CrossMemory, cross_memory_table
+    H, T = 4, 3
+    mems = []
+    for le, lep in ((39, 64), (70, 128)):
+        k = torch.zeros(T * 2, H, le, 64, dtype=torch.bfloat16)
+        vt = torch.zeros(T * 2, H, 64, lep, dtype=torch.bfloat16)
+        mems.append(CrossMemory(k, vt, le, lep, 2))
+    tab, max_le = cross_memory_table(mems, "cpu")
+    assert tab.shape == (4, 6) and tab.dtype == torch.int64 and max_le == 70
+    for u, mem in enumerate(mems):
+        for b in range(2):
+            row = tab[2 * u + b].tolist()
+            assert row[0] == mem.k[b].data_ptr() and row[1] == mem.vt[b].data_ptr()          # branch b of step 0
+            assert row[2:4] == [mem.Le, mem.Lep]
+            assert row[0] + row[4] * 2 == mem.k[2 + b].data_ptr() and row[1] + row[5] * 2 == mem.vt[2 + b].data_ptr()   # step 1
+
+
+def test_bench_c3_requests_follow_the_survey_spec():
+    """bench.py --workload c3 inputs: reference 150-900 frames, deterministic per seed."""
+    import bench
+
+    class Tok:
+        def encode(self, s, allowed_special=None):
+            return list(range(len(s.split())))
+
+    class M:
+        texttok, speechtok = Tok(), Tok()
+
+    a = bench.c3_requests(M(), 16, 450, seed=11)
+    b = bench.c3_requests(M(), 16, 450, seed=11)
+    assert a[0] == b[0] and a[1] == b[1] and a[3] == b[3] and all((x == y).all() for x, y in zip(a[2], b[2]))
+    for ref, ml in zip(a[2], a[3]):
+        assert ref.shape[0] == 1 and ref.shape[1] == 8 and 150 <= ref.shape[2] <= 900
+        assert ml > 450
+    assert len(set(r.shape[2] for r in a[2])) > 8          # genuinely mixed lengths
