@@ -31,8 +31,7 @@ import torch
 from . import _lib as L
 from . import ops
 from .blocks import (LAYERNORM_EPS, CrossMemory, SeqWorkspace, SpeakerEncoder, cross_attn_block, cross_memory_table, decoder_layer,
-                     encoder_layer,
-                     ff_block, pack_layer, round_up, self_attn_block)
+                     encoder_layer, ff_block, pack_layer, residual_gemm, round_up, self_attn_block)
 from .synth import NARShape
 from .tables import log_eps, nar_step_consts, reverse_schedule, sine_pe, timestep_inputs
 
@@ -227,9 +226,44 @@ class NARSession:
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
             self.xa = [cross_memory_table(mem, dev) for mem in self.mems]       # per layer, for the fused q-projection + cross-attention
+            # Deep clone: the prompt frames (row_offset of S rows) are never sampled, so in the LAST decoder layer their
+            # rows are needed only as keys / values.  That layer's queries, projections and feed-forward run on the
+            # s_out generated rows of each branch, gathered into a compact workspace (exact: every kernel is row-wise).
+            self.ws_l = None
+            so_r = round_up(self.s_out, 64)
+            if self.row_offset > 0 and 4 * so_r <= 3 * Sr and os.environ.get("M5_NAR_LASTROWS", "1") != "0":
+                self.ws_l = SeqWorkspace(nb, self.s_out, D, FF, dt, dev, row_pad=64)
+                self.x_l = torch.zeros(nb, so_r, D, dtype=torch.float32, device=dev)
+                self.hf_l = torch.zeros(nb * so_r, D, dtype=torch.float32, device=dev)
         self.graph = None
 
     # ----------------------------------------------------------------------------- step
+    def _last_layer_compact(self, lw, mem, normed: bool, st: int) -> None:
+        """The last decoder layer + final LayerNorm for the generated rows only (see prepare_loop): keys / values come
+        from ALL rows, queries and everything after the attention from rows row_offset..S-1 of each branch."""
+        mdl, s = self.m, self.m.shape
+        S, Sr, nb, D, H = self.S, self.Sr, self.nb, s.dim, s.dim // 64
+        ws, wl = self.ws, self.ws_l
+        so, so_r, off = self.s_out, wl.Sr, self.row_offset
+        hx = self.h.view(nb * Sr, D)
+        if not normed:
+            ops.layernorm(hx, lw.n1_w, lw.n1_b, LAYERNORM_EPS, ws.xn, stream=st)
+        ops.gemm(ws.xn, lw.in_w, None, L.EPI_QKV, bias=lw.in_b, scatter=ws.scatter(), stream=st)
+        a = ws.self_attn_args(None)
+        a.q = ws.q.data_ptr() + off * 64 * ws.q.element_size()          # queries row_offset.. of every (branch, head)
+        a.Sq = so
+        a.o, a.o_bs = wl.att.data_ptr(), so_r * D
+        ops.attention(ws.dt, a, stream=st)
+        with torch.cuda.stream(self.stream):                              # same stream: captured into the step graph
+            self.x_l[:, :so].copy_(self.h[:, off:S])
+            if so_r > so:
+                self.x_l[:, so:].zero_()                                  # pad rows: finite, never read as keys
+        xl = self.x_l.view(nb * so_r, D)
+        residual_gemm(wl.att, lw.out_w, xl, lw.out_b, wl, None, st)
+        cross_attn_block(xl, lw, wl, mem, self.step_ptr, st)
+        ff_block(xl, lw, wl, lw.n3_w, lw.n3_b, st)
+        ops.layernorm(xl, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf_l, stream=st)
+
     def enqueue_forward(self, st: int) -> None:
         """x_t -> logits for both guidance branches (the loop body's GEMM/attention work)."""
         mdl, s = self.m, self.m.shape
@@ -253,14 +287,22 @@ class NARSession:
             ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
                               rows=S, stream=st)
             normed, l0 = False, 0
+        compact = self.ws_l is not None and len(layers) >= 1
         for k, (lw, mem) in enumerate(layers):
             l = l0 + k                                         # every LayerNorm but the first rides on the residual GEMM before it
+            if compact and l == len(mdl.dec) - 1:
+                self._last_layer_compact(lw, mem, normed, st)
+                break
             nxt = (mdl.dec[l + 1].n1_w, mdl.dec[l + 1].n1_b) if l + 1 < len(mdl.dec) else None
             normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l])
-        ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         so = self.s_out
+        if compact:
+            hf, hrow = self.hf_l, [b * self.ws_l.Sr for b in range(nb)]
+        else:
+            ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
+            hf, hrow = self.hf, [b * Sr + self.row_offset for b in range(nb)]
         for b in range(nb):
-            ops.layernorm(self.hf[b * Sr + self.row_offset:], mdl.head_g, mdl.head_b, 1e-5, self.hn[:, b * so:], n_affine=Q - 1,
+            ops.layernorm(hf[hrow[b]:], mdl.head_g, mdl.head_b, 1e-5, self.hn[:, b * so:], n_affine=Q - 1,
                           affine_stride=D, y_affine_stride=nb * so * D, M=so, stream=st)
         ops.gemm(self.hn[0], mdl.head_w[0], self.logits, L.EPI_F32, bias=mdl.head_bias, ldc=(Q - 1) * self.Kp, batch=Q - 1,
                  sA=nb * so * D, sW=s.n_quant * D, sC=self.Kp, sBias=s.n_quant, stream=st)
