@@ -15,7 +15,7 @@ def main():
     m, bundle = bench.build_model("bf16", dev)
     eng = m.codecnar.engine()
     ref_codes = synth.make_ref_codes(450, seed=7).to(dev)
-    S, off, Le = 1349, 450, 39
+    S, off, Le = 1349, 899, 39          # bench shapes: 450 + 449 prompt frames, 450 generated
     g = torch.Generator().manual_seed(3)
     x = torch.randint(0, 1025, (S, 8), generator=g)
     c_text = torch.randint(0, eng.shape.n_text_vocab, (Le - 1,), generator=g)
