@@ -1,7 +1,8 @@
-"""Host-side silence trim (behaviour of ``librosa.effects.trim`` as used by reference
-``mars5/trim.py:110-178`` with its defaults: frame_length 2048, hop_length 512, centred
-reflect padding, ref = max) and weight-norm removal (reference ``mars5/utils.py:45-62``).
-CPU post-processing after the vocoder -- out of the accelerated path."""
+"""Host-side silence trim (behaviour of reference ``mars5/trim.py:110-178`` -- librosa's ``effects.trim`` carried
+over to torch -- with its defaults: frame_length 2048, hop_length 512, centred REFLECT padding, mono = mean over
+channels, power in dB relative to the loudest frame, fp32) and weight-norm removal (reference ``mars5/utils.py:45-62``).
+CPU post-processing after the vocoder -- out of the accelerated path; checked against the reference's
+output in ``tests/test_oracle_golden.py::test_trim_matches_reference``."""
 from __future__ import annotations
 
 import logging
@@ -9,38 +10,34 @@ from typing import Tuple
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 
-def _frame_rms(y: np.ndarray, frame_length: int, hop_length: int) -> np.ndarray:
+def _frame_power(y: torch.Tensor, frame_length: int, hop_length: int) -> torch.Tensor:
+    """Mean power of every analysis frame of the (mono) signal, centred frames with reflect padding
+    (reference ``rms`` with center=True, trim.py:255-263, squared)."""
     pad = frame_length // 2
-    yp = np.pad(y, [(0, 0)] * (y.ndim - 1) + [(pad, pad)], mode="constant")
-    n = 1 + (yp.shape[-1] - frame_length) // hop_length
-    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(n)[:, None]
-    frames = yp[..., idx]                                   # (..., n, frame_length)
-    return np.sqrt(np.mean(np.abs(frames) ** 2, axis=-1))   # (..., n)
+    yp = F.pad(y[None, None], (pad, pad), mode="reflect")[0, 0]
+    frames = yp.unfold(0, frame_length, hop_length)          # (n_frames, frame_length)
+    return torch.mean(frames.abs() ** 2, dim=-1)
 
 
-def trim(y, top_db: float = 60, ref=np.max, frame_length: int = 2048, hop_length: int = 512, aggregate=np.max) -> Tuple[torch.Tensor, np.ndarray]:
-    """Trim leading / trailing silence: frames whose RMS is more than `top_db` dB below `ref`
-    (of the RMS curve) are silent.  Returns (trimmed signal, [start, end] sample interval)."""
-    is_tensor = isinstance(y, torch.Tensor)
-    arr = y.detach().cpu().numpy() if is_tensor else np.asarray(y)
-    mse = _frame_rms(arr.astype(np.float64), frame_length, hop_length)
-    amin = 1e-5
-    magnitude = np.abs(mse)
-    ref_value = np.abs(ref(magnitude)) if callable(ref) else np.abs(ref)
-    db = 20.0 * np.log10(np.maximum(amin, magnitude)) - 20.0 * np.log10(np.maximum(amin, ref_value))
-    non_silent = db > -top_db
-    if non_silent.ndim > 1:
-        non_silent = np.apply_over_axes(aggregate, non_silent, range(non_silent.ndim - 1)).reshape(-1)
-    nz = np.flatnonzero(non_silent)
-    if nz.size > 0:
-        start = int(nz[0] * hop_length)
-        end = min(arr.shape[-1], int((nz[-1] + 1) * hop_length))
+def trim(y, top_db: float = 60, ref=torch.max, frame_length: int = 2048, hop_length: int = 512) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Trim leading / trailing silence: frames whose power is more than `top_db` dB below `ref` (of the frame
+    powers; a callable or a number) are silent.  y: (n,) or (channels, n).  Returns (y[..., start:end], [start, end])."""
+    yt = y if isinstance(y, torch.Tensor) else torch.as_tensor(np.asarray(y))
+    mono = torch.mean(yt, dim=0) if yt.dim() > 1 else yt
+    power = _frame_power(mono.to(torch.float32), frame_length, hop_length)
+    amin = torch.tensor(1e-10)
+    ref_value = ref(power) if callable(ref) else torch.abs(torch.as_tensor(ref, dtype=torch.float32))
+    db = 10.0 * torch.log10(torch.maximum(amin, power)) - 10.0 * torch.log10(torch.maximum(amin, ref_value))
+    nz = torch.nonzero(db > -top_db).reshape(-1)
+    if nz.numel() > 0:
+        start = int(nz[0]) * hop_length                      # end goes one frame past the last non-silent one
+        end = min(int(yt.shape[-1]), (int(nz[-1]) + 1) * hop_length)
     else:
         start, end = 0, 0
-    out = arr[..., start:end]
-    return (torch.from_numpy(np.ascontiguousarray(out)) if is_tensor else out), np.asarray([start, end])
+    return yt[..., start:end], torch.tensor([start, end])
 
 
 def nuke_weight_norm(module) -> None:

@@ -228,11 +228,41 @@ def gen_nar(tag, b, nar, tt, ar_tokens, first_idx, ref_codes, text_tokens, st, d
     np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **fx)
 
 
+def gen_trim():
+    """Silence trim after the vocoder (reference mars5/trim.py:110-178, called at inference.py:306 with trim_db = 27):
+    synthetic 24 kHz waveforms (silence / tone bursts / decaying noise / all-zero / stereo) through the reference."""
+    import mars5.trim as ref_trim_mod
+    from mars5.trim import trim as ref_trim
+
+    class _Np1:   # the reference targets NumPy 1.x: np.array(x, copy=False) meant "copy only if needed" (= np.asarray in 2.x)
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        @staticmethod
+        def array(obj, *a, copy=True, subok=False, **k):
+            return (np.asanyarray(obj, *a, **k) if subok else np.asarray(obj, *a, **k)) if copy is False else np.array(obj, *a, copy=copy, subok=subok, **k)
+
+    ref_trim_mod.np = _Np1()                                                  # the reference's own source runs unmodified
+    cases, outs = [], {}
+    for i, w in enumerate(O.trim_test_waves()):
+        for top_db in (27, 60, 10):
+            yt, idx = ref_trim(w.clone(), top_db=top_db)
+            outs[f"idx_{i}_{top_db}"] = idx.numpy().astype(np.int64)
+            outs[f"sum_{i}_{top_db}"] = np.float64(yt.double().abs().sum())
+            cases.append((i, top_db))
+    np.savez_compressed(os.path.join(GOLD, "trim_cases.npz"), cases=np.array(cases, dtype=np.int64), **outs)
+    print("trim fixture:", len(cases), "cases")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the full-size (1536/1024-dim) fixtures")
+    ap.add_argument("--only", default=None, choices=[None, "trim"], help="regenerate a single fixture")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
+    if args.only == "trim":
+        gen_trim()
+        return
     torch.set_num_threads(8)
     greedy = dict(temperature=0.7, topk=1, top_p=0.2, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4,
                   penalty_window=80, eos_penalty_decay=0.5, eos_penalty_factor=1.0)
@@ -258,6 +288,7 @@ def main():
     lmw, _ = ref_models(bw)
     gen_ar("ar_tiny_window48_shallow", bw, lmw, tt, st, 40, 100, False, dict(greedy, eos_penalty_factor=50.0, eos_penalty_decay=0.0), 1234, True)
     gen_nar("nar_tiny_shallow", b, nar, tt, out, fi, rc, ttk, st, False, 4, 4321, False)
+    gen_trim()
 
     if args.full:
         bf = synth.make_bundle("full", seed=0)

@@ -542,3 +542,24 @@ def parse_ar_output(ar_codes: Tensor, n_text: int, first_codec_idx: int, expansi
     for tk in toks:
         frames.extend(expansion[tk])
     return torch.tensor(frames, dtype=torch.long)
+
+
+# ----------------------------------------------------------------------------- trim test inputs
+def trim_test_waves() -> List[Tensor]:
+    """Deterministic 24 kHz waveforms for the silence-trim fixture (``tests/golden/trim_cases.npz`` holds what the
+    reference's ``mars5/trim.py:110-178`` returns for them; generator: ``oracle/gen_golden.py --only trim``)."""
+    g = torch.Generator().manual_seed(77)
+    sr = 24000
+    t = torch.arange(sr * 2) / sr
+    waves = []
+    w = torch.zeros(sr * 2)
+    w[9000:30000] = 0.5 * torch.sin(2 * math.pi * 220 * t[9000:30000])
+    waves.append(w)                                                            # silence - tone - silence
+    w = 1e-3 * torch.randn(sr * 2, generator=g)
+    w[20000:26000] += 0.8 * torch.sin(2 * math.pi * 440 * t[20000:26000])
+    waves.append(w)                                                            # noise floor 58 dB below a burst
+    waves.append(torch.randn(sr * 2, generator=g) * torch.exp(-t * 6))          # decaying noise (trailing trim only)
+    waves.append(torch.zeros(5000))                                            # all zeros -> empty
+    waves.append(0.3 * torch.randn(3000, generator=g))                          # shorter than two frames
+    waves.append(torch.stack([waves[0], 0.5 * waves[1]]))                      # stereo: mean over channels decides
+    return waves

@@ -130,3 +130,20 @@ def test_diffusion_tables_sanity():
     # the reference's own asserts (diffuser.py:87-89)
     assert float(O.log_add_exp(tb.log_alpha.double(), tb.log_1_min_alpha.double()).abs().sum()) < 1e-4
     assert float(O.log_add_exp(tb.log_cumprod_alpha.double(), tb.log_1_min_cumprod_alpha.double()).abs().sum()) < 1e-4
+
+
+def test_trim_matches_reference(gold_dir):
+    """Host-side silence trim (the last step of ``tts()``, reference inference.py:306 with trim_db = 27) against what
+    the reference's ``mars5/trim.py:110-178`` returned for the same deterministic waveforms: same [start, end]
+    interval and the same samples, for mono / stereo / all-zero / very short inputs at three thresholds."""
+    import mars5_oracle as O
+    from mars5_tts_amd.trim import trim
+    fx = np.load(os.path.join(gold_dir, "trim_cases.npz"))
+    waves = O.trim_test_waves()
+    assert len(fx["cases"]) == 3 * len(waves)
+    for i, top_db in fx["cases"].tolist():
+        y, idx = trim(waves[i].clone(), top_db=top_db)
+        ref_idx = fx[f"idx_{i}_{top_db}"].tolist()
+        assert list(np.asarray(idx).tolist()) == ref_idx, f"wave {i} top_db {top_db}: {idx} vs reference {ref_idx}"
+        assert torch.equal(y, waves[i][..., ref_idx[0]:ref_idx[1]])
+        assert abs(float(y.double().abs().sum()) - float(fx[f"sum_{i}_{top_db}"])) <= 1e-9 * max(1.0, float(fx[f"sum_{i}_{top_db}"]))
