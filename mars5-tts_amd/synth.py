@@ -248,6 +248,11 @@ class SynthBundle:
     n_speech: int = field(default=0)
 
 
+def make_vocab(text_merges: int, speech_merges: int) -> Dict[str, str]:
+    """The checkpoint's ``vocab`` entry alone (tokenizer model texts), without any weights."""
+    return {"texttok.model": make_text_tokenizer_model(text_merges), "speechtok.model": make_speech_tokenizer_model(speech_merges)}
+
+
 def make_bundle(size: str = "tiny", seed: int = 0, text_merges: int = None, speech_merges: int = None,
                 dtype_round: str = None, sliding_window: int = None) -> SynthBundle:
     """size 'tiny' (CPU-test scale) or 'full' (the real MARS5 geometry, n_vocab 4096).

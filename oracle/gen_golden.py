@@ -228,6 +228,27 @@ def gen_nar(tag, b, nar, tt, ar_tokens, first_idx, ref_codes, text_tokens, st, d
     np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **fx)
 
 
+def gen_tokenizers():
+    """Text (regex BPE) and speech (codebook BPE) tokenizers of the reference (mars5/minbpe/{regex,codebook}.py) on
+    awkward strings -- contractions, digit runs, whitespace runs, non-ASCII, special tokens in the text -- for three
+    synthetic vocabularies (tiny, the bench's, and one with 1023 speech merges); encode, decode round trip, decode_int."""
+    out = {}
+    for size, (tm, sm) in O.TOKENIZER_TEST_VOCABS.items():
+        tt, st = ref_tokenizers(synth.make_vocab(tm, sm))
+        for i, sx in enumerate(O.TOKENIZER_TEST_STRINGS):
+            ids = tt.encode(sx, allowed_special="all")
+            out[f"{size}_text_{i}"] = np.array(ids, dtype=np.int64)
+            out[f"{size}_text_{i}_dec"] = np.frombuffer(tt.decode(ids).encode("utf-8"), dtype=np.uint8)
+            ids_o = tt.encode_ordinary(sx)
+            out[f"{size}_text_{i}_ord"] = np.array(ids_o, dtype=np.int64)
+        for i, cs in enumerate(O.tokenizer_test_code_strings()):
+            ids = st.encode(cs)
+            out[f"{size}_code_{i}"] = np.array(ids, dtype=np.int64)
+            out[f"{size}_code_{i}_int"] = np.array(st.decode_int(ids), dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, "tokenizer_cases.npz"), **out)
+    print("tokenizer fixture:", len(out), "arrays")
+
+
 def gen_trim():
     """Silence trim after the vocoder (reference mars5/trim.py:110-178, called at inference.py:306 with trim_db = 27):
     synthetic 24 kHz waveforms (silence / tone bursts / decaying noise / all-zero / stereo) through the reference."""
@@ -257,11 +278,14 @@ def gen_trim():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the full-size (1536/1024-dim) fixtures")
-    ap.add_argument("--only", default=None, choices=[None, "trim"], help="regenerate a single fixture")
+    ap.add_argument("--only", default=None, choices=[None, "trim", "tokenizers"], help="regenerate a single fixture")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     if args.only == "trim":
         gen_trim()
+        return
+    if args.only == "tokenizers":
+        gen_tokenizers()
         return
     torch.set_num_threads(8)
     greedy = dict(temperature=0.7, topk=1, top_p=0.2, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4,
@@ -289,6 +313,7 @@ def main():
     gen_ar("ar_tiny_window48_shallow", bw, lmw, tt, st, 40, 100, False, dict(greedy, eos_penalty_factor=50.0, eos_penalty_decay=0.0), 1234, True)
     gen_nar("nar_tiny_shallow", b, nar, tt, out, fi, rc, ttk, st, False, 4, 4321, False)
     gen_trim()
+    gen_tokenizers()
 
     if args.full:
         bf = synth.make_bundle("full", seed=0)

@@ -563,3 +563,35 @@ def trim_test_waves() -> List[Tensor]:
     waves.append(0.3 * torch.randn(3000, generator=g))                          # shorter than two frames
     waves.append(torch.stack([waves[0], 0.5 * waves[1]]))                      # stereo: mean over channels decides
     return waves
+
+
+# ----------------------------------------------------------------------------- tokenizer test inputs
+TOKENIZER_TEST_STRINGS = [
+    "The quick brown rat.",
+    "We actually haven't managed to meet demand this year, I'm told; they'd've tried!",
+    "  leading and   multiple   spaces\tand\ttabs\nnew lines\r\n  ",
+    "Numbers 1 22 333 4444 55555 and 3.14159, 1,000,000; 2024-08-07 at 12:30pm.",
+    "Unicode: naïve café — “quotes” … ellipsis, ß, Ωmega, 北京, 🙂 emoji, e\u0301 combining.",
+    "CamelCaseWords and snake_case_words and SHOUTING and x86_64 and C++/C# #hashtag @user http://a.b/c?d=e&f=g",
+    "'s 't 're 've 'm 'll 'd contractions at start; O'Neil's it's IT'S",
+    "<|startoftext|>special tokens <|endoftext|> inside <|startoftext|> text<|endoftext|>",
+    "",
+    " ",
+    "a",
+    "!!!???...,,,;;;:::---___***(((]]]}}}",
+]
+
+
+TOKENIZER_TEST_VOCABS = {"tiny": (30, 63), "full": (2813, 0), "merged": (1790, 1023)}     # (text merges, speech merges)
+
+
+def tokenizer_test_code_strings() -> List[str]:
+    """Codebook-tokenizer inputs: space-separated code strings (what inference.py:237-238 builds from the L0 codes)."""
+    g = torch.Generator().manual_seed(31)
+    out = []
+    for n in (1, 2, 7, 40, 150):
+        out.append(" ".join(str(int(v)) for v in torch.randint(0, 1024, (n,), generator=g)))
+    from mars5_tts_amd import synth                       # merge-friendly sequences exercise the BPE merges
+    out.append(" ".join(str(v) for v in synth.speech_corpus_codes(120, seed=5)))
+    out.append(" ".join(str(v) for v in synth.speech_corpus_codes(33, seed=9)))
+    return out

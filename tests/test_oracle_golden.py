@@ -147,3 +147,30 @@ def test_trim_matches_reference(gold_dir):
         assert list(np.asarray(idx).tolist()) == ref_idx, f"wave {i} top_db {top_db}: {idx} vs reference {ref_idx}"
         assert torch.equal(y, waves[i][..., ref_idx[0]:ref_idx[1]])
         assert abs(float(y.double().abs().sum()) - float(fx[f"sum_{i}_{top_db}"])) <= 1e-9 * max(1.0, float(fx[f"sum_{i}_{top_db}"]))
+
+
+def test_tokenizers_match_reference_on_awkward_strings(gold_dir):
+    """Host BPE tokenizers (``mars5-tts_amd/minbpe.py``) vs the reference's (mars5/minbpe/{regex,codebook}.py) on
+    contractions, digit runs, whitespace runs, non-ASCII text, special tokens inside the text, and code strings with
+    and without applicable merges, for three synthetic vocabularies: ids, decode round trip, decode_int, and the
+    expansion table the AR -> NAR hand-off uses."""
+    import mars5_oracle as O
+    from mars5_tts_amd import minbpe, synth
+    fx = np.load(os.path.join(gold_dir, "tokenizer_cases.npz"))
+    for size, (tm, sm) in O.TOKENIZER_TEST_VOCABS.items():
+        vocab = synth.make_vocab(tm, sm)
+        tt = minbpe.RegexTokenizer()
+        tt.load(io.BytesIO(vocab["texttok.model"].encode()))
+        st = minbpe.CodebookTokenizer()
+        st.load(io.BytesIO(vocab["speechtok.model"].encode()))
+        for i, sx in enumerate(O.TOKENIZER_TEST_STRINGS):
+            ids = tt.encode(sx, allowed_special="all")
+            assert ids == fx[f"{size}_text_{i}"].tolist(), f"{size} text {i}: {sx!r}"
+            assert tt.encode_ordinary(sx) == fx[f"{size}_text_{i}_ord"].tolist(), f"{size} text {i} (ordinary)"
+            assert tt.decode(ids).encode("utf-8") == fx[f"{size}_text_{i}_dec"].tobytes(), f"{size} text {i}: decode"
+        exp = st.expansion_table()
+        for i, cs in enumerate(O.tokenizer_test_code_strings()):
+            ids = st.encode(cs)
+            assert ids == fx[f"{size}_code_{i}"].tolist(), f"{size} codes {i}"
+            assert st.decode_int(ids) == fx[f"{size}_code_{i}_int"].tolist()
+            assert [c for t in ids for c in exp[t]] == fx[f"{size}_code_{i}_int"].tolist()
