@@ -189,12 +189,17 @@ class Mars5TTS:
     @torch.inference_mode()
     def tts_from_codes(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str],
                        cfg: InferenceConfig = InferenceConfig(), ar_noise: Optional[Tensor] = None,
-                       generator: Optional[torch.Generator] = None) -> Tuple[Tensor, Tensor]:
+                       generator: Optional[torch.Generator] = None, rng_hooks=None) -> Tuple[Tensor, Tensor]:
         """``tts`` between the codec and the vocoder (reference inference.py:222-301):
-        prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out."""
+        prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out.
+        `rng_hooks` (parity tests): an object with ar_noise(n_steps, V), after_ar(n_iterations), randint(shape),
+        uniform(shape) that supplies every random draw instead of the device generator (oracle/fakes.py)."""
         T = self.default_T
         diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
         pr = self._prompt(text, prompt_codec, ref_transcript, cfg)
+        if rng_hooks is not None:
+            n_steps = self._ar_kwargs(cfg)["max_len"] - int(pr["prompt"].shape[0])
+            ar_noise = rng_hooks.ar_noise(max(n_steps, 1), self.n_vocab)
         # the NAR stage's conditioning work (text encoder for all 200 steps, cross-attention K / V) does not depend on the
         # AR output: enqueue it on the NAR stream now, it runs beside the AR decode
         nar_sess = begin_inference(self.codecnar, torch.tensor(pr["text_tokens"], dtype=torch.long, device=self.device)[None],
@@ -204,8 +209,13 @@ class Mars5TTS:
                                n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
                                generator=generator, **self._ar_kwargs(cfg))
         gen_codes_decoded, batch, skip_front = self._handoff(pr, ar_codes, cfg)
+        hook_kw = {}
+        if rng_hooks is not None:
+            n_gen = int(ar_codes.shape[0]) - int(pr["prompt"].shape[0])
+            rng_hooks.after_ar(n_gen + (1 if int(ar_codes.shape[0]) < self._ar_kwargs(cfg)["max_len"] else 0))
+            hook_kw = dict(uniform=rng_hooks.uniform, randint=rng_hooks.randint)
         final_output = perform_simple_inference(self.codecnar, batch, diff, diff.num_timesteps, torch.float16, dsh=self._dsh(cfg),
-                                                retain_quant0=True, generator=generator, session=nar_sess)
+                                                retain_quant0=True, generator=generator, session=nar_sess, **hook_kw)
         final_output = final_output[0, skip_front:].to(self.device)
         return gen_codes_decoded, final_output
 
@@ -263,7 +273,7 @@ class Mars5TTS:
 
     @torch.inference_mode()
     def tts(self, text: str, ref_audio: Tensor, ref_transcript: Optional[str] = None,
-            cfg: Optional[InferenceConfig] = InferenceConfig()) -> Tuple[Tensor, Tensor]:
+            cfg: Optional[InferenceConfig] = InferenceConfig(), rng_hooks=None) -> Tuple[Tensor, Tensor]:
         """ Perform TTS for `text`, given a reference audio `ref_audio` (of shape [sequence_length,], sampled at 24kHz)
         which has an associated `ref_transcript`.  Returns `ar_codes` (seq_len,) and `out_wav` (T,) at 24kHz. """
         if cfg.deep_clone and ref_transcript is None:
@@ -281,7 +291,7 @@ class Mars5TTS:
             ref_audio = ref_audio.mean(dim=0, keepdim=True)
         ref_audio = F.pad(ref_audio, (int(self.sr * cfg.ref_audio_pad), 0))
         prompt_codec = self.codec.encode(ref_audio[None].to(self.device))[0][0]
-        gen_codes_decoded, final_output = self.tts_from_codes(text, prompt_codec, ref_transcript, cfg)
+        gen_codes_decoded, final_output = self.tts_from_codes(text, prompt_codec, ref_transcript, cfg, rng_hooks=rng_hooks)
         final_audio = self.vocode(final_output).squeeze()
         final_audio, _ = trim(final_audio.cpu(), top_db=cfg.trim_db)
         return gen_codes_decoded, final_audio

@@ -249,13 +249,54 @@ def gen_tokenizers():
     print("tokenizer fixture:", len(out), "arrays")
 
 
-def gen_trim():
-    """Silence trim after the vocoder (reference mars5/trim.py:110-178, called at inference.py:306 with trim_db = 27):
-    synthetic 24 kHz waveforms (silence / tone bursts / decaying noise / all-zero / stereo) through the reference."""
-    import mars5.trim as ref_trim_mod
-    from mars5.trim import trim as ref_trim
+def gen_tts():
+    """The reference's OWN ``inference.py`` (``Mars5TTS.tts``, inference.py:201-307) end to end on CPU: full-size
+    synthetic checkpoints, deep clone, README sampling settings, the global CPU generator seeded once.  Encodec and
+    Vocos are replaced by the deterministic stand-ins of ``oracle/fakes.py`` (injected as the ``encodec`` / ``vocos``
+    modules the reference imports), everything between them runs unmodified."""
+    import importlib.util
+    import fakes
+    enc_mod, voc_mod = types.ModuleType("encodec"), types.ModuleType("vocos")
 
-    class _Np1:   # the reference targets NumPy 1.x: np.array(x, copy=False) meant "copy only if needed" (= np.asarray in 2.x)
+    class EncodecModel:
+        @staticmethod
+        def encodec_model_24khz():
+            return fakes.FakeCodec()
+
+    class Vocos:
+        @staticmethod
+        def from_pretrained(name):
+            return fakes.FakeVocos()
+
+    enc_mod.EncodecModel, voc_mod.Vocos = EncodecModel, Vocos
+    sys.modules["encodec"], sys.modules["vocos"] = enc_mod, voc_mod
+    _np1_shim()
+    spec = importlib.util.spec_from_file_location("ref_inference", "/root/reference/inference.py")
+    ref_inf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_inf)
+    b = synth.make_bundle("full", seed=0)
+    m = ref_inf.Mars5TTS(b.ar_ckpt, b.nar_ckpt, device="cpu")
+    out = {}
+    cases = [dict(text="Hi there.", transcript="We meet.", ref_frames=24, max_len=64, seed=2024, deep=True),
+             dict(text="Rats!", transcript="", ref_frames=30, max_len=20, seed=7, deep=False)]
+    for i, c in enumerate(cases):
+        cfg = ref_inf.InferenceConfig(deep_clone=c["deep"], temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
+                                      generate_max_len_override=c["max_len"])
+        ref_audio = torch.zeros(320 * c["ref_frames"])
+        torch.manual_seed(c["seed"])
+        gen, wav = m.tts(c["text"], ref_audio, c["transcript"], cfg)
+        final = m.vocos.last_tokens.T.contiguous()                          # (S_out, 8): what tts() handed to the vocoder
+        out[f"gen_{i}"], out[f"wav_{i}"], out[f"final_{i}"] = gen.numpy(), wav.numpy(), final.numpy()
+        print(f"[tts {i}] generated {gen.shape[0]} frames, final {tuple(final.shape)}, audio {wav.shape[-1]} samples")
+    np.savez_compressed(os.path.join(GOLD, "tts_full.npz"), cases=np.array([json.dumps(c) for c in cases]), **out)
+
+
+def _np1_shim():
+    """The reference's trim.py targets NumPy 1.x: np.array(x, copy=False) meant "copy only if needed" (= np.asarray in
+    2.x).  Give ITS module namespace that meaning so the reference source runs unmodified."""
+    import mars5.trim as ref_trim_mod
+
+    class _Np1:
         def __getattr__(self, name):
             return getattr(np, name)
 
@@ -263,7 +304,14 @@ def gen_trim():
         def array(obj, *a, copy=True, subok=False, **k):
             return (np.asanyarray(obj, *a, **k) if subok else np.asarray(obj, *a, **k)) if copy is False else np.array(obj, *a, copy=copy, subok=subok, **k)
 
-    ref_trim_mod.np = _Np1()                                                  # the reference's own source runs unmodified
+    ref_trim_mod.np = _Np1()
+
+
+def gen_trim():
+    """Silence trim after the vocoder (reference mars5/trim.py:110-178, called at inference.py:306 with trim_db = 27):
+    synthetic 24 kHz waveforms (silence / tone bursts / decaying noise / all-zero / stereo) through the reference."""
+    from mars5.trim import trim as ref_trim
+    _np1_shim()
     cases, outs = [], {}
     for i, w in enumerate(O.trim_test_waves()):
         for top_db in (27, 60, 10):
@@ -278,7 +326,7 @@ def gen_trim():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the full-size (1536/1024-dim) fixtures")
-    ap.add_argument("--only", default=None, choices=[None, "trim", "tokenizers"], help="regenerate a single fixture")
+    ap.add_argument("--only", default=None, choices=[None, "trim", "tokenizers", "tts"], help="regenerate a single fixture")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     if args.only == "trim":
@@ -286,6 +334,9 @@ def main():
         return
     if args.only == "tokenizers":
         gen_tokenizers()
+        return
+    if args.only == "tts":
+        gen_tts()
         return
     torch.set_num_threads(8)
     greedy = dict(temperature=0.7, topk=1, top_p=0.2, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4,
@@ -321,6 +372,8 @@ def main():
         lmf, narf = ref_models(bf)
         out, fi, rc, ttk = gen_ar("ar_full_greedy_deep", bf, lmf, ttf, stf, 24, 16, True, greedy, 1234, False)
         gen_nar("nar_full_deep", bf, narf, ttf, out, fi, rc, ttk, stf, True, 2, 4321, False)
+        del lmf, narf
+        gen_tts()
 
     meta = dict(torch=torch.__version__, device="cpu", reference="Camb-ai/MARS5-TTS @ 2024_08_07",
                 text=TEXT, transcript=TRANSCRIPT, note="generated by oracle/gen_golden.py from the unmodified reference")

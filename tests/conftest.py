@@ -24,3 +24,10 @@ def gold_dir():
 def tiny_bundle():
     from mars5_tts_amd import synth
     return synth.make_bundle("tiny", seed=0)
+
+
+@pytest.fixture(scope="session")
+def full_bundle():
+    """Seeded random checkpoints of the real MARS5 geometry (takes ~20 s of host time: built once per session)."""
+    from mars5_tts_amd import synth
+    return synth.make_bundle("full", seed=0)

@@ -292,12 +292,12 @@ def test_nar_tiny_reduced_precision_logits(dev, dt):
     assert ec < tol and eu < tol
 
 
-def test_full_size_goldens_f32(dev, gold_dir):
+def test_full_size_goldens_f32(dev, gold_dir, full_bundle):
     """The real MARS5 geometry (1536-d x 26 layers AR, 1024-d 8+16 layers NAR) with seeded
     weights regenerated on this host: fp32 engine vs tokens produced by the reference."""
     from mars5_tts_amd import synth
     from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_simple_inference
-    b = synth.make_bundle("full", seed=0)
+    b = full_bundle
     tt, st = _toks(b)
     fx = np.load(os.path.join(gold_dir, "ar_full_greedy_deep.npz"))
     lm = _lm(b, torch.float32, dev)
@@ -480,14 +480,14 @@ def test_ar_batch_tiny_f32_matches_reference_tokens(dev, tiny_bundle, gold_dir):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16])
-def test_ar_batch_full_size_vs_single(dev, dt):
+def test_ar_batch_full_size_vs_single(dev, dt, full_bundle):
     """Full-size geometry, 16-bit operands: the batched step (skinny GEMMs) against the batch-1 GEMV path on
     the same prompts and noise.  The two differ only by fp32 summation order inside the projections, so the
     logits of the first steps must agree to dtype tolerance and greedy tokens may first differ only late /
     at near-ties; the statistic is printed, the logit agreement is asserted."""
     from mars5_tts_amd import synth
     from mars5_tts_amd.ar_engine import ARBatchSession, ARSamplingConfig, ARSession
-    b = synth.make_bundle("full", seed=0)
+    b = full_bundle
     lm = _lm(b, dt, dev)
     tt, st = _toks(b)
     eng = lm.engine()
@@ -556,3 +556,36 @@ def test_ar_batch_full_size_vs_single(dev, dt):
         assert o.shape == r.shape and torch.equal(o[:P], r[:P])
         agree.append(next((j - P for j in range(P, o.shape[0]) if int(o[j]) != int(r[j])), n_gen))
     print(f"batched vs batch-1: worst rel logit diff {worst:.2e}; greedy tokens agree for the first {agree} of {n_gen} steps")
+
+
+def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle):
+    """The public ``Mars5TTS.tts()`` against the reference's OWN ``inference.py`` (fixture: the unmodified reference on
+    CPU, full-size seeded weights, deep and shallow clone, README sampling settings; Encodec / Vocos replaced on both
+    sides by the deterministic stand-ins of oracle/fakes.py).  fp32 engine, the reference's CPU random stream replayed
+    draw by draw: the AR frames must be identical, the final codes identical up to the rare libm-ulp near-tie of the
+    free-running diffusion (<= 2 %), and when they are identical so is the trimmed waveform."""
+    import json as _json
+    import fakes
+    from inference import InferenceConfig, Mars5TTS
+    from mars5_tts_amd import synth
+    fx = np.load(os.path.join(gold_dir, "tts_full.npz"))
+    b = full_bundle
+    m = Mars5TTS(b.ar_ckpt, b.nar_ckpt, device=str(dev), codec=fakes.FakeCodec(), vocos=fakes.FakeVocos())
+    m.codeclm.set_engine_dtype(torch.float32)
+    m.codecnar.set_engine_dtype(torch.float32)
+    for i, cj in enumerate(fx["cases"].tolist()):
+        c = _json.loads(cj)
+        cfg = InferenceConfig(deep_clone=c["deep"], temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
+                              generate_max_len_override=c["max_len"])
+        hooks = fakes.CpuStreamHooks(c["seed"], dev)
+        gen, wav = m.tts(c["text"], torch.zeros(320 * c["ref_frames"]), c["transcript"], cfg, rng_hooks=hooks)
+        assert gen.cpu().tolist() == fx[f"gen_{i}"].tolist(), f"case {i}: AR frames differ from the reference"
+        final = m.vocos.last_tokens.T.contiguous().numpy()
+        ref_final = fx[f"final_{i}"]
+        assert final.shape == ref_final.shape
+        n_bad = int((final != ref_final).sum())
+        print(f"tts case {i}: {gen.shape[0]} frames, final codes differing from the reference: {n_bad}/{ref_final.size}")
+        assert n_bad <= 0.02 * ref_final.size
+        if n_bad == 0:
+            assert wav.shape[-1] == fx[f"wav_{i}"].shape[-1]
+            assert float((wav.cpu() - torch.from_numpy(fx[f"wav_{i}"])).abs().max()) < 1e-6
