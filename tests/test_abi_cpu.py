@@ -114,3 +114,56 @@ def test_bench_c3_requests_follow_the_survey_spec():
         assert ref.shape[0] == 1 and ref.shape[1] == 8 and 150 <= ref.shape[2] <= 900
         assert ml > 450
     assert len(set(r.shape[2] for r in a[2])) > 8          # genuinely mixed lengths
+
+
+def test_hub_entry_points_assemble_the_reference_checkpoint_dicts(tiny_bundle, tmp_path, monkeypatch):
+    """``hubconf.mars5_english`` (safetensors cache / explicit .pt paths, reference hubconf.py:17-75) and
+    ``Mars5TTS.from_pretrained`` (reference inference.py:123-158) hand ``Mars5TTS(ar_ckpt, nar_ckpt, device)`` the
+    {'vocab': {texttok.model, speechtok.model}, 'model': state_dict} dicts the reference builds -- no network: the hub
+    cache and hf_hub_download are pointed at local files."""
+    import torch
+    from safetensors.torch import save_file
+    import hubconf
+    import inference
+    b = tiny_bundle
+    seen = []
+
+    class Recorder:
+        def __init__(self, ar_ckpt, nar_ckpt, device=None, **kw):
+            seen.append((ar_ckpt, nar_ckpt, device))
+
+    def same(ck, ref):
+        assert ck["vocab"] == ref["vocab"] and set(ck["model"]) == set(ref["model"])
+        assert all(torch.equal(ck["model"][k], ref["model"][k]) for k in ref["model"])
+
+    # 1. torch.hub route, safetensors already in the hub cache (file names = the reference's release assets)
+    hub = tmp_path / "hub"
+    (hub / "checkpoints").mkdir(parents=True)
+    monkeypatch.setattr(torch.hub, "get_dir", lambda: str(hub))
+    for url, ck in ((hubconf.ar_sf_url, b.ar_ckpt), (hubconf.nar_sf_url, b.nar_ckpt)):
+        save_file({k: v.contiguous() for k, v in ck["model"].items()}, str(hub / "checkpoints" / url.rsplit("/", 1)[1]), metadata=ck["vocab"])
+    monkeypatch.setattr(hubconf, "Mars5TTS", Recorder)
+    model, cfg_cls = hubconf.mars5_english(device="cpu", ckpt_format="safetensors")
+    assert isinstance(model, Recorder) and cfg_cls is inference.InferenceConfig and seen[-1][2] == "cpu"
+    same(seen[-1][0], b.ar_ckpt)
+    same(seen[-1][1], b.nar_ckpt)
+    # 2. explicit .pt paths
+    torch.save(b.ar_ckpt, tmp_path / "ar.pt")
+    torch.save(b.nar_ckpt, tmp_path / "nar.pt")
+    hubconf.mars5_english(device="cpu", ckpt_format="pt", ar_path=tmp_path / "ar.pt", nar_path=tmp_path / "nar.pt")
+    same(seen[-1][0], b.ar_ckpt)
+    same(seen[-1][1], b.nar_ckpt)
+    with pytest.raises(AssertionError):
+        hubconf.mars5_english(pretrained=False)
+    with pytest.raises(AssertionError):
+        hubconf.mars5_english(ckpt_format="onnx")
+    # 3. huggingface route
+    import huggingface_hub
+    files = {"mars5_ar.safetensors": str(hub / "checkpoints" / hubconf.ar_sf_url.rsplit("/", 1)[1]),
+             "mars5_nar.safetensors": str(hub / "checkpoints" / hubconf.nar_sf_url.rsplit("/", 1)[1])}
+    monkeypatch.setattr(huggingface_hub, "hf_hub_download", lambda repo_id, filename, **kw: files[filename])
+    got = []
+    monkeypatch.setattr(inference.Mars5TTS, "__init__", lambda self, ar_ckpt, nar_ckpt, device=None, **kw: got.append((ar_ckpt, nar_ckpt, device)))
+    inference.Mars5TTS.from_pretrained("CAMB-AI/MARS5-TTS", device="cpu")
+    same(got[-1][0], b.ar_ckpt)
+    same(got[-1][1], b.nar_ckpt)
