@@ -276,7 +276,7 @@ def gen_tts():
     spec.loader.exec_module(ref_inf)
     b = synth.make_bundle("full", seed=0)
     m = ref_inf.Mars5TTS(b.ar_ckpt, b.nar_ckpt, device="cpu")
-    out = {}
+    out = {"spk_emb_24": m.get_speaker_embedding(torch.zeros(320 * 24)).numpy()}        # inference.py:174-199
     cases = [dict(text="Hi there.", transcript="We meet.", ref_frames=24, max_len=64, seed=2024, deep=True),
              dict(text="Rats!", transcript="", ref_frames=30, max_len=20, seed=7, deep=False)]
     for i, c in enumerate(cases):

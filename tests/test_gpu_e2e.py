@@ -573,6 +573,10 @@ def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle)
     m = Mars5TTS(b.ar_ckpt, b.nar_ckpt, device=str(dev), codec=fakes.FakeCodec(), vocos=fakes.FakeVocos())
     m.codeclm.set_engine_dtype(torch.float32)
     m.codecnar.set_engine_dtype(torch.float32)
+    emb = m.get_speaker_embedding(torch.zeros(320 * 24)).cpu()                      # reference inference.py:174-199
+    ref_emb = torch.from_numpy(fx["spk_emb_24"])
+    assert emb.shape == ref_emb.shape == (1, 1536)
+    assert float((emb - ref_emb).abs().max() / ref_emb.abs().max()) < 1e-4
     for i, cj in enumerate(fx["cases"].tolist()):
         c = _json.loads(cj)
         cfg = InferenceConfig(deep_clone=c["deep"], temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
