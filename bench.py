@@ -133,12 +133,8 @@ def main_c3(args, m, dev, world, rank, barrier):
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, frames = float(tmax[0]), float(t[1])
+        from mars5_tts_amd.sharding import reduce_timing
+        elapsed, frames = reduce_timing(elapsed, float(frames))
     if rank != 0:
         return
     ref_frames = [int(r.shape[-1]) for r in refs]
@@ -392,11 +388,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, float(frames)], device=dev, dtype=torch.float64)
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed, frames = float(tmax[0]), float(t[1])
+        from mars5_tts_amd.sharding import reduce_timing
+        elapsed, frames = reduce_timing(elapsed, float(frames))
         lats = [None] * world
         dist.all_gather_object(lats, lat)
         lat = [x for l in lats for x in l]

@@ -51,6 +51,17 @@ def _dev(group=None) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
+def reduce_timing(elapsed_s: float, units: float, group=None) -> Tuple[float, float]:
+    """The bench contract for N > 1 replicas: (MAX over ranks of the timed region, SUM over ranks of the units
+    processed).  Every rank gets the pair.  Two tiny all-reduces; the data path itself has no collective."""
+    dev = _dev(group)
+    t = torch.tensor([elapsed_s, units], dtype=torch.float64, device=dev)
+    tmax = t.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(tmax[0]), float(t[1])
+
+
 def _pack(reqs: List[Request]) -> torch.Tensor:
     """[n, then per request: idx, seed, n_gen_est, Lt, Lc, text_ids..., ref_codes (row-major)...]"""
     parts = [torch.tensor([len(reqs)], dtype=torch.int64)]

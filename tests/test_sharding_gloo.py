@@ -49,6 +49,9 @@ def _worker(rank: int, world: int, port: int, ok):
         for r in shard:                                          # payload survives the wire bit-exactly
             assert torch.equal(r.text_ids, full[r.idx].text_ids) and torch.equal(r.ref_codes, full[r.idx].ref_codes)
             assert r.seed == full[r.idx].seed and r.n_gen_est == full[r.idx].n_gen_est
+        # bench.py's N > 1 reduction: max of the timed regions, sum of the units, on every rank
+        tmax, total = sh.reduce_timing(1.5 + rank, 10.0 * (rank + 1))
+        assert tmax == 1.5 + (world - 1) and total == 10.0 * world * (world + 1) / 2
         out = sh.run_sharded(reqs, n, _fake_tts, src=0)
         if rank == 0:
             assert out is not None and len(out) == n
