@@ -167,6 +167,17 @@ int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, in
 
 #define M5_ATTN_PART 66    /* floats per (head, split) partial: o[64], m, l                 */
 
+/* Same-stream weight prefetch (batch-1 decode).  A decode launch lives ~5 us of which the HBM pipe is busy for
+ * 1-3: `wgs` extra workgroups appended to a launch touch (one 4-byte load per 64 bytes, result discarded) the
+ * weights a LATER launch of the step will stream, so they are on their way into L2 / Infinity Cache while this
+ * launch's own dependency chain runs.  The region is `n_chunks` chunks of `chunk_bytes` starting at chunk
+ * `first_chunk` of `ptr`, chunk j being what workgroup j of the consuming launch reads; a prefetching workgroup
+ * only touches chunks j with j % 8 == its own (block id % 8), i.e. (observed placement, speed only) the chunks its
+ * own XCD's L2 will be asked for.  ptr == NULL or wgs == 0: off.  Never changes any result. */
+typedef struct {
+    const void* ptr; int64_t chunk_bytes; int32_t first_chunk, n_chunks, wgs, pad_;
+} M5Prefetch;
+
 typedef struct {
     const void* W; int64_t ldw; int32_t N, K;
     const float* x_f32; const float* norm_w; float eps;   /* PRO_RMS                        */
@@ -177,6 +188,7 @@ typedef struct {
     void* kcache; void* vcache; void* qbuf;                /* this layer's cache [h][W][64]  */
     int32_t w_alloc, window, dim;
     unsigned long long* dbg;                               /* diagnostics: phase stamps of workgroup 0 (NULL = off) */
+    M5Prefetch pf;                                         /* optional: the NEXT launch's weights (streaming geometry only) */
 } M5GemvArgs;
 int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void* stream);
 
@@ -190,6 +202,7 @@ typedef struct {
      * state + b*state_bs (int32 words). */
     int32_t batch, state_bs;
     int64_t q_bs, cache_bs, part_bs;
+    M5Prefetch pf;                                         /* optional: a later launch's weights (batch 1 only) */
 } M5AttnDecodeArgs;
 /* nn_future.py:257-272 decode branch: q . K[:min(pos+1,W)] softmax . V, split over keys. */
 int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream);

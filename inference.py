@@ -193,7 +193,8 @@ class Mars5TTS:
         """``tts`` between the codec and the vocoder (reference inference.py:222-301):
         prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out.
         `rng_hooks` (parity tests): an object with ar_noise(n_steps, V), after_ar(n_iterations), randint(shape),
-        uniform(shape) that supplies every random draw instead of the device generator (oracle/fakes.py)."""
+        uniform(shape) that supplies every random draw instead of the device generator (oracle/fakes.py), and
+        optionally nar_on_step(dict), an observer of every reverse step."""
         T = self.default_T
         diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
         pr = self._prompt(text, prompt_codec, ref_transcript, cfg)
@@ -213,7 +214,7 @@ class Mars5TTS:
         if rng_hooks is not None:
             n_gen = int(ar_codes.shape[0]) - int(pr["prompt"].shape[0])
             rng_hooks.after_ar(n_gen + (1 if int(ar_codes.shape[0]) < self._ar_kwargs(cfg)["max_len"] else 0))
-            hook_kw = dict(uniform=rng_hooks.uniform, randint=rng_hooks.randint)
+            hook_kw = dict(uniform=rng_hooks.uniform, randint=rng_hooks.randint, on_step=getattr(rng_hooks, "nar_on_step", None))
         final_output = perform_simple_inference(self.codecnar, batch, diff, diff.num_timesteps, torch.float16, dsh=self._dsh(cfg),
                                                 retain_quant0=True, generator=generator, session=nar_sess, **hook_kw)
         final_output = final_output[0, skip_front:].to(self.device)

@@ -54,6 +54,10 @@ class AttnArgs(C.Structure):
                 ("kv_index", vp), ("kv_index_stride_k", i64), ("kv_index_stride_v", i64)]
 
 
+class Prefetch(C.Structure):
+    _fields_ = [("ptr", vp), ("chunk_bytes", i64), ("first_chunk", i32), ("n_chunks", i32), ("wgs", i32), ("pad_", i32)]
+
+
 class GemvArgs(C.Structure):
     _fields_ = [("W", vp), ("ldw", i64), ("N", i32), ("K", i32),
                 ("x_f32", vp), ("norm_w", vp), ("eps", f32),
@@ -62,13 +66,13 @@ class GemvArgs(C.Structure):
                 ("y_dt", vp), ("y_f32", vp), ("xres", vp),
                 ("rope", vp), ("state", vp),
                 ("kcache", vp), ("vcache", vp), ("qbuf", vp),
-                ("w_alloc", i32), ("window", i32), ("dim", i32), ("dbg", vp)]
+                ("w_alloc", i32), ("window", i32), ("dim", i32), ("dbg", vp), ("pf", Prefetch)]
 
 
 class AttnDecodeArgs(C.Structure):
     _fields_ = [("qbuf", vp), ("kcache", vp), ("vcache", vp), ("part", vp), ("state", vp),
                 ("n_heads", i32), ("w_alloc", i32), ("window", i32), ("nsplit", i32), ("scale", f32),
-                ("batch", i32), ("state_bs", i32), ("q_bs", i64), ("cache_bs", i64), ("part_bs", i64)]
+                ("batch", i32), ("state_bs", i32), ("q_bs", i64), ("cache_bs", i64), ("part_bs", i64), ("pf", Prefetch)]
 
 
 class SampleArgs(C.Structure):

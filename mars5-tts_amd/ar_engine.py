@@ -15,6 +15,7 @@ What is different from the reference by design (all exact):
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -173,24 +174,43 @@ class ARSession:
         ops.ar_gemv(m.dt, L.PRO_RMS, L.GEPI_F32, a, stream=st)
         ops.ar_sample(self._sample_args, stream=st)
 
+    @staticmethod
+    def _pf(w: Optional[torch.Tensor], wgs: int, first: int = 0, n: int = 256) -> L.Prefetch:
+        """Prefetch descriptor for weight matrix `w` as the streaming GEMV will read it: 256 consuming workgroups, each a
+        contiguous block of rows (include/mars5_hip.h, M5Prefetch).  None / wgs 0 = off."""
+        if w is None or wgs <= 0:
+            return L.Prefetch()
+        chunk = w.numel() * w.element_size() // 256
+        if chunk % 64 or w.numel() * w.element_size() % 256:
+            return L.Prefetch()
+        return L.Prefetch(ptr=w.data_ptr(), chunk_bytes=chunk, first_chunk=first, n_chunks=n, wgs=wgs)
+
     def enqueue_layers(self, st: int) -> None:
         m, s = self.m, self.m.shape
         D, F, H = s.dim, s.hidden_dim, s.nhead
+        # same-stream prefetch plan (M5Prefetch): 0 off; 1 every launch pulls the NEXT launch's weights; 2 only the two
+        # bandwidth-idle launches (cache scan, Wo) pull the two halves of W1|W3.  16-bit streaming geometry only.
+        plan = int(os.environ.get("M5_AR_PREFETCH", "0")) if (m.dt != torch.float32 and D == 1536 and F == 3584) else 0
+        npf = int(os.environ.get("M5_AR_PREFETCH_WGS", "64"))
         for l in range(s.n_layers):
+            nxt = m.wqkv[l + 1] if l + 1 < s.n_layers else m.w_out
             a = self._gemv_args(W=m.wqkv[l], ldw=D, N=3 * D, K=D, x_f32=self.xdec, norm_w=m.attn_norm[l], eps=s.norm_eps,
                                 rope=m.rope, state=self.state, kcache=self.kc[l], vcache=self.vc[l], qbuf=self.qbuf,
-                                w_alloc=self.w_alloc, window=self.window, dim=D)
+                                w_alloc=self.w_alloc, window=self.window, dim=D, pf=self._pf(m.wo[l] if plan == 1 else None, npf))
             ops.ar_gemv(m.dt, L.PRO_RMS, L.GEPI_QKV_ROPE, a, stream=st)
             d = L.AttnDecodeArgs(qbuf=self.qbuf.data_ptr(), kcache=self.kc[l].data_ptr(), vcache=self.vc[l].data_ptr(),
                                  part=self.part.data_ptr(), state=self.state.data_ptr(), n_heads=H, w_alloc=self.w_alloc,
-                                 window=self.window, nsplit=NSPLIT, scale=64 ** -0.5)
+                                 window=self.window, nsplit=NSPLIT, scale=64 ** -0.5,
+                                 pf=self._pf(m.w13[l] if plan else None, (npf + H - 1) // H * H, 0, 128))
             ops.ar_attn_decode(m.dt, d, stream=st)
-            a = self._gemv_args(W=m.wo[l], ldw=D, N=D, K=D, part=self.part, nsplit=NSPLIT, n_heads=H, xres=self.xdec, state=self.state)
+            a = self._gemv_args(W=m.wo[l], ldw=D, N=D, K=D, part=self.part, nsplit=NSPLIT, n_heads=H, xres=self.xdec, state=self.state,
+                                pf=self._pf(m.w13[l] if plan else None, npf, 128, 128))
             ops.ar_gemv(m.dt, L.PRO_ATTN, L.GEPI_RESIDUAL, a, stream=st)
             a = self._gemv_args(W=m.w13[l], ldw=D, N=2 * F, K=D, x_f32=self.xdec, norm_w=m.ffn_norm[l], eps=s.norm_eps,
-                                y_dt=self.hbuf, state=self.state)
+                                y_dt=self.hbuf, state=self.state, pf=self._pf(m.w2[l] if plan == 1 else None, npf))
             ops.ar_gemv(m.dt, L.PRO_RMS, L.GEPI_SWIGLU, a, stream=st)
-            a = self._gemv_args(W=m.w2[l], ldw=F, N=D, K=F, x_dt=self.hbuf, xres=self.xdec, state=self.state)
+            a = self._gemv_args(W=m.w2[l], ldw=F, N=D, K=F, x_dt=self.hbuf, xres=self.xdec, state=self.state,
+                                pf=self._pf(nxt if plan == 1 else None, npf))
             ops.ar_gemv(m.dt, L.PRO_DT, L.GEPI_RESIDUAL, a, stream=st)
 
     def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: torch.Tensor) -> None:

@@ -21,6 +21,25 @@ __device__ inline void ar_stamp(unsigned long long* d, int k) {
     if (d && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) d[k] = wall_clock64();
 }
 
+// Prefetch workgroup `pid` of `pf.wgs` (appended behind a launch's compute workgroups; `lin` = its linear block id, whose
+// residue mod 8 is -- observed, speed only -- its XCD): touches the chunks j = first + r + 8 k of the region whose residue
+// matches, sharing them with the other prefetchers of that residue.  One dword per 64 bytes pulls the line towards L2.
+__device__ inline void prefetch_wg(const M5Prefetch& pf, int pid, int npf, int lin, int nthreads) {
+    const int r = lin & 7;
+    const int per_res = max(npf >> 3, 1), idx = (pid >> 3) % per_res;       // npf: prefetch workgroups actually launched
+    const int nk = (pf.n_chunks - r + 7) >> 3;                       // chunks of this residue
+    const int kper = (nk + per_res - 1) / per_res;
+    const int units = (int)(pf.chunk_bytes >> 6);
+    const unsigned char* base = (const unsigned char*)pf.ptr;
+    int acc = 0;
+    for (int k = idx * kper; k < min((idx + 1) * kper, nk); ++k) {
+        const unsigned char* cb = base + (int64_t)(pf.first_chunk + r + 8 * k) * pf.chunk_bytes;
+#pragma unroll 8
+        for (int u = threadIdx.x; u < units; u += nthreads) acc += *reinterpret_cast<const int*>(cb + (int64_t)u * 64);
+    }
+    asm volatile("" :: "v"(acc));
+}
+
 // ----------------------------------------------------------------------------- GEMV
 template <typename T, int PRO, int EPI, int R>
 __global__ __launch_bounds__(256) void gemv_kernel(M5GemvArgs a) {
@@ -195,6 +214,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
     __shared__ float wsm[24 * 8 + 24];           // PRO_ATTN: split weights [h][s], then l_tot[h]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {   // workgroups behind the compute grid only prefetch (see M5Prefetch)
+        const int ncomp = (a.N + NW * R - 1) / (NW * R);
+        if ((int)blockIdx.x >= ncomp) { prefetch_wg(a.pf, blockIdx.x - ncomp, gridDim.x - ncomp, blockIdx.x, NT); return; }
+    }
     unsigned long long* dbg = a.dbg;
     ar_stamp(dbg, 0);
     const int done = a.state ? a.state[M5_ST_DONE] : 0;     // consumed only before the epilogue's writes
@@ -401,7 +424,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
 
 template <typename T, int PRO, int EPI, int R, int NW, int NIT>
 int launch_gemv_stream(const M5GemvArgs& a, hipStream_t s) {
-    dim3 grid((a.N + NW * R - 1) / (NW * R));
+    int ncomp = (a.N + NW * R - 1) / (NW * R);
+    const bool pf = a.pf.ptr && a.pf.wgs > 0 && a.pf.n_chunks > 0 && (a.pf.chunk_bytes % 64) == 0 && (a.pf.first_chunk % 8) == 0;
+    // the prefetchers' residues must line up with the block ids: pad the compute grid's count to a multiple of 8 (no-op here)
+    dim3 grid(ncomp + ((pf && ncomp % 8 == 0) ? a.pf.wgs / 8 * 8 : 0));
     hipLaunchKernelGGL((gemv_stream_kernel<T, PRO, EPI, R, NW, NIT>), grid, dim3(NW * 64), 0, s, a);
     M5_CHECK_LAUNCH();
     return M5_OK;
@@ -442,6 +468,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
         a.kcache = reinterpret_cast<const st*>(a.kcache) + b * a.cache_bs;
         a.vcache = reinterpret_cast<const st*>(a.vcache) + b * a.cache_bs;
         a.part += b * a.part_bs;
+    }
+    if ((int)blockIdx.y >= a.nsplit) {             // appended prefetch workgroups (batch 1): see M5Prefetch
+        const int pid = (blockIdx.y - a.nsplit) * gridDim.x + blockIdx.x;
+        prefetch_wg(a.pf, pid, (gridDim.y - a.nsplit) * gridDim.x, blockIdx.y * gridDim.x + blockIdx.x, 256);
+        return;
     }
     const int done = a.state[M5_ST_DONE];          // consumed before the only global write (a finished sequence just idles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -918,6 +949,9 @@ extern "C" int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void
 extern "C" int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream) {
     if (!a || !a->qbuf || !a->kcache || !a->vcache || !a->part || !a->state || a->n_heads <= 0 || a->nsplit <= 0) return M5_ERR_ARG;
     dim3 grid(a->n_heads, a->nsplit, a->batch > 1 ? a->batch : 1);
+    if (a->batch <= 1 && a->pf.ptr && a->pf.wgs > 0 && a->pf.n_chunks > 0 && (a->pf.chunk_bytes % 64) == 0 && (a->pf.first_chunk % 8) == 0 &&
+        (a->n_heads % 8) == 0)
+        grid.y += (a->pf.wgs + a->n_heads - 1) / a->n_heads;          // whole rows of n_heads prefetch workgroups
     hipStream_t s = (hipStream_t)stream;
     switch (dtype) {
         case M5_F32: hipLaunchKernelGGL(attn_decode_kernel<F32T>, grid, dim3(256), 0, s, *a); break;

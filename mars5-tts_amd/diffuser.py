@@ -115,13 +115,15 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
                              retain_quant0: bool = True, dsh=DSH,
                              uniform: Optional[Callable[[tuple], Tensor]] = None, randint: Optional[Callable] = None,
                              use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None,
-                             generator: Optional[torch.Generator] = None, session: Optional[NARSession] = None) -> Tensor:
+                             generator: Optional[torch.Generator] = None, session: Optional[NARSession] = None,
+                             on_step: Optional[Callable[[dict], None]] = None) -> Tensor:
     """batch = (c_text (1,Lt), c_codes (1,Lc,8), c_text_lengths, c_codes_lengths, x (1,Lx,8),
     x_padding_mask); returns (1, S - offset, 8) int64.  RNG draws follow the reference order:
     randint(0,K,(1,Lx,8)) then per step rand (1,S,8,K) x2 (x1 at t = 0).
     `uniform(shape)` / `randint(shape)` override the device generator (parity tests);
     `generator` draws from a private device generator instead of the global one; `session`: the result of
-    ``begin_inference`` for the same conditioning, T and dsh (its conditioning work is then not repeated)."""
+    ``begin_inference`` for the same conditioning, T and dsh (its conditioning work is then not repeated);
+    `on_step`: per-step observer for parity tests (``NARSession.run``)."""
     c_text, c_codes = batch[0], batch[1]
     assert retain_quant0, "retain_quant0=False is not a shipped configuration (inference.py:298)"
     cfg = _nar_config(T, dsh, div_mode)
@@ -141,7 +143,7 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
         assert sess.times == list(times) and sess.cfg == cfg, "session was begun with a different schedule / DSH"
         sess.prepare_state(xr, x_known, m, offset)
         sess.prepare_loop()
-    out = sess.run(uniform, use_graph=use_graph, n_steps=n_steps)
+    out = sess.run(uniform, use_graph=use_graph, n_steps=n_steps, on_step=on_step)
     return out[None, offset:].clone()
 
 

@@ -341,13 +341,30 @@ class NARSession:
             self.enqueue_sample(u1[0], u2[0] if u2 is not None else None, st)
         self.step_i += 1
 
-    def run(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True, n_steps: Optional[int] = None) -> torch.Tensor:
+    def run(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True, n_steps: Optional[int] = None,
+            on_step: Optional[Callable[[dict], None]] = None) -> torch.Tensor:
+        """`on_step` (parity tests only; synchronises every step): called after each reverse step with
+        {i, t, x_t, x_tm1, u1, u2} so a checker can replay the step."""
         n = len(self.times) if n_steps is None else n_steps
         st = self.stream.cuda_stream
         ev0, ev1 = ops.Event(), ops.Event()
         ev0.record(st)
-        for _ in range(n):
-            self.step(uniform, use_graph)
+        for i in range(n):
+            if on_step is None:
+                self.step(uniform, use_graph)
+                continue
+            with torch.cuda.stream(self.stream):
+                x_t = self.x.clone()
+            drawn: List[torch.Tensor] = []
+
+            def spy(shape, _d=drawn):
+                _d.append(uniform(shape))
+                return _d[-1]
+
+            t = self.times[self.step_i]
+            self.step(spy, use_graph)
+            self.stream.synchronize()
+            on_step(dict(i=i, t=t, x_t=x_t, x_tm1=self.x.clone(), u1=drawn[0][0], u2=drawn[1][0] if len(drawn) > 1 else None))
         ev1.record(st)
         self.stream.synchronize()
         if self.ws.ln_scratch is not None and int(self.ws.ln_scratch[:4].view(torch.int32)[0]) != 0:

@@ -28,6 +28,36 @@ LAYERNORM_EPS = 4e-5            # mars5/model.py:13
 MIN_LOG_ARG = 1e-7              # mars5/diffuser.py:18
 
 
+# ---- reduced-precision emulation ---------------------------------------------------------
+# On a GPU the reference runs the AR stage under ``torch.autocast(dtype=float16)``
+# (mars5/ar_generate.py:59,67): every nn.Linear casts its input to the autocast dtype,
+# accumulates in fp32 and returns the autocast dtype; RMSNorm / LayerNorm / softmax and the
+# residual stream stay fp32 (nn_future.py:307-312, x + r promotes).  ``dt`` (None = the CPU path,
+# all fp32) reproduces those rounding points on fp32 containers, so the 16-bit engines can be
+# compared with what the reference computes in that dtype.  Weights must already be
+# dt-representable (``round_linear_weights``): autocast's weight cast is then the identity.  Biases
+# (speaker encoder only on this stage) are added in fp32 before the output rounding; autocast
+# would first round them to dt -- at most half a dt-ulp of the bias, far below the output rounding.
+def _r(x: Tensor, dt: Optional[torch.dtype]) -> Tensor:
+    return x if dt is None else x.to(dt).to(torch.float32)
+
+
+def _lin(x: Tensor, w: Tensor, b: Optional[Tensor] = None, dt: Optional[torch.dtype] = None) -> Tensor:
+    if dt is None:
+        return F.linear(x, w, b)
+    return _r(F.linear(_r(x, dt), w, b), dt)
+
+
+def round_linear_weights(sd: Dict[str, Tensor], dt: torch.dtype) -> Dict[str, Tensor]:
+    """Copy of ``sd`` with every matrix that feeds an nn.Linear rounded to ``dt`` (what autocast /
+    a 16-bit engine sees); embedding tables, norms, biases and scalars keep their fp32 values."""
+    out = {}
+    for k, v in sd.items():
+        is_table = k in ("embed.weight", "text_embed.weight", "spk_identity_emb.weight") or ".embs." in k
+        out[k] = v.to(dt).to(torch.float32) if (v.dim() == 2 and not is_table) else v
+    return out
+
+
 # ======================================================================================
 # shared building blocks
 # ======================================================================================
@@ -75,53 +105,54 @@ def rmsnorm(x: Tensor, w: Tensor, eps: float) -> Tensor:
 
 
 def mha(q_in: Tensor, kv_in: Tensor, w_in: Tensor, b_in: Tensor, w_out: Tensor, b_out: Tensor,
-        nhead: int, key_mask: Optional[Tensor]) -> Tensor:
+        nhead: int, key_mask: Optional[Tensor], dt: Optional[torch.dtype] = None) -> Tensor:
     """torch.nn.MultiheadAttention forward as used by the reference encoder/decoder layers
     (model.py:61-67,179-203): packed in-projection with bias, SDPA with scale 1/sqrt(hd),
     boolean key-padding mask (True = ignore), out-projection with bias.
     q_in (Lq, D), kv_in (Lk, D)."""
     D = q_in.shape[-1]
     hd = D // nhead
-    q = F.linear(q_in, w_in[:D], b_in[:D])
-    k = F.linear(kv_in, w_in[D:2 * D], b_in[D:2 * D])
-    v = F.linear(kv_in, w_in[2 * D:], b_in[2 * D:])
+    q = _lin(q_in, w_in[:D], b_in[:D], dt)
+    k = _lin(kv_in, w_in[D:2 * D], b_in[D:2 * D], dt)
+    v = _lin(kv_in, w_in[2 * D:], b_in[2 * D:], dt)
     q = q.view(-1, nhead, hd).transpose(0, 1)
     k = k.view(-1, nhead, hd).transpose(0, 1)
     v = v.view(-1, nhead, hd).transpose(0, 1)
     scores = (q @ k.transpose(1, 2)) / math.sqrt(hd)
     if key_mask is not None:
         scores = scores.masked_fill(key_mask[None, None, :], float("-inf"))
-    att = torch.softmax(scores, dim=-1) @ v
-    return F.linear(att.transpose(0, 1).reshape(-1, D), w_out, b_out)
+    att = _r(torch.softmax(scores, dim=-1) @ v, dt)
+    return _lin(att.transpose(0, 1).reshape(-1, D), w_out, b_out, dt)
 
 
-def swiglu_ff(x: Tensor, sd: Dict[str, Tensor], p: str) -> Tensor:
+def swiglu_ff(x: Tensor, sd: Dict[str, Tensor], p: str, dt: Optional[torch.dtype] = None) -> Tensor:
     """linear1 = Identity, activation = FNNSwiGLU (nn_future.py:21-29), then linear2+bias."""
-    h = F.silu(F.linear(x, sd[f"{p}.activation.W.weight"])) * F.linear(x, sd[f"{p}.activation.V.weight"])
-    return F.linear(h, sd[f"{p}.linear2.weight"], sd[f"{p}.linear2.bias"])
+    h = _r(_r(F.silu(_lin(x, sd[f"{p}.activation.W.weight"], None, dt)), dt) * _lin(x, sd[f"{p}.activation.V.weight"], None, dt), dt)
+    return _lin(h, sd[f"{p}.linear2.weight"], sd[f"{p}.linear2.bias"], dt)
 
 
-def encoder_layer(x: Tensor, sd: Dict[str, Tensor], p: str, nhead: int, key_mask: Optional[Tensor]) -> Tensor:
+def encoder_layer(x: Tensor, sd: Dict[str, Tensor], p: str, nhead: int, key_mask: Optional[Tensor],
+                  dt: Optional[torch.dtype] = None) -> Tensor:
     """nn.TransformerEncoderLayer, norm_first=True, eps 4e-5 (model.py:61-67)."""
     h = F.layer_norm(x, x.shape[-1:], sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"], LAYERNORM_EPS)
     x = x + mha(h, h, sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"],
-                sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"], nhead, key_mask)
+                sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"], nhead, key_mask, dt)
     h = F.layer_norm(x, x.shape[-1:], sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"], LAYERNORM_EPS)
-    return x + swiglu_ff(h, sd, p)
+    return x + swiglu_ff(h, sd, p, dt)
 
 
 def decoder_layer(x: Tensor, mem: Tensor, sd: Dict[str, Tensor], p: str, nhead: int,
-                  tgt_mask: Optional[Tensor], mem_mask: Optional[Tensor]) -> Tensor:
+                  tgt_mask: Optional[Tensor], mem_mask: Optional[Tensor], dt: Optional[torch.dtype] = None) -> Tensor:
     """nn.TransformerDecoderLayer, norm_first=True (model.py:187-193): self-attn, cross-attn
     (queries from tgt, keys/values from memory), SwiGLU feed-forward."""
     h = F.layer_norm(x, x.shape[-1:], sd[f"{p}.norm1.weight"], sd[f"{p}.norm1.bias"], LAYERNORM_EPS)
     x = x + mha(h, h, sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"],
-                sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"], nhead, tgt_mask)
+                sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"], nhead, tgt_mask, dt)
     h = F.layer_norm(x, x.shape[-1:], sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"], LAYERNORM_EPS)
     x = x + mha(h, mem, sd[f"{p}.multihead_attn.in_proj_weight"], sd[f"{p}.multihead_attn.in_proj_bias"],
-                sd[f"{p}.multihead_attn.out_proj.weight"], sd[f"{p}.multihead_attn.out_proj.bias"], nhead, mem_mask)
+                sd[f"{p}.multihead_attn.out_proj.weight"], sd[f"{p}.multihead_attn.out_proj.bias"], nhead, mem_mask, dt)
     h = F.layer_norm(x, x.shape[-1:], sd[f"{p}.norm3.weight"], sd[f"{p}.norm3.bias"], LAYERNORM_EPS)
-    return x + swiglu_ff(h, sd, p)
+    return x + swiglu_ff(h, sd, p, dt)
 
 
 def _count_layers(sd: Dict[str, Tensor], prefix: str) -> int:
@@ -132,7 +163,7 @@ def _count_layers(sd: Dict[str, Tensor], prefix: str) -> int:
 
 
 def speaker_encode(sd: Dict[str, Tensor], codes: Tensor, nhead: int, emb_prefix: str, pos_alpha: str,
-                   valid_len: Optional[int] = None) -> Tensor:
+                   valid_len: Optional[int] = None, dt: Optional[torch.dtype] = None) -> Tensor:
     """Speaker-reference encoder shared by CodecLM (model.py:109-127) and
     ResidualTransformer (model.py:298-310): [spk_identity, chunked_emb(codes)] + sine pos,
     pre-LN encoder layers, final LayerNorm, take position 0.  codes (Lc, 8).
@@ -144,7 +175,7 @@ def speaker_encode(sd: Dict[str, Tensor], codes: Tensor, nhead: int, emb_prefix:
     if valid_len is not None:
         key_mask = torch.arange(seq.shape[0]) >= (valid_len + 1)
     for l in range(_count_layers(sd, "spk_encoder.layers")):
-        seq = encoder_layer(seq, sd, f"spk_encoder.layers.{l}", nhead, key_mask)
+        seq = encoder_layer(seq, sd, f"spk_encoder.layers.{l}", nhead, key_mask, dt)
     seq = F.layer_norm(seq, seq.shape[-1:], sd["spk_encoder.norm.weight"], sd["spk_encoder.norm.bias"], LAYERNORM_EPS)
     return seq[0]
 
@@ -159,15 +190,15 @@ class ARState:
     spk: Optional[Tensor] = None
 
 
-def ar_spk_vector(sd: Dict[str, Tensor], ref_codes: Tensor, nhead: int) -> Tensor:
+def ar_spk_vector(sd: Dict[str, Tensor], ref_codes: Tensor, nhead: int, dt: Optional[torch.dtype] = None) -> Tensor:
     """model.py:109-127: ref_codes (Lc, 8).  AR padding mask = cumsum(code0 == 1024) > 0."""
     pad = (ref_codes[:, 0] == 1024).cumsum(0) > 0
     valid = None if not bool(pad.any()) else int((~pad).sum())
-    return speaker_encode(sd, ref_codes, nhead, "ref_chunked_emb", "pos_embedding.alpha", valid)
+    return speaker_encode(sd, ref_codes, nhead, "ref_chunked_emb", "pos_embedding.alpha", valid, dt)
 
 
 def mistral_forward(sd: Dict[str, Tensor], h: Tensor, positions: Tensor, st: ARState, nhead: int,
-                    norm_eps: float = 1e-5, sliding_window: int = 3000) -> Tensor:
+                    norm_eps: float = 1e-5, sliding_window: int = 3000, dt: Optional[torch.dtype] = None) -> Tensor:
     """nn_future.py:369-398 + Attention.forward :235-274 + FeedForward :297-298.
     h (M, D) rows at RoPE ``positions`` (M,).  M > 1 = prefill (attends over the fresh k/v
     with the causal band mask, :380-392, while filling the cache); M == 1 = decode against
@@ -185,10 +216,10 @@ def mistral_forward(sd: Dict[str, Tensor], h: Tensor, positions: Tensor, st: ARS
     for l in range(n_layers):
         p = f"ar.layers.{l}"
         a = rmsnorm(h, sd[f"{p}.attention_norm.weight"], norm_eps)
-        q = F.linear(a, sd[f"{p}.attention.wq.weight"]).view(M, nhead, hd)
-        k = F.linear(a, sd[f"{p}.attention.wk.weight"]).view(M, nhead, hd)
-        v = F.linear(a, sd[f"{p}.attention.wv.weight"]).view(M, nhead, hd)
-        q, k = apply_rotary(q, freqs), apply_rotary(k, freqs)
+        q = _lin(a, sd[f"{p}.attention.wq.weight"], None, dt).view(M, nhead, hd)
+        k = _lin(a, sd[f"{p}.attention.wk.weight"], None, dt).view(M, nhead, hd)
+        v = _lin(a, sd[f"{p}.attention.wv.weight"], None, dt).view(M, nhead, hd)
+        q, k = _r(apply_rotary(q, freqs), dt), _r(apply_rotary(k, freqs), dt)      # .type_as(x): back to the autocast dtype
         if len(st.k) <= l:
             st.k.append(k[-sliding_window:].clone())
             st.v.append(v[-sliding_window:].clone())
@@ -202,16 +233,17 @@ def mistral_forward(sd: Dict[str, Tensor], h: Tensor, positions: Tensor, st: ARS
         scores = torch.einsum("mhd,nhd->hmn", q, key) / math.sqrt(hd)
         if mask is not None:
             scores = scores + mask[None]
-        o = torch.einsum("hmn,nhd->mhd", torch.softmax(scores, dim=-1), val).reshape(M, D)
-        h = h + F.linear(o, sd[f"{p}.attention.wo.weight"])
+        o = _r(torch.einsum("hmn,nhd->mhd", torch.softmax(scores, dim=-1), val).reshape(M, D), dt)
+        h = h + _lin(o, sd[f"{p}.attention.wo.weight"], None, dt)
         f = rmsnorm(h, sd[f"{p}.ffn_norm.weight"], norm_eps)
-        h = h + F.linear(F.silu(F.linear(f, sd[f"{p}.feed_forward.w1.weight"])) * F.linear(f, sd[f"{p}.feed_forward.w3.weight"]),
-                         sd[f"{p}.feed_forward.w2.weight"])
-    return F.linear(rmsnorm(h, sd["ar.norm.weight"], norm_eps), sd["ar.output.weight"])
+        g = _r(_r(F.silu(_lin(f, sd[f"{p}.feed_forward.w1.weight"], None, dt)), dt) * _lin(f, sd[f"{p}.feed_forward.w3.weight"], None, dt), dt)
+        h = h + _lin(g, sd[f"{p}.feed_forward.w2.weight"], None, dt)
+    return _lin(rmsnorm(h, sd["ar.norm.weight"], norm_eps), sd["ar.output.weight"], None, dt)
 
 
 def codeclm_step(sd: Dict[str, Tensor], tokens: Tensor, ref_codes: Tensor, st: ARState, counter: int,
-                 nhead: int, recompute_spk: bool = False, sliding_window: int = 3000) -> Tensor:
+                 nhead: int, recompute_spk: bool = False, sliding_window: int = 3000,
+                 dt: Optional[torch.dtype] = None) -> Tensor:
     """CodecLM.forward with a KV cache (model.py:95-141): internal sequence is
     [spk_vec, tok_0 .. tok_{L-1}] so token i sits at position i+1; counter == 1 runs the
     whole prefix (prefill) and strips the speaker position; later steps feed the last
@@ -219,7 +251,7 @@ def codeclm_step(sd: Dict[str, Tensor], tokens: Tensor, ref_codes: Tensor, st: A
     The reference recomputes the speaker vector every step (bit-identical, SURVEY App.B-12);
     ``recompute_spk`` reproduces that *cost* for the CPU baseline."""
     if st.spk is None or recompute_spk:
-        st.spk = ar_spk_vector(sd, ref_codes, nhead)
+        st.spk = ar_spk_vector(sd, ref_codes, nhead, dt)
     L = tokens.shape[0]
     if counter == 1:
         x = torch.cat([st.spk[None], sd["embed.weight"][tokens]], dim=0)
@@ -227,7 +259,7 @@ def codeclm_step(sd: Dict[str, Tensor], tokens: Tensor, ref_codes: Tensor, st: A
     else:
         x = sd["embed.weight"][tokens[-1:]]
         positions = torch.tensor([L])
-    return mistral_forward(sd, x, positions, st, nhead, sliding_window=sliding_window)[-1]
+    return mistral_forward(sd, x, positions, st, nhead, sliding_window=sliding_window, dt=dt)[-1]
 
 
 # ---- sampler chain  (samplers.py + ar_generate.py:74-115) ----------------------------
@@ -294,11 +326,16 @@ def draw_token(z: Tensor, q: Tensor) -> int:
 def ar_generate_oracle(sd: Dict[str, Tensor], nhead: int, n_text: int, n_speech: int, eos_special: int,
                        prompt: Tensor, ref_codes: Tensor, max_len: int, params: ARSamplingParams,
                        generator: Optional[torch.Generator] = None, noise: Optional[Tensor] = None,
-                       recompute_spk: bool = False, return_logits: bool = False, sliding_window: int = 3000):
+                       recompute_spk: bool = False, return_logits: bool = False, sliding_window: int = 3000,
+                       dt: Optional[torch.dtype] = None, forced: Optional[Tensor] = None):
     """ar_generate.py:15-165 for bs = beam = 1 with the KV cache.  prompt (P,) int64 (global
     ids), ref_codes (Lc, 8).  Returns the full sequence (prompt + generated, EOS not appended,
     ar_generate.py:121-131).  RNG: one Exp(1) vector of size V per step, from ``noise[step]``
-    when given, else ``torch.empty(V).exponential_(1, generator)`` (what multinomial draws)."""
+    when given, else ``torch.empty(V).exponential_(1, generator)`` (what multinomial draws).
+    ``dt``: autocast dtype of the reference's GPU path (None = the CPU path, fp32).
+    ``forced`` (teacher forcing, for logit comparisons): a full token sequence whose generated part is
+    fed back instead of the oracle's own draws; ``choices`` then records what the oracle WOULD have drawn
+    at each step given that history.  Returns (forced, logits, choices) in that mode."""
     V = n_text + n_speech
     eos_idx = n_text + eos_special
     tokens = prompt.clone()
@@ -306,10 +343,13 @@ def ar_generate_oracle(sd: Dict[str, Tensor], nhead: int, n_text: int, n_speech:
     prev: List[int] = []
     counter = 0
     all_logits = []
+    choices: List[int] = []
+    if forced is not None:
+        max_len = min(max_len, int(forced.shape[0]) + 1)     # one step per forced token, plus the step after the last
     while tokens.shape[0] < max_len:
         counter += 1
-        logits = codeclm_step(sd, tokens, ref_codes, st, counter, nhead, recompute_spk, sliding_window).float()
-        if return_logits:
+        logits = codeclm_step(sd, tokens, ref_codes, st, counter, nhead, recompute_spk, sliding_window, dt).float()
+        if return_logits or forced is not None:
             all_logits.append(logits.clone())
         z = filter_logits(logits, prev, params, n_text, eos_idx)
         if noise is not None:
@@ -317,10 +357,17 @@ def ar_generate_oracle(sd: Dict[str, Tensor], nhead: int, n_text: int, n_speech:
         else:
             q = torch.empty(V).exponential_(1, generator=generator)
         tok = draw_token(z, q)
-        if tok == eos_idx:
+        if forced is not None:
+            choices.append(tok)
+            if tokens.shape[0] >= forced.shape[0]:
+                break
+            tok = int(forced[tokens.shape[0]])
+        elif tok == eos_idx:
             break
         prev.append(tok)
         tokens = torch.cat([tokens, torch.tensor([tok])])
+    if forced is not None:
+        return tokens, all_logits, choices
     return (tokens, all_logits) if return_logits else tokens
 
 
@@ -338,28 +385,31 @@ def timestep_embedding(t: Tensor, dim: int, max_period: int = 10000) -> Tensor:
     return emb
 
 
-def nar_spk_vector(sd: Dict[str, Tensor], c_codes: Tensor, nhead: int, drop_cond: bool) -> Tensor:
+def nar_spk_vector(sd: Dict[str, Tensor], c_codes: Tensor, nhead: int, drop_cond: bool, dt: Optional[torch.dtype] = None) -> Tensor:
     """model.py:295-310: with drop_cond the codes become pad (1024) and the length 0, so
     only position 0 is attended: a per-model constant (App. B-13)."""
     if drop_cond:
-        return speaker_encode(sd, torch.full_like(c_codes, 1024), nhead, "ref_embedder", "ref_pos_embedding.alpha", 0)
-    return speaker_encode(sd, c_codes, nhead, "ref_embedder", "ref_pos_embedding.alpha", c_codes.shape[0])
+        return speaker_encode(sd, torch.full_like(c_codes, 1024), nhead, "ref_embedder", "ref_pos_embedding.alpha", 0, dt)
+    return speaker_encode(sd, c_codes, nhead, "ref_embedder", "ref_pos_embedding.alpha", c_codes.shape[0], dt)
 
 
 def nar_forward(sd: Dict[str, Tensor], nhead: int, c_text: Tensor, c_codes: Tensor, x: Tensor, t: int,
-                drop_cond: bool = False, spk_vec: Optional[Tensor] = None) -> Tensor:
+                drop_cond: bool = False, spk_vec: Optional[Tensor] = None, dt: Optional[torch.dtype] = None) -> Tensor:
     """ResidualTransformer.forward for one utterance (bs = 1, no padding).
     c_text (Lt,), c_codes (Lc, 8), x (S, 8), t int -> logits (S, 8, K) (already in the
-    permuted layout of diffuser.py:359)."""
+    permuted layout of diffuser.py:359).  The reference runs this stage in fp32 on every device
+    (SURVEY App. B-4); ``dt`` is NOT a reference mode here: it applies the 16-bit engines' operand
+    rounding (Linear inputs / outputs in dt, fp32 accumulate, fp32 norms and residual) so the engine's
+    implementation can be checked tightly, beside the fp32 comparison that bounds the dtype's own error."""
     D = sd["text_embed.weight"].shape[1]
     t_dim = sd["timestep_encoder_emb.0.weight"].shape[1]
     Q = x.shape[-1]
     if spk_vec is None:
-        spk_vec = nar_spk_vector(sd, c_codes, nhead, drop_cond)
+        spk_vec = nar_spk_vector(sd, c_codes, nhead, drop_cond, dt)
     t_emb = timestep_embedding(torch.tensor([t]), t_dim)
 
     def mlp(name):
-        h = F.silu(F.linear(t_emb, sd[f"{name}.0.weight"], sd[f"{name}.0.bias"]))
+        h = _r(F.silu(_lin(t_emb, sd[f"{name}.0.weight"], sd[f"{name}.0.bias"], dt)), dt)
         return F.linear(h, sd[f"{name}.2.weight"], sd[f"{name}.2.bias"])[0]
 
     t_enc, t_dec = mlp("timestep_encoder_emb"), mlp("timestep_decoder_emb")
@@ -369,16 +419,16 @@ def nar_forward(sd: Dict[str, Tensor], nhead: int, c_text: Tensor, c_codes: Tens
     xe = sine_positional_embedding(xe, sd["pos_embedding.alpha"]) + t_dec[None]      # :334-336
     mem = c
     for l in range(_count_layers(sd, "tfm.encoder.layers")):
-        mem = encoder_layer(mem, sd, f"tfm.encoder.layers.{l}", nhead, None)
+        mem = encoder_layer(mem, sd, f"tfm.encoder.layers.{l}", nhead, None, dt)
     mem = F.layer_norm(mem, (D,), sd["tfm.encoder.norm.weight"], sd["tfm.encoder.norm.bias"], LAYERNORM_EPS)
     h = xe
     for l in range(_count_layers(sd, "tfm.decoder.layers")):
-        h = decoder_layer(h, mem, sd, f"tfm.decoder.layers.{l}", nhead, None, None)
+        h = decoder_layer(h, mem, sd, f"tfm.decoder.layers.{l}", nhead, None, None, dt)
     h = F.layer_norm(h, (D,), sd["tfm.decoder.norm.weight"], sd["tfm.decoder.norm.bias"], LAYERNORM_EPS)
     outs = []
     for q in range(Q):                                                               # :342 (LN eps 1e-5)
         hn = F.layer_norm(h, (D,), sd[f"residual_decoder.{q}.0.weight"], sd[f"residual_decoder.{q}.0.bias"], 1e-5)
-        outs.append(F.linear(hn, sd[f"residual_decoder.{q}.1.weight"], sd[f"residual_decoder.{q}.1.bias"]))
+        outs.append(F.linear(_r(hn, dt), sd[f"residual_decoder.{q}.1.weight"], sd[f"residual_decoder.{q}.1.bias"]))
     return torch.stack(outs, dim=1)        # (S, Q, K)
 
 
@@ -419,17 +469,24 @@ def index_to_log_onehot(x: Tensor, K: int) -> Tensor:
     return torch.log(F.one_hot(x, K).to(torch.float32).clamp(min=MIN_LOG_ARG))
 
 
-def gumbel_argmax(logp: Tensor, u: Tensor) -> Tensor:
-    """diffuser.py:219-228 with the uniforms supplied."""
+def gumbel_scores(logp: Tensor, u: Tensor) -> Tensor:
+    """diffuser.py:219-228 with the uniforms supplied: the perturbed scores whose arg-max is the sample."""
     g = -torch.log((-torch.log(u.clamp(min=MIN_LOG_ARG))).clamp(min=MIN_LOG_ARG))
-    return (g + logp).argmax(dim=-1)
+    return g + logp
+
+
+def gumbel_argmax(logp: Tensor, u: Tensor) -> Tensor:
+    return gumbel_scores(logp, u).argmax(dim=-1)
 
 
 def reverse_step(tb: DiffusionTables, logits_c: Tensor, logits_u: Optional[Tensor], x_t: Tensor, x_known: Tensor,
-                 m: Tensor, t: int, u1: Tensor, u2: Optional[Tensor], guidance_w: float, temperature: float) -> Tensor:
+                 m: Tensor, t: int, u1: Tensor, u2: Optional[Tensor], guidance_w: float, temperature: float,
+                 return_scores: bool = False):
     """diffuser.py:345-394 for one utterance given the model outputs.  logits (S, 8, K),
     x_t / x_known / m (S, 8), u1/u2 uniforms (S, 8, K).  The 'ensemble' block (:373-378) is
-    an exact identity at bs = 1; last_greedy never reaches here (App. B-3)."""
+    an exact identity at bs = 1; last_greedy never reaches here (App. B-3).
+    ``return_scores``: also return the (S, 8, K) perturbed scores of the unknown and the known branch (None at
+    t = 0), so a test can tell a wrong id from a tie that float rounding may legally break either way."""
     K = tb.num_classes
     lnK = math.log(K)      # np.log(num_classes): python double, subtracted from fp32 tensors
     x0 = logits_c
@@ -446,13 +503,17 @@ def reverse_step(tb: DiffusionTables, logits_c: Tensor, logits_u: Optional[Tenso
     one = log_add_exp(log_x_t + tb.log_alpha[t], tb.log_1_min_alpha[t] - lnK)
     un = ev + one
     logp = un - torch.logsumexp(un, dim=-1, keepdim=True)
-    unk = gumbel_argmax(logp, u1)
+    s_unk = gumbel_scores(logp, u1)
+    unk = s_unk.argmax(dim=-1)
+    s_kn = None
     if t == 0:
         kn = x_known
     else:
         lk = index_to_log_onehot(x_known, K)
-        kn = gumbel_argmax(log_add_exp(lk + tb.log_cumprod_alpha[t], tb.log_1_min_cumprod_alpha[t] - lnK), u2)
-    return kn * m.long() + unk * (1 - m.long())
+        s_kn = gumbel_scores(log_add_exp(lk + tb.log_cumprod_alpha[t], tb.log_1_min_cumprod_alpha[t] - lnK), u2)
+        kn = s_kn.argmax(dim=-1)
+    out = kn * m.long() + unk * (1 - m.long())
+    return (out, s_unk, s_kn) if return_scores else out
 
 
 @dataclass
@@ -503,11 +564,12 @@ def perform_simple_inference_oracle(sd: Dict[str, Tensor], nhead: int, c_text: T
         u1 = torch.rand((1, S, 8, K), generator=generator)[0]
         u2 = torch.rand((1, S, 8, K), generator=generator)[0] if t > 0 else None
         x_prev = x
-        x = reverse_step(tb, lc, lu, x, x_known, m, t, u1, u2, p.guidance_w, p.x_0_temp)
+        x, s_unk, s_kn = reverse_step(tb, lc, lu, x, x_known, m, t, u1, u2, p.guidance_w, p.x_0_temp, return_scores=True)
         if p.q0_override_steps < t:
             x[:, 0] = x_quant0
         if record is not None:
-            record.append({"t": t, "x_t": x_prev.clone(), "x_tm1": x.clone()})
+            record.append({"t": t, "x_t": x_prev.clone(), "x_tm1": x.clone(), "u1": u1, "u2": u2, "s_unk": s_unk, "s_kn": s_kn,
+                           "m": m, "x_known": x_known})
     return x[offset:]
 
 

@@ -205,3 +205,39 @@ def test_batch_entry_point_groups_by_length_and_restores_order(monkeypatch):
     assert sorted(flat) == list(range(n)) and [lens[i] for i in flat] == sorted(lens)      # similar lengths share a pass
     for i, (frames, final) in enumerate(out):
         assert frames.shape[0] == lens[i] and final.shape == (lens[i], 8) and int(final[0, 0]) == i   # skip_front rows dropped, order kept
+
+
+def test_ctypes_structs_match_the_header_layout(tmp_path):
+    """Every argument struct of include/mars5_hip.h as gcc lays it out (size and every field offset) against its
+    ctypes mirror in mars5_tts_amd/_lib.py: a field added on one side only would silently shift the kernel arguments."""
+    import ctypes
+    import re
+    import subprocess
+    from mars5_tts_amd import _lib as L
+    hdr = os.path.join(ROOT, "include", "mars5_hip.h")
+    pairs = {"M5QkvScatter": L.QkvScatter, "M5AttnArgs": L.AttnArgs, "M5Prefetch": L.Prefetch, "M5GemvArgs": L.GemvArgs,
+             "M5AttnDecodeArgs": L.AttnDecodeArgs, "M5SampleArgs": L.SampleArgs, "M5NarSampleArgs": L.NarSampleArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['return 0; }']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    seen = 0
+    for ln in out.splitlines():
+        cname, fname, val = ln.split()
+        cls = pairs[cname]
+        if fname == "size":
+            assert ctypes.sizeof(cls) == int(val), (cname, ctypes.sizeof(cls), val)
+        else:
+            assert getattr(cls, fname).offset == int(val), (cname, fname, getattr(cls, fname).offset, val)
+        seen += 1
+    assert seen == sum(len(c._fields_) + 1 for c in pairs.values())
+    # and no header struct is left without a mirror
+    names = set(re.findall(r"^\} (M5\w+);", open(hdr).read(), flags=re.M))
+    assert names == set(pairs), names ^ set(pairs)

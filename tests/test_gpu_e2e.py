@@ -150,42 +150,6 @@ def test_ar_tiny_f32_logits_vs_reference(dev, tiny_bundle, gold_dir):
     assert max(errs) < 2e-4, errs     # |logits| ~ 5; fp32 accumulation-order noise only
 
 
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_ar_tiny_reduced_precision_vs_oracle(dev, dt):
-    """f16 / bf16 operands, weights pre-rounded so the oracle sees the same values: logits
-    within dtype tolerance of the fp32 oracle; greedy tokens agree except where the oracle's
-    own top-2 margin is inside that tolerance."""
-    import mars5_oracle as O
-    from mars5_tts_amd import synth
-    b = synth.make_bundle("tiny", seed=0, dtype_round="f16" if dt == torch.float16 else "bf16")
-    tt, st = _toks(b)
-    lm = _lm(b, dt, dev)
-    ref_codes = synth.make_ref_codes(40, seed=7, merge_friendly=True)
-    text = tt.encode("<|startoftext|>" + TEXT + "<|endoftext|>", allowed_special="all")
-    prompt = torch.tensor(text, dtype=torch.long)
-    p = O.ARSamplingParams(temperature=0.7, top_k=1, top_p=0.2, penalty_window=80, n_phones_gen=round(len(TEXT)))
-    n_gen = 16
-    V = b.ar_shape.n_vocab
-    noise = torch.ones(n_gen, V)
-    o_tok, o_logits = O.ar_generate_oracle(b.ar_ckpt["model"], b.ar_shape.nhead, b.n_text, b.n_speech, st.special_tokens["<|endofspeech|>"],
-                                           prompt, ref_codes[0].T.contiguous(), prompt.shape[0] + n_gen, p, noise=noise, return_logits=True)
-    from mars5_tts_amd.ar_generate import ar_generate
-    out = ar_generate(tt, st, lm, prompt, ref_codes[0].T.contiguous(), len(text) + 1, max_len=prompt.shape[0] + n_gen, fp16=True,
-                      temperature=0.7, topk=1, top_p=0.2, alpha_frequency=3, alpha_presence=0.4, penalty_window=80,
-                      eos_penalty_decay=0.5, eos_penalty_factor=1.0, n_phones_gen=round(len(TEXT)), vocode=False, noise=noise).cpu()
-    tol = 0.06 if dt == torch.float16 else 0.35
-    n = min(out.shape[0], o_tok.shape[0])
-    first_diff = next((i for i in range(n) if int(out[i]) != int(o_tok[i])), None)
-    if first_diff is not None:
-        step = first_diff - prompt.shape[0]
-        top2 = torch.topk(O.filter_logits(o_logits[step], o_tok[prompt.shape[0]:first_diff].tolist(), p, b.n_text,
-                                          b.n_text + st.special_tokens["<|endofspeech|>"]), 2)[0]
-        # a flip is only acceptable at a near-tie of the oracle's own logits (before top-k they differ by < tol)
-        lg = torch.topk(o_logits[step][b.n_text - 1:], 2)[0]
-        assert float(lg[0] - lg[1]) < tol, f"{dt}: token flip at step {step} with oracle margin {float(lg[0] - lg[1])}"
-    print(f"{dt}: first differing token index: {first_diff} of {n}")
-
-
 @pytest.mark.parametrize("tag", ["nar_tiny_deep", "nar_tiny_shallow"])
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_nar_tiny_f32_matches_reference(dev, tiny_bundle, gold_dir, tag, use_graph):
@@ -228,16 +192,46 @@ def test_nar_tiny_f32_matches_reference(dev, tiny_bundle, gold_dir, tag, use_gra
     torch.randint(0, 1025, (1, x_l0.shape[0], 8), dtype=torch.long, generator=g)
     sess = NARSession(eng, NARConfig(T=T, x_0_temp=0.7, guidance_w=3.0, deep_clone=deep, q0_override_steps=20))
     sess.prepare(c_text[0], c_codes[0], torch.from_numpy(fx["steps_x_t"][0]), x_known, m, off, list(range(T - 1, -1, -1)))
-    worst = 0
+    import mars5_oracle as O
+    from parity_util import ungated_mismatches
+    sd = tiny_bundle.nar_ckpt["model"]
+    nh = tiny_bundle.nar_shape.nhead
+    tb = O.diffusion_tables(1025, 200)
+    spk = [O.nar_spk_vector(sd, c_codes[0], nh, False), O.nar_spk_vector(sd, c_codes[0], nh, True)]
+    n_excused = 0
     for i in range(T):
-        sess.x.copy_(torch.from_numpy(fx["steps_x_t"][i]).to(dev))
-        sess.step(lambda shp: torch.rand(shp, generator=g).to(dev), use_graph=use_graph)
+        t = int(fx["steps_t"][i])
+        x_t = torch.from_numpy(fx["steps_x_t"][i])
+        sess.x.copy_(x_t.to(dev))
+        drawn = []
+
+        def uni(shp):
+            drawn.append(torch.rand(shp, generator=g))
+            return drawn[-1].to(dev)
+
+        sess.step(uni, use_graph=use_graph)
         sess.stream.synchronize()
-        bad = int((sess.x.cpu() != torch.from_numpy(fx["steps_x_tm1"][i])).sum())
-        worst = max(worst, bad)
-    print(f"{tag}: worst teacher-forced step mismatch {worst}/{S * 8}")
-    assert worst <= 2
-    assert n_bad <= 0.02 * fx["final"].size
+        got = sess.x.cpu()
+        want = torch.from_numpy(fx["steps_x_tm1"][i])
+        if not torch.equal(got, want):
+            # the oracle's scores at this step (its ids are pinned to this very fixture by tests/test_oracle_golden.py): a
+            # differing id is legal only where the two classes' scores are within what the fp32 engine's logit
+            # noise (<= 3e-4, test_nar_tiny_logits_vs_reference) times the guidance / temperature gain (7.1) can move
+            lc = O.nar_forward(sd, nh, c_text[0], c_codes[0], x_t, t, False, spk[0])
+            lu = O.nar_forward(sd, nh, c_text[0], c_codes[0], x_t, t, True, spk[1])
+            ref, s_unk, s_kn = O.reverse_step(tb, lc, lu, x_t, x_known, m.bool(), t, drawn[0][0], drawn[1][0] if t > 0 else None, 3.0, 0.7,
+                                              return_scores=True)
+            if 20 < t:
+                ref[:, 0] = x_known[:, 0]
+            assert torch.equal(ref, want), "oracle and reference fixture disagree (CPU pinning test should have caught this)"
+            n_mis, bad = ungated_mismatches(got, want, s_unk, s_kn, m.bool(), eps=5e-3)
+            assert not bad, f"{tag} step {i} (t={t}): ids differ from the reference away from any tie: {bad[:5]}"
+            n_excused += n_mis
+    print(f"{tag}: teacher-forced steps: {n_excused} tie-excused id differences over {T * S * 8}")
+    if n_excused == 0:
+        assert n_bad == 0, f"{n_bad} free-running final ids differ although every teacher-forced step is exact"
+    else:
+        assert n_bad <= 0.02 * fx["final"].size      # a legal tie flip may cascade through the free-running trajectory
 
 
 def test_nar_tiny_logits_vs_reference(dev, tiny_bundle, gold_dir):
@@ -288,8 +282,15 @@ def test_nar_tiny_reduced_precision_logits(dev, dt):
     tol = 0.05 if dt == torch.float16 else 0.3
     ec = float((lg[:so] - lc[off:, 1:]).abs().max())
     eu = float((lg[so:] - lu[off:, 1:]).abs().max())
-    print(f"NAR {dt} logits max|diff| cond {ec:.3e} uncond {eu:.3e} (|logit| max {float(lc.abs().max()):.2f})")
+    # the same forward with the engine's operand rounding (weights here are already dt-valued): a much tighter bound
+    lce = O.nar_forward(b.nar_ckpt["model"], b.nar_shape.nhead, c_text, c_codes, x, t, False, dt=dt)
+    lue = O.nar_forward(b.nar_ckpt["model"], b.nar_shape.nhead, c_text, c_codes, x, t, True, dt=dt)
+    ece = float((lg[:so] - lce[off:, 1:]).abs().max())
+    eue = float((lg[so:] - lue[off:, 1:]).abs().max())
+    print(f"NAR {dt} logits max|diff| vs fp32 oracle cond {ec:.3e} uncond {eu:.3e}; vs operand-rounding oracle cond {ece:.3e} uncond {eue:.3e} "
+          f"(|logit| max {float(lc.abs().max()):.2f})")
     assert ec < tol and eu < tol
+    assert ece < tol / 2 and eue < tol / 2
 
 
 def test_full_size_goldens_f32(dev, gold_dir, full_bundle):
@@ -314,12 +315,27 @@ def test_full_size_goldens_f32(dev, gold_dir, full_bundle):
     _x = torch.from_numpy(fx["x_l0"])[None, :, None].repeat(1, 1, 8)
     batch = (c_text, c_codes, torch.tensor([c_text.shape[1]]), torch.tensor([c_codes.shape[1]]), _x, torch.zeros(1, _x.shape[1], dtype=torch.bool))
     g = torch.Generator().manual_seed(int(fx["seed"]))
+    traj = []
     outn = perform_simple_inference(nar, batch, MultinomialDiffusion(1025, timesteps=200), int(fx["T_run"]), torch.float16,
                                     dsh=DSH(last_greedy=True, x_0_temp=0.7, guidance_w=3, deep_clone=True, q0_override_steps=20),
                                     uniform=lambda shp: torch.rand(shp, generator=g).to(dev),
-                                    randint=lambda shp: torch.randint(0, 1025, shp, dtype=torch.long, generator=g))
+                                    randint=lambda shp: torch.randint(0, 1025, shp, dtype=torch.long, generator=g), on_step=traj.append)
     n_bad = int((outn[0].cpu() != torch.from_numpy(fx["final"])).sum())
-    print(f"full-size NAR: {n_bad}/{fx['final'].size} ids differ from the reference")
+    # every step of the engine's own trajectory replayed by the oracle (on the GPU: full-size forwards): ids equal up to oracle ties
+    import mars5_oracle as O
+    from parity_util import gate_trajectory
+    off = c_codes.shape[1]
+    S = off + _x.shape[1]
+    x_known = torch.zeros(S, 8, dtype=torch.long)
+    m = torch.zeros(S, 8, dtype=torch.uint8)
+    m[:, 0] = 1
+    m[:off] = 1
+    x_known[:off] = c_codes[0]
+    x_known[off:, 0] = torch.from_numpy(fx["x_l0"])
+    n_diff, bad = gate_trajectory(O, b.nar_ckpt["model"], b.nar_shape.nhead, c_text[0], c_codes[0], x_known, m, traj, 3.0, 0.7, 20, 5e-3, dev)
+    print(f"full-size NAR: {n_bad}/{fx['final'].size} final ids differ from the reference; per-step replay: {n_diff} tie-excused, {len(bad)} unexcused")
+    assert not bad, bad[:5]
+    assert n_bad == 0 or n_diff > 0, "final ids differ although every step equals the oracle's"
     assert n_bad <= 0.02 * fx["final"].size
 
 
@@ -562,8 +578,9 @@ def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle)
     """The public ``Mars5TTS.tts()`` against the reference's OWN ``inference.py`` (fixture: the unmodified reference on
     CPU, full-size seeded weights, deep and shallow clone, README sampling settings; Encodec / Vocos replaced on both
     sides by the deterministic stand-ins of oracle/fakes.py).  fp32 engine, the reference's CPU random stream replayed
-    draw by draw: the AR frames must be identical, the final codes identical up to the rare libm-ulp near-tie of the
-    free-running diffusion (<= 2 %), and when they are identical so is the trimmed waveform."""
+    draw by draw: the AR frames must be identical and so must the final codes -- unless a step of the engine's own
+    trajectory, replayed by the oracle, hit a tie of the oracle's top-2 scores (then the free-running diffusion may
+    legally cascade, bounded at 2 %); when the codes are identical so is the trimmed waveform."""
     import json as _json
     import fakes
     from inference import InferenceConfig, Mars5TTS
@@ -582,6 +599,8 @@ def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle)
         cfg = InferenceConfig(deep_clone=c["deep"], temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
                               generate_max_len_override=c["max_len"])
         hooks = fakes.CpuStreamHooks(c["seed"], dev)
+        traj = []
+        hooks.nar_on_step = traj.append
         gen, wav = m.tts(c["text"], torch.zeros(320 * c["ref_frames"]), c["transcript"], cfg, rng_hooks=hooks)
         assert gen.cpu().tolist() == fx[f"gen_{i}"].tolist(), f"case {i}: AR frames differ from the reference"
         final = m.vocos.last_tokens.T.contiguous().numpy()
@@ -589,6 +608,28 @@ def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle)
         assert final.shape == ref_final.shape
         n_bad = int((final != ref_final).sum())
         print(f"tts case {i}: {gen.shape[0]} frames, final codes differing from the reference: {n_bad}/{ref_final.size}")
+        if True:
+            # replay all 200 steps of the engine's own trajectory through the oracle (on the GPU): every id must be the
+            # oracle's, except at oracle ties -- and only such a tie can excuse final codes that are not bit-equal
+            import mars5_oracle as O
+            from parity_util import gate_trajectory
+            codes = m.codec.encode(torch.zeros(1, 1, 320 * c["ref_frames"]))[0][0][0].T.contiguous().cpu()     # (Lc, 8)
+            tt_ids = m.texttok.encode("<|startoftext|>" + ((c["transcript"] + ' ') if c["deep"] else '') + c["text"].strip() + "<|endoftext|>",
+                                      allowed_special='all')
+            off = codes.shape[0] if c["deep"] else 0
+            S = traj[0]["x_t"].shape[0]
+            x_known = torch.zeros(S, 8, dtype=torch.long)
+            mk = torch.zeros(S, 8, dtype=torch.uint8)
+            mk[:, 0] = 1
+            if c["deep"]:
+                x_known[:off] = codes
+                mk[:off] = 1
+            x_known[off:, 0] = gen.cpu()
+            n_diff, bad = gate_trajectory(O, b.nar_ckpt["model"], b.nar_shape.nhead, torch.tensor(tt_ids), codes, x_known, mk, traj,
+                                          3.0, 0.7, 20, 5e-3, dev)
+            print(f"tts case {i}: per-step replay of the engine trajectory: {n_diff} tie-excused, {len(bad)} unexcused id differences")
+            assert not bad, bad[:5]
+            assert n_bad == 0 or n_diff > 0, "final codes differ although every step equals the oracle's"
         assert n_bad <= 0.02 * ref_final.size
         if n_bad == 0:
             assert wav.shape[-1] == fx[f"wav_{i}"].shape[-1]

@@ -641,8 +641,9 @@ def test_ar_sampler_topk_ties_and_masked_threshold(dev):
 
 
 def test_nar_sample_vs_oracle(dev):
-    """Fused posterior/sample kernel vs the oracle's reverse_step on identical logits and
-    uniforms: integer outputs, exact up to libm-ulp near-ties (bound: <= 2 of ~5k rows)."""
+    """Fused posterior/sample kernel vs the oracle's reverse_step on identical logits and uniforms: integer
+    outputs, EQUAL -- a differing id is accepted only where the oracle's own scores of the two classes are
+    within float noise of each other (tests/parity_util.py), i.e. a tie either side may break."""
     import mars5_oracle as O
     from mars5_tts_amd import _lib as L, ops
     from mars5_tts_amd.tables import log_eps, nar_step_consts
@@ -665,7 +666,7 @@ def test_nar_sample_vs_oracle(dev):
         fc = torch.zeros(S, Q, K)
         fu = torch.zeros(S, Q, K)
         fc[off:, 1:], fu[off:, 1:] = lc, lu
-        ref = O.reverse_step(tb, fc, fu, x_t, x_known, m, t, u1, u2 if t > 0 else None, 3.0, 0.7)
+        ref, s_unk, s_kn = O.reverse_step(tb, fc, fu, x_t, x_known, m, t, u1, u2 if t > 0 else None, 3.0, 0.7, return_scores=True)
         if 20 < t:
             ref[:, 0] = x_known[:, 0]
         Kp = 1028
@@ -681,10 +682,11 @@ def test_nar_sample_vs_oracle(dev):
                             log_eps=log_eps(), div_mode=0, q0_override_steps=20)
         ops.nar_sample(a)
         torch.cuda.synchronize()
-        bad = int((xd.cpu() != ref).sum())
-        total_bad += bad
-        assert bad <= 2, f"t={t}: {bad} of {S * Q} ids differ from the oracle"
-    print(f"nar_sample: {total_bad} mismatching ids over {len(times) * S * Q}")
+        from parity_util import ungated_mismatches
+        n_mis, bad = ungated_mismatches(xd.cpu(), ref, s_unk, s_kn, m)
+        total_bad += n_mis
+        assert not bad, f"t={t}: ids differ from the oracle away from any tie: {bad[:5]}"
+    print(f"nar_sample: {total_bad} tie-excused mismatching ids over {len(times) * S * Q}")
 
 
 def test_graph_capture_replay(dev):

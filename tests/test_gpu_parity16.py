@@ -1,0 +1,249 @@
+"""Parity of the BENCHMARKED configuration: the 16-bit engines (bf16 = BASELINE's dtype, f16 = the
+reference's own GPU dtype) at the real MARS5 geometry and at bench length, against the oracle.
+
+The oracle is plain torch, so it runs on the GPU here (``with torch.device(dev)``): that makes the
+full-size / full-length comparison affordable (450 teacher-forced decode steps of a 26-layer
+1536-d model, a 16-layer decoder pass over 1349 rows) and takes exp / log from the same device
+math library as the kernels.  Two oracle modes (oracle/mars5_oracle.py, "reduced-precision emulation"):
+  * ``dt=None``  fp32 arithmetic on the dt-rounded weights: bounds what the operand dtype costs;
+  * ``dt=<16-bit>``  the reference's autocast rounding points (ar_generate.py:59,67): the engine's
+    implementation is then checked to a much tighter tolerance.
+Tolerances are absolute on logits whose magnitude is printed next to them.
+"""
+import io
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TEXT = "The quick brown rat jumped over the lazy dogs twice."
+TRANSCRIPT = "We actually haven't managed to meet demand this year."
+
+# max |engine logit - oracle logit| allowed, per operand dtype:  vs the autocast-emulating oracle / vs the fp32 oracle
+AR_TOL_EMU = {torch.bfloat16: 0.20, torch.float16: 0.03}
+AR_TOL_F32 = {torch.bfloat16: 0.40, torch.float16: 0.06}
+NAR_TOL_EMU = {torch.bfloat16: 0.04, torch.float16: 0.006}      # relative to max |logit|
+NAR_TOL_F32 = {torch.bfloat16: 0.08, torch.float16: 0.012}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _toks(b):
+    from mars5_tts_amd import minbpe
+    tt = minbpe.RegexTokenizer()
+    tt.load(io.BytesIO(b.ar_ckpt["vocab"]["texttok.model"].encode()))
+    st = minbpe.CodebookTokenizer()
+    st.load(io.BytesIO(b.ar_ckpt["vocab"]["speechtok.model"].encode()))
+    return tt, st
+
+
+def _bench_prompt(b, tt, st, ref_codes):
+    """The AR prompt bench.py builds for BASELINE configs[1] (deep clone: transcript + text + reference L0 tokens)."""
+    text = tt.encode("<|startoftext|>" + TRANSCRIPT + ' ' + TEXT.strip() + "<|endoftext|>", allowed_special='all')
+    sp = st.encode(' '.join(str(t) for t in ref_codes[0, 0].tolist()))
+    return torch.tensor(text + [s + b.n_text for s in sp], dtype=torch.long), len(text)
+
+
+def _ar_compare(dev, b, dt, prompt, ref, N, n_f32, odev, text_len, tol_emu, tol_f32, min_gen):
+    """Engine (graph + eager) vs oracle, teacher-forced on the engine's greedy tokens.  Returns the statistics dict."""
+    import mars5_oracle as O
+    from mars5_tts_amd import _lib as L, model
+    from mars5_tts_amd.ar_engine import ARSamplingConfig, ARSession
+    tt, st = _toks(b)
+    a = b.ar_shape
+    lm = model.CodecLM(a.n_vocab, dim=a.dim, nhead=a.nhead, n_layers=a.n_layers, n_spk_layers=a.n_spk_layers,
+                       dim_ff_scale=a.hidden_dim / a.dim + 1e-9, sliding_window=a.sliding_window)
+    lm.load_state_dict(b.ar_ckpt["model"])
+    eng = lm.to(dev).set_engine_dtype(dt).engine()
+    P, V = int(prompt.shape[0]), a.n_vocab
+    n_text = b.n_text
+    eos = n_text + st.special_tokens["<|endofspeech|>"]
+    kw = dict(temperature=0.7, topk=1, top_p=0.2, alpha_frequency=3.0, alpha_presence=0.4, penalty_window=100,
+              eos_penalty_factor=50.0, eos_penalty_decay=0.5, n_phones_gen=100 * text_len)
+    noise = torch.ones(N, V, device=dev)
+
+    # ---- engine, graph replay (the timed path)
+    sg = ARSession(eng, P + N)
+    sg.configure_sampler(ARSamplingConfig(**kw), n_text, eos, noise)
+    sg.prefill(prompt, ref)
+    tok_graph = sg.decode(use_graph=True).cpu()
+    del sg
+    # ---- engine, eager, logits of every step
+    se = ARSession(eng, P + N)
+    se.configure_sampler(ARSamplingConfig(**kw), n_text, eos, noise)
+    se.prefill(prompt, ref)
+    sv = se.stream.cuda_stream
+    eng_logits = []
+    for i in range(N):
+        if i:
+            se.enqueue_layers(sv)
+        se.enqueue_head_and_sample(sv)
+        se.stream.synchronize()
+        eng_logits.append(se.logits.clone())
+    n_tok = int(se.state.cpu()[L.ST_NTOK])
+    tok_eager = se.tokens[:n_tok].cpu()
+    assert tok_graph.tolist() == tok_eager.tolist(), "hipGraph replay and the eager launch sequence disagree"
+    n_gen = n_tok - P
+    assert n_gen >= min_gen, f"only {n_gen} tokens generated: the forced-length settings did not hold"
+
+    # ---- oracle (on `odev`), teacher-forced on the engine's tokens
+    okw = dict(temperature=0.7, alpha_frequency=3.0, alpha_presence=0.4, penalty_window=100, eos_penalty_factor=50.0, eos_penalty_decay=0.5,
+               n_phones_gen=100 * text_len)
+    p = O.ARSamplingParams(top_k=1, top_p=0.2, **okw)
+    p_nofilter = O.ARSamplingParams(top_k=0, top_p=1.0, **okw)
+    with torch.device(odev), torch.inference_mode():
+        sd = O.round_linear_weights({k: v.to(odev) for k, v in b.ar_ckpt["model"].items()}, dt)
+        forced = tok_eager.to(odev)
+        noise1 = torch.ones(N, V)
+        args = (sd, a.nhead, n_text, b.n_speech, st.special_tokens["<|endofspeech|>"], prompt.to(odev), ref.to(odev), P + N, p)
+        _, lo_emu, choices = O.ar_generate_oracle(*args, noise=noise1, forced=forced, dt=dt)
+        _, lo_f32, _ = O.ar_generate_oracle(*args, noise=noise1, forced=forced[:P + n_f32], dt=None)
+        assert len(lo_emu) >= n_gen and len(lo_f32) >= n_f32
+        err_emu = [float((eng_logits[i].to(odev) - lo_emu[i]).abs().max()) for i in range(n_gen)]
+        err_f32 = [float((eng_logits[i].to(odev) - lo_f32[i]).abs().max()) for i in range(n_f32)]
+        zmax = max(float(l.abs().max()) for l in lo_emu[:n_f32])
+        flips = [i for i in range(n_gen) if choices[i] != int(tok_eager[P + i])]
+        bad_flips = []
+        for i in flips:
+            prev = tok_eager[P:P + i].tolist()
+            z = O.filter_logits(lo_emu[i], prev, p_nofilter, n_text, eos)
+            margin = float(z[choices[i]] - z[int(tok_eager[P + i])])
+            if not margin <= 2.0 * err_emu[i] / 0.7 + 1e-6:
+                bad_flips.append((i, margin, err_emu[i]))
+    first = flips[0] if flips else None
+    print(f"AR {dt} dim {a.dim} x {a.n_layers}L, P={P}, {n_gen} tokens: max|dlogit| vs autocast-emulating oracle {max(err_emu):.4f} "
+          f"(mean {sum(err_emu) / n_gen:.4f}), vs fp32 oracle ({n_f32} steps) {max(err_f32):.4f}; max|logit| {zmax:.2f}; "
+          f"greedy agreement {n_gen - len(flips)}/{n_gen}, first divergence at step {first}")
+    assert max(err_emu) <= tol_emu, (max(err_emu), err_emu.index(max(err_emu)))
+    assert max(err_f32) <= tol_f32, (max(err_f32), err_f32.index(max(err_f32)))
+    assert not bad_flips, f"token flips outside the oracle's near-tie margin: {bad_flips[:5]}"
+    return dict(n_gen=n_gen, first_divergence=first, agreement=(n_gen - len(flips)) / n_gen, err_emu=max(err_emu), err_f32=max(err_f32))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_ar_full_size_16bit_450_tokens_vs_oracle(dev, full_bundle, dt):
+    """BASELINE configs[1]'s AR stage as timed by bench.py (prompt 488, 450 generated tokens, 16-bit operands), greedy
+    so that no random stream is involved: (1) the hipGraph decode (what bench.py times) and the eager launch sequence
+    give the same tokens; (2) every step's logits, teacher-forced on the engine's own tokens, are within AR_TOL_EMU of
+    the oracle that rounds where the reference's autocast rounds, and the first 64 steps within AR_TOL_F32 of the fp32
+    oracle; (3) wherever the oracle would have picked a different token, its own margin between the two candidates is
+    inside twice the measured logit error of that step (a legal near-tie flip), and the agreement rate is reported."""
+    from mars5_tts_amd import synth
+    b = full_bundle
+    tt, st = _toks(b)
+    ref_codes = synth.make_ref_codes(450, seed=7)
+    prompt, _ = _bench_prompt(b, tt, st, ref_codes)
+    assert 480 <= prompt.shape[0] <= 500
+    _ar_compare(dev, b, dt, prompt, ref_codes[0].T.contiguous(), 450, 64, dev, len(TEXT), AR_TOL_EMU[dt], AR_TOL_F32[dt], 400)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_ar_tiny_16bit_vs_cpu_oracle(dev, tiny_bundle, dt):
+    """The same comparison at test scale against the oracle on the CPU (the pinned instrument itself, CPU libm): the
+    generic-shape GEMV kernels (the streaming kernels only cover the real geometry) and a BPE-merged speech prompt."""
+    from mars5_tts_amd import synth
+    b = tiny_bundle
+    tt, st = _toks(b)
+    ref_codes = synth.make_ref_codes(40, seed=7, merge_friendly=True)
+    prompt, _ = _bench_prompt(b, tt, st, ref_codes)
+    _ar_compare(dev, b, dt, prompt, ref_codes[0].T.contiguous(), 48, 48, "cpu", len(TEXT), AR_TOL_EMU[dt], AR_TOL_F32[dt], 40)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_nar_full_size_16bit_forward_and_step_vs_oracle(dev, full_bundle, dt):
+    """BASELINE configs[1]'s NAR stage at bench shape (S = 1349 rows: 899 prompt + 450 generated, 38 text tokens, both
+    guidance branches), 16-bit operands: logits of one decoder pass vs the oracle (fp32 reference arithmetic, and with
+    the engine's operand rounding), then one whole reverse step (forward + fused posterior / Gumbel sample) on the same
+    uniforms: the ids are reported as an agreement rate, and with the ORACLE's logits fed to the kernel the ids must
+    be equal wherever the oracle's own top-2 scores are further apart than the float noise of the formula."""
+    import mars5_oracle as O
+    from mars5_tts_amd import model, synth
+    from mars5_tts_amd.nar_engine import NARConfig, NARSession
+    b = full_bundle
+    n = b.nar_shape
+    nar = model.ResidualTransformer(n.n_text_vocab, n_quant=n.n_quant, dim=n.dim, nhead=n.nhead, enc_layers=n.enc_layers,
+                                    dec_layers=n.dec_layers, n_spk_layers=n.n_spk_layers, t_emb_dim=n.t_emb_dim, p_cond_drop=0, dropout=0)
+    nar.load_state_dict(b.nar_ckpt["model"])
+    eng = nar.to(dev).set_engine_dtype(dt).engine()
+    g = torch.Generator().manual_seed(3)
+    S, off, Lt, t = 1349, 899, 38, 100
+    K = n.n_quant
+    c_text = torch.randint(0, n.n_text_vocab, (Lt,), generator=g)
+    c_codes = synth.make_ref_codes(450, seed=7)[0].T.contiguous()
+    x = torch.randint(0, 1024, (S, 8), generator=g)
+    x_known = torch.zeros(S, 8, dtype=torch.long)
+    m = torch.zeros(S, 8, dtype=torch.uint8)
+    m[:, 0] = 1
+    m[:off] = 1
+    x_known[:off] = x[:off]
+    x_known[:, 0] = x[:, 0]
+    sess = NARSession(eng, NARConfig(T=200, x_0_temp=0.7, guidance_w=3.0, deep_clone=True, q0_override_steps=20))
+    sess.prepare(c_text, c_codes, x, x_known, m, off, [t])
+    sess.enqueue_forward(sess.stream.cuda_stream)
+    sess.stream.synchronize()
+    so = S - off
+    lg = sess.logits[:, :, :K].clone()                      # (2*so, 7, K): cond rows then uncond rows
+    with torch.device(dev), torch.inference_mode():
+        sd = O.round_linear_weights({k: v.to(dev) for k, v in b.nar_ckpt["model"].items()}, dt)
+        res = {}
+        for name, odt in (("f32", None), ("emu", dt)):
+            lc = O.nar_forward(sd, n.nhead, c_text.to(dev), c_codes.to(dev), x.to(dev), t, False, dt=odt)
+            lu = O.nar_forward(sd, n.nhead, c_text.to(dev), c_codes.to(dev), x.to(dev), t, True, dt=odt)
+            zmax = float(torch.maximum(lc.abs().max(), lu.abs().max()))
+            ec = float((lg[:so] - lc[off:, 1:]).abs().max()) / zmax
+            eu = float((lg[so:] - lu[off:, 1:]).abs().max()) / zmax
+            am = float((lg[:so].argmax(-1) == lc[off:, 1:].argmax(-1)).float().mean())
+            res[name] = (ec, eu, zmax, am, lc, lu)
+        print(f"NAR {dt} S={S}: max|dlogit|/max|logit| cond/uncond vs fp32 oracle {res['f32'][0]:.4f}/{res['f32'][1]:.4f}, vs operand-rounding "
+              f"oracle {res['emu'][0]:.4f}/{res['emu'][1]:.4f}; max|logit| {res['f32'][2]:.2f}; argmax agreement vs fp32 {res['f32'][3]:.4f}")
+        assert max(res["emu"][0], res["emu"][1]) <= NAR_TOL_EMU[dt]
+        assert max(res["f32"][0], res["f32"][1]) <= NAR_TOL_F32[dt]
+        # ---- one whole reverse step on the same uniforms
+        from mars5_tts_amd import _lib as L, ops
+        from mars5_tts_amd.tables import log_eps
+        from parity_util import ungated_mismatches
+        gg = torch.Generator(device=dev).manual_seed(11)
+        u1 = torch.rand((1, S, 8, K), generator=gg, device=dev)
+        u2 = torch.rand((1, S, 8, K), generator=gg, device=dev)
+        draws = iter([u1, u2])
+        sess2 = NARSession(eng, NARConfig(T=200, x_0_temp=0.7, guidance_w=3.0, deep_clone=True, q0_override_steps=20))
+        sess2.prepare(c_text, c_codes, x, x_known, m, off, [t])
+        sess2.step(lambda shp: next(draws), use_graph=True)
+        sess2.stream.synchronize()
+        x_eng = sess2.x.clone()
+        tb = O.diffusion_tables(K, 200)
+        lc, lu = res["f32"][4], res["f32"][5]
+        mb = m.to(dev).bool()
+        ref, s_unk, s_kn = O.reverse_step(tb, lc, lu, x.to(dev), x_known.to(dev), mb, t, u1[0], u2[0], 3.0, 0.7, return_scores=True)
+        ref[:, 0] = x_known[:, 0].to(dev)                   # t > q0_override_steps
+        agree = float((x_eng[off:, 1:] == ref[off:, 1:]).float().mean())
+        # known positions (prompt frames, codebook 0) do not depend on the logits: exact, up to float ties
+        kn_mask = mb.clone()
+        n_kn, bad_kn = ungated_mismatches(torch.where(kn_mask, x_eng, ref), ref, s_unk, s_kn, mb)
+        print(f"NAR {dt}: one reverse step at t={t} on identical uniforms: sampled ids equal to the fp32 oracle's {agree:.4f} "
+              f"(Gumbel arg-max over 1025 near-flat classes of a random-weight model: logit noise x (|w|+|1-w|)/T = 7.1 decides near-ties); "
+              f"known-branch mismatches {n_kn} (unexcused {len(bad_kn)})")
+        assert not bad_kn, bad_kn[:5]
+        assert agree >= 0.5
+        # ---- the fused posterior / sample kernel at bench size on the ORACLE's logits: ids equal up to excused ties
+        Kp = (K + 3) // 4 * 4
+        lgc = torch.zeros(so, 7, Kp)
+        lgu = torch.zeros(so, 7, Kp)
+        lgc[..., :K], lgu[..., :K] = lc[off:, 1:], lu[off:, 1:]
+        xd = x.to(dev).clone()
+        xk, md = x_known.to(dev), m.to(dev)
+        step = torch.zeros(1, dtype=torch.int32)
+        a = L.NarSampleArgs(logits_c=lgc.data_ptr(), logits_u=lgu.data_ptr(), ld_row=7 * Kp, ld_q=Kp, S=S, n_q=8, K=K, row_offset=off,
+                            x=xd.data_ptr(), x_known=xk.data_ptr(), m=md.data_ptr(), u1=u1.data_ptr(), u2=u2.data_ptr(),
+                            consts=sess2.consts.data_ptr(), step=step.data_ptr(), guidance_w=3.0, temperature=0.7, log_eps=log_eps(),
+                            div_mode=0, q0_override_steps=20)
+        ops.nar_sample(a)
+        torch.cuda.synchronize()
+        n_mis, bad = ungated_mismatches(xd, ref, s_unk, s_kn, mb)
+        print(f"nar_sample_kernel at S={S} on the oracle's logits: {n_mis} of {S * 8} ids differ, {len(bad)} not excused by an oracle tie")
+        assert not bad, bad[:5]
