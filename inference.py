@@ -27,7 +27,7 @@ from mars5_tts_amd.trim import trim
 
 @dataclass
 class InferenceConfig():
-    """ The defaults configuration variables for TTS inference. """
+    """Inference settings: the 21 fields, names and defaults of the reference's ``InferenceConfig`` (inference.py:24-77)."""
     ## >>>> AR CONFIG
     temperature: float = 0.7
     top_k: int = 200          # 0 disables it
@@ -108,7 +108,7 @@ class Mars5TTS:
     # ------------------------------------------------------------------ audio ends (third party)
     @torch.inference_mode()
     def vocode(self, tokens: Tensor) -> Tensor:
-        """ Vocodes tokens of shape (seq_len, n_q) """
+        """(seq_len, n_q) Encodec codes -> waveform (1, T), through the injected Vocos model (reference inference.py:160-172)."""
         _need(self.vocos, "vocos")
         tokens = tokens.T.to(self.device)
         features = self.vocos.codes_to_features(tokens)
@@ -117,7 +117,7 @@ class Mars5TTS:
 
     @torch.inference_mode()
     def get_speaker_embedding(self, ref_audio: Tensor) -> Tensor:
-        """ Given `ref_audio` (bs, T) audio tensor, compute the implicit speaker embedding of shape (bs, dim). """
+        """Speaker vector (bs, dim) of the AR model's reference encoder for `ref_audio` (bs, T) (reference inference.py:174-199)."""
         _need(self.codec, "encodec")
         if ref_audio.dim() == 1:
             ref_audio = ref_audio[None]
@@ -204,7 +204,7 @@ class Mars5TTS:
         # the NAR stage's conditioning work (text encoder for all 200 steps, cross-attention K / V) does not depend on the
         # AR output: enqueue it on the NAR stream now, it runs beside the AR decode
         nar_sess = begin_inference(self.codecnar, torch.tensor(pr["text_tokens"], dtype=torch.long, device=self.device)[None],
-                                   pr["prompt_codec"].permute(0, 2, 1), diff.num_timesteps, dsh=self._dsh(cfg))
+                                   pr["prompt_codec"].permute(0, 2, 1), diff.num_timesteps, dsh=self._dsh(cfg), diff=diff)
         ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
                                fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
                                n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
@@ -238,7 +238,9 @@ class Mars5TTS:
         gens = []
         for i in range(n):
             g = torch.Generator(device=self.device)
-            g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.seed()))
+            # no seeds given: derive them from the global CPU generator (honours torch.manual_seed, and -- unlike
+            # torch.seed() -- leaves every global generator seeded as the caller left it)
+            g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
             gens.append(g)
         def cfg_of(i):
             return cfg if max_lens is None else dataclasses.replace(cfg, generate_max_len_override=int(max_lens[i]))
@@ -275,16 +277,16 @@ class Mars5TTS:
     @torch.inference_mode()
     def tts(self, text: str, ref_audio: Tensor, ref_transcript: Optional[str] = None,
             cfg: Optional[InferenceConfig] = InferenceConfig(), rng_hooks=None) -> Tuple[Tensor, Tensor]:
-        """ Perform TTS for `text`, given a reference audio `ref_audio` (of shape [sequence_length,], sampled at 24kHz)
-        which has an associated `ref_transcript`.  Returns `ar_codes` (seq_len,) and `out_wav` (T,) at 24kHz. """
+        """Speak `text` in the voice of `ref_audio` ((T,) samples at 24 kHz; `ref_transcript` = what it says, required
+        for deep clone).  Returns (L0 codes of the generated frames (seq_len,), waveform (T_out,) at 24 kHz) like the
+        reference ``tts`` (inference.py:201-307), with the same AssertionError / warning conditions."""
         if cfg.deep_clone and ref_transcript is None:
-            raise AssertionError(
-                ("Inference config deep clone is set to true, but reference transcript not specified! "
-                 "Please specify the transcript of the prompt, or set deep_clone=False in the inference `cfg` argument."))
+            raise AssertionError("cfg.deep_clone=True needs `ref_transcript` (the words spoken in `ref_audio`); pass it, or use "
+                                 "InferenceConfig(deep_clone=False) for a shallow clone")
         ref_dur = ref_audio.shape[-1] / self.sr
         if ref_dur > cfg.max_prompt_dur:
-            logging.warning((f"Reference audio duration is {ref_dur:.2f} > max suggested ref audio. "
-                             f"Expect quality degradations. We recommend you trim prompt to be shorter than max prompt length."))
+            logging.warning(f"reference audio is {ref_dur:.2f} s long, above cfg.max_prompt_dur = {cfg.max_prompt_dur} s: quality "
+                            f"usually drops; a shorter reference is recommended")
         _need(self.codec, "encodec")
         if ref_audio.dim() == 1:
             ref_audio = ref_audio[None]

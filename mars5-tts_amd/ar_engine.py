@@ -98,16 +98,20 @@ class ARSession:
         assert max_len + 1 <= model.max_pos
         H, D, F, V = s.nhead, s.dim, s.hidden_dim, s.n_vocab
         bf = buffers or {}
-        self.kc = bf["kc"] if "kc" in bf else torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
-        self.vc = bf["vc"] if "vc" in bf else torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
-        self.xdec = bf["xdec"] if "xdec" in bf else torch.zeros(D, dtype=torch.float32, device=dev)
-        self.qbuf = torch.zeros(D, dtype=dt, device=dev)
-        self.hbuf = torch.zeros(F, dtype=dt, device=dev)
-        self.part = torch.zeros(H, NSPLIT, L.ATTN_PART, dtype=torch.float32, device=dev)
-        self.logits = bf["logits"] if "logits" in bf else torch.zeros(V, dtype=torch.float32, device=dev)
-        self.state = bf["state"] if "state" in bf else torch.zeros(L.ST_WORDS, dtype=torch.int32, device=dev)
-        self.tokens = bf["tokens"] if "tokens" in bf else torch.zeros(max_len + 1, dtype=torch.int64, device=dev)
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        # the buffers are zero-filled ON the session stream (behind the caller's pending work): a memset left on the
+        # caller's stream could otherwise land after this stream has started writing state / KV rows
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            self.kc = bf["kc"] if "kc" in bf else torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
+            self.vc = bf["vc"] if "vc" in bf else torch.zeros(s.n_layers, H, self.w_alloc, 64, dtype=dt, device=dev)
+            self.xdec = bf["xdec"] if "xdec" in bf else torch.zeros(D, dtype=torch.float32, device=dev)
+            self.qbuf = torch.zeros(D, dtype=dt, device=dev)
+            self.hbuf = torch.zeros(F, dtype=dt, device=dev)
+            self.part = torch.zeros(H, NSPLIT, L.ATTN_PART, dtype=torch.float32, device=dev)
+            self.logits = bf["logits"] if "logits" in bf else torch.zeros(V, dtype=torch.float32, device=dev)
+            self.state = bf["state"] if "state" in bf else torch.zeros(L.ST_WORDS, dtype=torch.int32, device=dev)
+            self.tokens = bf["tokens"] if "tokens" in bf else torch.zeros(max_len + 1, dtype=torch.int64, device=dev)
         self.graph: Optional[ops.Graph] = None
         self._sample_args: Optional[L.SampleArgs] = None
         self._keep: List[torch.Tensor] = []
@@ -125,6 +129,7 @@ class ARSession:
         M = P + 1
         assert M <= self.window, "prefill longer than the sliding window is not supported"
         H, D, F = s.nhead, s.dim, s.hidden_dim
+        self.stream.wait_stream(torch.cuda.current_stream(dev))       # prompt / ref_codes may have been produced there
         with torch.cuda.stream(self.stream):
             prompt = prompt.to(dev)
             ref_codes = ref_codes.to(dev).contiguous()
@@ -241,12 +246,24 @@ class ARSession:
         self.enqueue_head_and_sample(st)
         self.graph = ops.Graph().end(st)
 
-    def decode(self, use_graph: bool = True, poll: int = 32) -> torch.Tensor:
+    def decode(self, use_graph: bool = True, poll: int = 32, noise_fill=None) -> torch.Tensor:
         """Run sampler for the prefill logits, then decode steps until EOS / max_len.
-        Returns the token sequence (prompt + generated) like ``ar_generate`` (EOS not appended)."""
+        Returns the token sequence (prompt + generated) like ``ar_generate`` (EOS not appended).
+        `noise_fill(lo, hi)`: called (host side, before the launches that read them) to draw noise rows lo..hi-1
+        on this session's stream -- sampler call i reads row i -- so an utterance that stops early never pays for the
+        rows of the steps it does not run; None = the noise tensor is already complete."""
         st = self.stream.cuda_stream
         if self.P >= self.max_len:
             return self.tokens[: self.P].clone()
+        filled = 0
+
+        def need(hi):
+            nonlocal filled
+            hi = min(hi, self.n_noise)
+            if noise_fill is not None and hi > filled:
+                filled = noise_fill(filled, hi) or hi
+
+        need(1)
         self.enqueue_head_and_sample(st)                       # token P from the prefill's last row
         budget = min(self.max_len - self.P - 1, self.n_noise - 1)
         if use_graph and self.graph is None and budget > 0:
@@ -256,6 +273,7 @@ class ARSession:
         done = 0
         while done < budget:
             n = min(poll, budget - done)
+            need(done + n + 1)                                 # the n steps below read rows done+1 .. done+n
             for _ in range(n):
                 if use_graph:
                     self.graph.launch(st)
@@ -296,21 +314,23 @@ class ARBatchSession:
         self.w_alloc = min(s.sliding_window, max(max_lens) + 1)
         assert max(max_lens) + 1 <= model.max_pos
         H, D, F, V, Lr = s.nhead, s.dim, s.hidden_dim, s.n_vocab, s.n_layers
-        self.kc = torch.zeros(B, Lr, H, self.w_alloc, 64, dtype=dt, device=dev)
-        self.vc = torch.zeros(B, Lr, H, self.w_alloc, 64, dtype=dt, device=dev)
-        self.x = torch.zeros(B, D, dtype=torch.float32, device=dev)
-        self.xn = torch.zeros(B, D, dtype=dt, device=dev)
-        self.qkv = torch.zeros(B, 3 * D, dtype=dt, device=dev)
-        self.qbuf = torch.zeros(B, D, dtype=dt, device=dev)
-        self.att = torch.zeros(B, D, dtype=dt, device=dev)
-        self.hbuf = torch.zeros(B, F, dtype=dt, device=dev)
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
         # key-range splits of the cache scan: enough workgroups to fill the chip, no more (each costs a partial + merge)
         self.nsplit = max(1, min(NSPLIT, 1 << max(0, (1024 // (H * B)).bit_length() - 1)))
-        self.part = torch.zeros(B, H, self.nsplit, L.ATTN_PART, dtype=torch.float32, device=dev)
-        self.logits = torch.zeros(B, V, dtype=torch.float32, device=dev)
-        self.state = torch.zeros(B, L.ST_WORDS, dtype=torch.int32, device=dev)
-        self.tokens = torch.zeros(B, max(max_lens) + 1, dtype=torch.int64, device=dev)
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(self.stream):                           # zero-fills ordered on the session stream (see ARSession)
+            self.kc = torch.zeros(B, Lr, H, self.w_alloc, 64, dtype=dt, device=dev)
+            self.vc = torch.zeros(B, Lr, H, self.w_alloc, 64, dtype=dt, device=dev)
+            self.x = torch.zeros(B, D, dtype=torch.float32, device=dev)
+            self.xn = torch.zeros(B, D, dtype=dt, device=dev)
+            self.qkv = torch.zeros(B, 3 * D, dtype=dt, device=dev)
+            self.qbuf = torch.zeros(B, D, dtype=dt, device=dev)
+            self.att = torch.zeros(B, D, dtype=dt, device=dev)
+            self.hbuf = torch.zeros(B, F, dtype=dt, device=dev)
+            self.part = torch.zeros(B, H, self.nsplit, L.ATTN_PART, dtype=torch.float32, device=dev)
+            self.logits = torch.zeros(B, V, dtype=torch.float32, device=dev)
+            self.state = torch.zeros(B, L.ST_WORDS, dtype=torch.int32, device=dev)
+            self.tokens = torch.zeros(B, max(max_lens) + 1, dtype=torch.int64, device=dev)
         self.subs = [ARSession(model, max_lens[b], self.stream, w_alloc=self.w_alloc,
                                buffers=dict(kc=self.kc[b], vc=self.vc[b], xdec=self.x[b], logits=self.logits[b], state=self.state[b],
                                             tokens=self.tokens[b])) for b in range(B)]
@@ -378,10 +398,20 @@ class ARBatchSession:
             ops.gemm(self.xn, m.w13[l], self.hbuf, L.EPI_SWIGLU, stream=st)
             ops.gemm(self.hbuf, m.w2[l], self.x, L.EPI_RESIDUAL, stream=st)
 
-    def decode(self, use_graph: bool = True, poll: int = 32) -> List[torch.Tensor]:
+    def decode(self, use_graph: bool = True, poll: int = 32, noise_fill=None) -> List[torch.Tensor]:
         """Sampler for the prefill logits of every sequence, then batched steps until every sequence has hit
-        EOS or its max_len.  Returns the B token sequences (prompt + generated, EOS not appended)."""
+        EOS or its max_len.  Returns the B token sequences (prompt + generated, EOS not appended).
+        `noise_fill(lo, hi)`: draws noise rows lo..hi-1 of every sequence before the launches that read them (see ARSession)."""
         st = self.stream.cuda_stream
+        filled = 0
+
+        def need(hi):
+            nonlocal filled
+            hi = min(hi, self.n_noise)
+            if noise_fill is not None and hi > filled:
+                filled = noise_fill(filled, hi) or hi
+
+        need(1)
         self.enqueue_head_and_sample(st)
         budget = min(max(ml - p - 1 for ml, p in zip(self.max_lens, self.P)), self.n_noise - 1)
         if use_graph and self.graph is None and budget > 0:
@@ -395,6 +425,7 @@ class ARBatchSession:
         done = 0
         while done < budget:
             n = min(poll, budget - done)
+            need(done + n + 1)
             for _ in range(n):
                 if use_graph:
                     self.graph.launch(st)

@@ -42,24 +42,35 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
     logging.info(f"Starting beam decoding with beam_width={beam_width}")
     P = int(xx.shape[-1])
     if P >= max_len:
-        logging.warning(f"[autoregressive generation] output length = {P} -- inference likely failed or input too long!")
+        logging.warning(f"[ar_generate] prompt of {P} tokens leaves no room under max_len = {max_len}: nothing generated")
         return xx.to(dev)
 
     sess = ARSession(eng, max_len)
     n_steps = max_len - P
     gen = None
+    fill = None
     with torch.cuda.stream(sess.stream):
         if noise is None:
-            # One Exp(1) vector per sampler call, drawn call-by-call like torch.multinomial does
-            # (ar_generate.py:115).  All max_len - P rows are drawn up front so the decode loop never
-            # touches the host; the generator is then rewound to where the reference leaves it (one
-            # draw per executed loop iteration), so what follows (the NAR stage) sees the same stream.
+            # One Exp(1) vector per sampler call, drawn call-by-call like torch.multinomial does (ar_generate.py:115).
+            # Rows are drawn in chunks just ahead of the graph replays that read them (ARSession.decode asks for them
+            # every poll interval), so an utterance that ends on EOS does not pay for max_len - P draws; the generator is
+            # then rewound to where the reference leaves it (one draw per executed loop iteration), so what follows (the
+            # NAR stage) sees the same stream.
             gen = generator if generator is not None else torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
             off0 = gen.get_offset()
             noise_d = torch.empty(n_steps, n_vocab, dtype=torch.float32, device=dev)
-            for i in range(n_steps):
-                noise_d[i].exponential_(1, generator=generator)
-            per_draw = (gen.get_offset() - off0) // n_steps
+            probe = torch.empty(n_vocab, dtype=torch.float32, device=dev)
+
+            def fill(lo, hi, _chunk=64):
+                hi = min(n_steps, (hi + _chunk - 1) // _chunk * _chunk)      # whole chunks: fewer host round trips
+                with torch.cuda.stream(sess.stream):
+                    for i in range(lo, hi):
+                        noise_d[i].exponential_(1, generator=generator)
+                return hi
+
+            probe.exponential_(1, generator=generator)                       # the generator offset one (V,) draw consumes
+            per_draw = gen.get_offset() - off0
+            gen.set_offset(off0)
         else:
             noise_d = noise.to(device=dev, dtype=torch.float32).contiguous()
     cfg = ARSamplingConfig(temperature=float(temperature), topk=topk, top_p=float(top_p), alpha_frequency=float(alpha_frequency),
@@ -68,12 +79,12 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
                            n_phones_gen=n_phones_gen, div_mode=div_mode)
     sess.configure_sampler(cfg, n_text, eos_idx, noise_d)
     sess.prefill(xx, ss_gen)
-    out = sess.decode(use_graph=use_graph)
+    out = sess.decode(use_graph=use_graph, noise_fill=fill)
     if gen is not None:
         n_iter = (int(out.shape[-1]) - P) + (1 if sess.ended_on_eos else 0)      # loop iterations the reference executes
         gen.set_offset(off0 + n_iter * per_draw)
     if out.shape[-1] >= max_len - 1:
-        logging.warning(f"[autoregressive generation] output length = {out.shape[-1]} -- inference likely failed or input too long!")
+        logging.warning(f"[ar_generate] stopped by max_len ({out.shape[-1]} tokens) rather than by the end-of-speech token")
     return out
 
 
@@ -88,24 +99,40 @@ def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: L
     its Exp(1) noise from ``generators[i]`` (or ``noises[i]``, (n_steps, V)); the decode step reads the
     weights once for all requests.  `max_len` may be a list (one cap per request).
     Returns the B full sequences (prompt + generated, EOS not appended)."""
-    B = len(xxs)
-    max_lens = [int(max_len)] * B if not isinstance(max_len, (list, tuple)) else [int(v) for v in max_len]
-    assert len(max_lens) == B
-    assert len(ss_gens) == B and len(first_codex_idxs) == B
+    B_all = len(xxs)
+    max_lens_all = [int(max_len)] * B_all if not isinstance(max_len, (list, tuple)) else [int(v) for v in max_len]
+    assert len(max_lens_all) == B_all
+    assert len(ss_gens) == B_all and len(first_codex_idxs) == B_all
     eng = codeclm.engine()
     dev = eng.dev
     n_text = len(texttok.vocab)
     n_vocab = n_text + len(speechtok.vocab)
     assert n_vocab == eng.shape.n_vocab, (n_vocab, eng.shape.n_vocab)
     eos_idx = n_text + speechtok.special_tokens['<|endofspeech|>']
+    results: List[Optional[Tensor]] = [None] * B_all
+    live = []
+    for i, (x, ml) in enumerate(zip(xxs, max_lens_all)):
+        assert x.dim() == 1
+        if int(x.shape[-1]) >= ml:          # no room to generate: what a lone call does (ar_generate.py:62,160-161)
+            logging.warning(f"[ar_generate] prompt of {int(x.shape[-1])} tokens leaves no room under max_len = {ml}: nothing generated")
+            results[i] = x.to(dev)
+        else:
+            live.append(i)
+    if not live:
+        return results
+    xxs, ss_gens = [xxs[i] for i in live], [ss_gens[i] for i in live]
+    max_lens = [max_lens_all[i] for i in live]
+    n_phones_gens = [n_phones_gens[i] for i in live] if n_phones_gens is not None else None
+    generators = [generators[i] for i in live] if generators is not None else None
+    noises = [noises[i] for i in live] if noises is not None else None
+    B = len(live)
     Ps = [int(x.shape[-1]) for x in xxs]
-    for x, P, ml in zip(xxs, Ps, max_lens):
-        assert x.dim() == 1 and P < ml, "every request needs room to generate (a lone call just returns the prompt)"
     sess = ARBatchSession(eng, max_lens)
     n_steps = max(ml - P for ml, P in zip(max_lens, Ps))
     gens, offs, pers = [], [], []
     with torch.cuda.stream(sess.stream):
         noise_d = torch.ones(B, n_steps, n_vocab, dtype=torch.float32, device=dev)
+        probe = torch.empty(n_vocab, dtype=torch.float32, device=dev)
         for b in range(B):
             nb = max_lens[b] - Ps[b]
             if noises is not None:
@@ -117,20 +144,43 @@ def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: L
             g = generators[b] if generators is not None and generators[b] is not None else \
                 torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
             off0 = g.get_offset()
-            for i in range(nb):
-                noise_d[b, i].exponential_(1, generator=g)
+            probe.exponential_(1, generator=g)                 # the generator offset one (V,) draw consumes
             gens.append(g)
             offs.append(off0)
-            pers.append((g.get_offset() - off0) // nb)
+            pers.append(g.get_offset() - off0)
+            g.set_offset(off0)
+    shared = len({id(g) for g in gens if g is not None}) < sum(g is not None for g in gens)
+    if shared:                              # one generator for several requests: request b's rows follow request b-1's in full
+        run = {}
+        for b in range(B):
+            if gens[b] is not None:
+                offs[b] = offs[b] + run.get(id(gens[b]), 0)
+                run[id(gens[b])] = run.get(id(gens[b]), 0) + (max_lens[b] - Ps[b]) * pers[b]
+
+    def fill(lo, hi, _chunk=64):
+        """rows lo..hi-1 of every sequence that draws from a generator, in whole chunks just ahead of the replays that read
+        them.  Requests that share ONE generator (the global one) would interleave their draws chunk by chunk; a lone call
+        draws a request's rows consecutively, so in that case everything is drawn up front, request by request."""
+        hi = n_steps if shared else min(n_steps, (hi + _chunk - 1) // _chunk * _chunk)
+        with torch.cuda.stream(sess.stream):
+            for b in range(B):
+                if gens[b] is None:
+                    continue
+                for i in range(lo, min(hi, max_lens[b] - Ps[b])):
+                    noise_d[b, i].exponential_(1, generator=gens[b])
+        return hi
+
     cfg = ARSamplingConfig(temperature=float(temperature), topk=topk, top_p=float(top_p), alpha_frequency=float(alpha_frequency),
                            alpha_presence=float(alpha_presence), penalty_window=int(penalty_window), typical_p=float(typical_p),
                            eos_penalty_factor=float(eos_penalty_factor), eos_penalty_decay=float(eos_penalty_decay),
                            n_phones_gen=None, div_mode=div_mode)
     sess.configure_sampler(cfg, n_text, eos_idx, noise_d, n_phones_gen=n_phones_gens)
     sess.prefill(xxs, ss_gens)
-    outs = sess.decode(use_graph=use_graph)
+    outs = sess.decode(use_graph=use_graph, noise_fill=fill if any(g is not None for g in gens) else None)
     for b in range(B):                      # leave every generator where a lone reference call leaves it
         if gens[b] is not None:
             n_iter = (int(outs[b].shape[-1]) - Ps[b]) + (1 if sess.ended_on_eos[b] else 0)
             gens[b].set_offset(offs[b] + n_iter * pers[b])
-    return outs
+    for i, o in zip(live, outs):
+        results[i] = o
+    return results

@@ -97,7 +97,21 @@ def _nar_config(T, dsh, div_mode: int) -> NARConfig:
 
 
 @torch.inference_mode()
-def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode: int = 0) -> NARSession:
+def _tables(diff) -> Optional[tuple]:
+    """The four log-tables of a MultinomialDiffusion (q_pred / q_posterior read them from `diff`, reference
+    diffuser.py:118-206), or None for the default schedule."""
+    if diff is None:
+        return None
+    return (diff.log_alpha, diff.log_1_min_alpha, diff.log_cumprod_alpha, diff.log_1_min_cumprod_alpha)
+
+
+def _same_tables(a, b) -> bool:
+    if a is None or b is None:
+        return a is None and b is None
+    return all(torch.equal(x.detach().cpu().float(), y.detach().cpu().float()) for x, y in zip(a, b))
+
+
+def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode: int = 0, diff=None) -> NARSession:
     """Start the part of ``perform_simple_inference`` that depends only on the conditioning (text ids (1,Lt),
     reference codes (1,Lc,8)) and the schedule -- speaker vector, text encoder for every step and guidance branch,
     cross-attention K / V -- on the session's own stream and return without waiting.  ``tts()`` calls this BEFORE the
@@ -105,7 +119,7 @@ def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode
     cfg = _nar_config(T, dsh, div_mode)
     eng = model.engine()
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
-    sess = NARSession(eng, cfg)
+    sess = NARSession(eng, cfg, diff_tables=_tables(diff))
     sess.prepare_cond(c_text[0], c_codes[0].to(eng.dev), times)
     return sess
 
@@ -132,7 +146,9 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
     K = diff.num_classes
     assert K == eng.shape.n_quant
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
-    sess = session if session is not None else NARSession(eng, cfg)
+    assert all(0 <= t < diff.num_timesteps for t in times), "T exceeds the diffusion's number of timesteps"
+    sess = session if session is not None else NARSession(eng, cfg, diff_tables=_tables(diff))
+    sess._enter()
     with torch.cuda.stream(sess.stream):
         xr, x_known, m, offset = _inpaint_state(batch, K, dsh, dev, randint, generator)
         if uniform is None:
@@ -141,6 +157,8 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
         sess.prepare(c_text[0], c_codes[0].to(dev), xr, x_known, m, offset, times)
     else:
         assert sess.times == list(times) and sess.cfg == cfg, "session was begun with a different schedule / DSH"
+        assert _same_tables(sess.diff_tables, _tables(diff)) or (sess.diff_tables is None and _same_tables(
+            _tables(diff), _tables(MultinomialDiffusion(diff.num_classes, timesteps=200)))), "session was begun with another diffusion"
         sess.prepare_state(xr, x_known, m, offset)
         sess.prepare_loop()
     out = sess.run(uniform, use_graph=use_graph, n_steps=n_steps, on_step=on_step)
@@ -166,8 +184,9 @@ def perform_batch_inference(model, batches: List[tuple], diff: MultinomialDiffus
     U = len(batches)
     generators = generators if generators is not None else [None] * U
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
-    sess = NARBatchSession(eng, cfg)
+    sess = NARBatchSession(eng, cfg, diff_tables=_tables(diff))
     items, offsets, us = [], [], []
+    sess.stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(sess.stream):
         for i, batch in enumerate(batches):
             g = generators[i]

@@ -15,10 +15,16 @@ from .ops import DT_NAME
 from .synth import ARShape, NARShape
 
 
+SAMPLER_MAX_VOCAB = 8192             # m5_ar_sample (csrc/ar_decode.hip): V2 * 12 B of LDS, V2 = next power of two
+SAMPLER_MAX_VOCAB_TYPICAL = 4096     # with typical_p < 1 (a second sort: V2 * 20 B)
+
+
 def default_engine_dtype() -> torch.dtype:
-    """GEMM operand dtype of the engines: env MARS5_DTYPE in {bf16 (default, BASELINE.json),
-    f16 (the reference's GPU autocast dtype), f32 (exact-fp32 parity mode)}."""
-    return DT_NAME[os.environ.get("MARS5_DTYPE", "bf16")]
+    """GEMM operand dtype of the engines: env MARS5_DTYPE in {f16 (default), bf16, f32 (exact-fp32 parity mode)}.
+    f16 is what the reference computes in on a GPU (autocast, ar_generate.py:59,67) and what the published MARS5
+    checkpoints are stored in (reference README.md:163-164), so loading them rounds nothing; bf16 (same MFMA rate,
+    3 mantissa bits fewer) is BASELINE.json's stated dtype and what bench.py selects explicitly."""
+    return DT_NAME[os.environ.get("MARS5_DTYPE", "f16")]
 
 
 class _Container:
@@ -94,6 +100,10 @@ class CodecLM(_Container):
             from .ar_engine import ARModel
             if self.device.type != "cuda":
                 raise RuntimeError("CodecLM engine needs a ROCm GPU device: there is no CPU fallback in mars5_tts_amd")
+            if self.shape.n_vocab > SAMPLER_MAX_VOCAB:
+                raise RuntimeError(f"n_vocab = {self.shape.n_vocab} exceeds the on-device sampler's limit of {SAMPLER_MAX_VOCAB} "
+                                   f"(m5_ar_sample sorts the whole vocabulary in one workgroup's LDS; typical_p < 1 further needs "
+                                   f"n_vocab <= {SAMPLER_MAX_VOCAB_TYPICAL})")
             self._engine = ARModel(self._sd, self.shape, self.engine_dtype or default_engine_dtype(), self.device)
         return self._engine
 

@@ -122,10 +122,17 @@ class NARConfig:
 class NARSession:
     """One utterance.  ``prepare`` = everything x_t-independent; ``step`` = one reverse step."""
 
-    def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None):
+    def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None, diff_tables=None):
+        """`diff_tables`: the four fp32 log-tables of the caller's MultinomialDiffusion (None = default schedule)."""
         self.m, self.cfg = model, cfg
         self.stream = stream if stream is not None else torch.cuda.Stream(device=model.dev)
         self.graph: Optional[ops.Graph] = None
+        self.diff_tables = diff_tables
+
+    def _enter(self) -> None:
+        """Order this session's stream behind whatever the caller has already enqueued on its current stream (inputs
+        produced there: codec codes, the AR hand-off, memsets of fresh allocations)."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.m.dev))
 
     # -------------------------------------------------------------------------- prepare
     def prepare(self, c_text: torch.Tensor, c_codes: torch.Tensor, x: torch.Tensor, x_known: torch.Tensor, m_mask: torch.Tensor,
@@ -140,6 +147,7 @@ class NARSession:
     def prepare_state(self, x: torch.Tensor, x_known: torch.Tensor, m_mask: torch.Tensor, row_offset: int) -> None:
         """The inpainting state of one utterance (depends on the AR output)."""
         dev = self.m.dev
+        self._enter()
         with torch.cuda.stream(self.stream):
             self.x = x.to(dev).contiguous().clone()
             self.x_known = x_known.to(dev).contiguous()
@@ -162,6 +170,7 @@ class NARSession:
         guided = cfg.guidance_w != 1
         nb = 2 if guided else 1
         self.nb = nb
+        self._enter()
         with torch.cuda.stream(self.stream):
             c_text = c_text.to(dev)
             c_codes = c_codes.to(dev).contiguous()
@@ -202,7 +211,7 @@ class NARSession:
                                   vt_bs=H * 64 * Lep, vt_hs=64 * Lep, vt_ds=Lep)
                 ops.gemm(mem, lw.ca_kv_w, None, L.EPI_QKV, bias=lw.ca_kv_b, scatter=sc, stream=st)
                 self.mems.append(CrossMemory(k, vt, Le, Lep, nb))
-            self.consts = nar_step_consts(self.times, K).to(dev)
+            self.consts = nar_step_consts(self.times, K, tables=self.diff_tables).to(dev)
             self._keep = [table, t_enc, mem]
 
     def prepare_loop(self) -> None:
@@ -211,6 +220,7 @@ class NARSession:
         dev, dt = mdl.dev, mdl.dt
         D, FF, K, Q = s.dim, s.dim_ff, s.n_quant, s.n_codebooks
         S, nb = self.S, self.nb
+        self._enter()
         with torch.cuda.stream(self.stream):
             self.ws = SeqWorkspace(nb, S, D, FF, dt, dev, row_pad=64, fuse_ln=True)
             self.Sr = Sr = self.ws.Sr
@@ -385,11 +395,12 @@ class NARBatchSession:
     Rows between an utterance's length and the common padded length hold finite junk that no real
     row ever attends to and that is never sampled."""
 
-    def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None):
+    def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None, diff_tables=None):
         self.m, self.cfg = model, cfg
         self.stream = stream if stream is not None else torch.cuda.Stream(device=model.dev)
         self.graph: Optional[ops.Graph] = None
         self.subs: List[NARSession] = []
+        self.diff_tables = diff_tables
 
     def prepare(self, items: List[dict], times: Optional[List[int]] = None) -> None:
         """items: dicts with the arguments of ``NARSession.prepare`` (c_text, c_codes, x, x_known,
@@ -400,7 +411,7 @@ class NARBatchSession:
         assert len(items) >= 1
         self.subs = []
         for it in items:
-            sub = NARSession(mdl, self.cfg, self.stream)
+            sub = NARSession(mdl, self.cfg, self.stream, self.diff_tables)
             sub.prepare_state(it["x"], it["x_known"], it["m_mask"], it["row_offset"])
             sub.prepare_cond(it["c_text"], it["c_codes"], times)
             self.subs.append(sub)
@@ -408,6 +419,7 @@ class NARBatchSession:
         self.nb = nb = self.subs[0].nb
         U = len(self.subs)
         S_max = max(sub.S for sub in self.subs)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):
             self.ws = SeqWorkspace(U * nb, S_max, D, FF, dt, dev, row_pad=64)
             self.Sr = Sr = self.ws.Sr

@@ -60,12 +60,17 @@ def diffusion_log_tables(timesteps: int = 200, s: float = 0.008):
     return la.float(), l1ma.float(), lca.float(), l1mca.float()
 
 
-def nar_step_consts(times: List[int], num_classes: int = 1025, timesteps: int = 200) -> torch.Tensor:
+def nar_step_consts(times: List[int], num_classes: int = 1025, timesteps: int = 200, tables=None) -> torch.Tensor:
     """Per reverse step (in schedule order) the eight scalars m5_nar_sample consumes:
     [lca[t-1], l1mca[t-1]-lnK, la[t], l1ma[t]-lnK, lca[t], l1mca[t]-lnK, t, 0].
     The ``- np.log(K)`` is done on fp32 tensors with a python double exactly as in
-    diffuser.py:130-133,169-172."""
-    la, l1ma, lca, l1mca = diffusion_log_tables(timesteps)
+    diffuser.py:130-133,169-172.  `tables` = (log_alpha, log_1_min_alpha, log_cumprod_alpha,
+    log_1_min_cumprod_alpha) of the caller's ``MultinomialDiffusion`` (the reference reads them from `diff` in
+    q_pred / q_posterior, diffuser.py:118-206); None = the default schedule (`timesteps`, s = 0.008)."""
+    if tables is None:
+        tables = diffusion_log_tables(timesteps)
+    la, l1ma, lca, l1mca = [t.detach().to("cpu", torch.float32) for t in tables]
+    assert all(0 <= t < la.shape[0] for t in times), f"schedule step outside the diffusion's {la.shape[0]} timesteps"
     lnK = np.log(num_classes)
     rows = []
     for t in times:

@@ -20,11 +20,13 @@ pytestmark = pytest.mark.gpu
 TEXT = "The quick brown rat jumped over the lazy dogs twice."
 TRANSCRIPT = "We actually haven't managed to meet demand this year."
 
-# max |engine logit - oracle logit| allowed, per operand dtype:  vs the autocast-emulating oracle / vs the fp32 oracle
-AR_TOL_EMU = {torch.bfloat16: 0.20, torch.float16: 0.03}
-AR_TOL_F32 = {torch.bfloat16: 0.40, torch.float16: 0.06}
-NAR_TOL_EMU = {torch.bfloat16: 0.04, torch.float16: 0.006}      # relative to max |logit|
-NAR_TOL_F32 = {torch.bfloat16: 0.08, torch.float16: 0.012}
+# max |engine logit - oracle logit| allowed, per operand dtype:  vs the autocast-emulating oracle / vs the fp32 oracle.
+# About 3x what round 2 measured on MI355X (profiles/r2a_parity16.txt): AR, |logit| <= 12.2: bf16 0.053 / 0.030, f16 0.0062 / 0.0038
+# over 450 teacher-forced steps; NAR at S = 1349, |logit| <= 9.3, relative to max |logit|: bf16 0.0029 / 0.0022, f16 0.0004 / 0.0003.
+AR_TOL_EMU = {torch.bfloat16: 0.15, torch.float16: 0.02}
+AR_TOL_F32 = {torch.bfloat16: 0.10, torch.float16: 0.012}
+NAR_TOL_EMU = {torch.bfloat16: 0.009, torch.float16: 0.0012}      # relative to max |logit|
+NAR_TOL_F32 = {torch.bfloat16: 0.007, torch.float16: 0.0010}
 
 
 @pytest.fixture(scope="module")
