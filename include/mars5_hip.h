@@ -281,6 +281,10 @@ int m5_event_record(void* ev, void* stream);
 int m5_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
 int m5_event_destroy(void* ev);
 
+#ifdef M5_TOOLS
+/* ---- tools library only (libmars5_hip_tools.so, built with -DM5_TOOLS; the scripts under tools/ load it with M5_HIP_TOOLS=1).  The
+ * product library libmars5_hip.so exports none of these, reads no environment variable and contains no ablation kernel. */
+
 /* Diagnostics: placement census of a grid (nblocks x threads, lds_bytes of LDS per workgroup);
  * out[6 * block] = {XCC_ID, HW_ID, start clock lo/hi, end clock lo/hi}.  tools/census.py. */
 int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int spin, void* stream);
@@ -302,6 +306,7 @@ int m5_debug_gemm_clock(unsigned long long* buf);
  * times; mode 0 LDS-DMA, 1 global_load -> ds_write, 2 global loads only.  tools/feed_probe.py. */
 int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int iters, int row_bytes, int mode, int blocks, int threads,
                         float* sink, void* stream);
+#endif /* M5_TOOLS */
 
 #ifdef __cplusplus
 }

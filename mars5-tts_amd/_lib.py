@@ -11,7 +11,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmars5_hip.so")
+# M5_HIP_TOOLS=1 (set by tools/*.py before importing the package) loads the tools build of the same sources:
+# tuning knobs, A/B kernels and probes live only there (csrc/common.h, m5_tool_env)
+TOOLS = os.environ.get("M5_HIP_TOOLS") == "1"
+LIB_PATH = os.path.join(_HERE, "libmars5_hip_tools.so" if TOOLS else "libmars5_hip.so")
 
 M5_OK, M5_ERR_ARG, M5_ERR_LAUNCH, M5_ERR_UNSUPPORTED = 0, -1, -2, -3
 F32, F16, BF16 = 0, 1, 2
@@ -132,6 +135,9 @@ PROTOTYPES = {
     "m5_event_record": (C.c_int, [vp, vp]),
     "m5_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "m5_event_destroy": (C.c_int, [vp]),
+}
+# exported by libmars5_hip_tools.so only (header: #ifdef M5_TOOLS)
+TOOLS_PROTOTYPES = {
     "m5_debug_census": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "m5_debug_gemm_clock": (C.c_int, [vp]),
     "m5_debug_feed_probe": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
@@ -146,7 +152,10 @@ def _load() -> C.CDLL:
             f"{LIB_PATH} not found: the MARS5 HIP library is not built. There is no CPU fallback. "
             "Build it with mars5-tts_amd/csrc/build.sh (needs hipcc, cross-compiles gfx950).")
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in PROTOTYPES.items():
+    protos = dict(PROTOTYPES)
+    if TOOLS:
+        protos.update(TOOLS_PROTOTYPES)
+    for name, (res, args) in protos.items():
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args

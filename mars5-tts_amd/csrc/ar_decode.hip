@@ -11,15 +11,19 @@
 // rows with 16-byte loads per lane (1 KiB per wave instruction, fully coalesced, no LDS
 // round trip for the streamed operand), fp32 accumulate, xor-shuffle reduction.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
 // diagnostics (tools/ar_phase_clock.py): when set, workgroup 0 of every decode launch stamps the 100 MHz
 // wall clock at its phases into dbg[slot * 8 + k]; slot advances on the host per launch
-__device__ unsigned long long* g_ar_dbg = nullptr;
+#ifdef M5_TOOLS
 __device__ inline void ar_stamp(unsigned long long* d, int k) {
     if (d && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) d[k] = wall_clock64();
 }
+#else
+__device__ inline void ar_stamp(unsigned long long*, int) {}     // product build: M5GemvArgs.dbg is ignored
+#endif
 
 // Prefetch workgroup `pid` of `pf.wgs` (appended behind a launch's compute workgroups; `lin` = its linear block id, whose
 // residue mod 8 is -- observed, speed only -- its XCD): touches the chunks j = first + r + 8 k of the region whose residue
@@ -971,11 +975,10 @@ extern "C" int m5_ar_sample(const M5SampleArgs* a, void* stream) {
     while (V2 < a->V) V2 <<= 1;
     if (a->typical_p <= 0.999f && V2 > 4096) return M5_ERR_UNSUPPORTED;      // typical-p scratch: 20 B per slot
     const size_t sm = (size_t)V2 * (a->typical_p <= 0.999f ? 20 : 12);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::once_flag attr_once;          // thread-safe: several host threads may drive their own streams
+    std::call_once(attr_once, [] {
         (void)hipFuncSetAttribute((const void*)sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 12);   // = 4096 * 24 >= 4096 * 20
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(sample_kernel, dim3(a->batch > 1 ? a->batch : 1), dim3(1024), sm, (hipStream_t)stream, *a, V2);
     M5_CHECK_LAUNCH();
     return M5_OK;

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_kernel(M5AttnArgs p) {
 int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s);   // attention16.hip; returns 1 when not handled
 
 static bool use_v1_attn() {   // M5_ATTN_V1=1: A/B the first-generation kernel
-    static const bool v = [] { const char* e = getenv("M5_ATTN_V1"); return e && e[0] == '1'; }();
+    static const bool v = [] { const char* e = m5_tool_env("M5_ATTN_V1"); return e && e[0] == '1'; }();
     return v;
 }
 

@@ -302,22 +302,26 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     if ((a->o_rs % 4) || (a->o_bs % 4) || ((uintptr_t)a->o & 7)) return 1;      // 8-byte output vectors
     if ((a->k_rs % 8) || (a->q_rs % 8) || (a->vt_ds % 8)) return 1;
     // M5_ATTN_NW / M5_ATTN_VARIANT: tuning + ablation hooks (tools/attn_bench.py); product = 4 waves, variant 0
-    static const int nw = [] { const char* e = getenv("M5_ATTN_NW"); return e ? atoi(e) : 4; }();
-    static const int var = [] { const char* e = getenv("M5_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
+    static const int nw = [] { const char* e = m5_tool_env("M5_ATTN_NW"); return e ? atoi(e) : 4; }();
+    static const int var = [] { const char* e = m5_tool_env("M5_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
 #define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a)
     if (dtype == M5_F16) {
         M5_A16(F16T, 4, 0);
+#ifdef M5_TOOLS
     } else if (nw == 2) {
         M5_A16(BF16T, 2, 0);
     } else if (nw == 8) {
         M5_A16(BF16T, 8, 0);
-    } else {
+    } else if (var >= 1 && var <= 3) {          // timing ablations, results are WRONG by construction
         switch (var) {
             case 1: M5_A16(BF16T, 4, 1); break;
             case 2: M5_A16(BF16T, 4, 2); break;
-            case 3: M5_A16(BF16T, 4, 3); break;
-            default: M5_A16(BF16T, 4, 0); break;
+            default: M5_A16(BF16T, 4, 3); break;
         }
+#endif
+    } else {
+        (void)nw; (void)var;
+        M5_A16(BF16T, 4, 0);
     }
 #undef M5_A16
     M5_CHECK_LAUNCH();

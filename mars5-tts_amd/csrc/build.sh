@@ -1,16 +1,25 @@
 #!/bin/bash
-# Build libmars5_hip.so for gfx950 (cross-compiles without a GPU).  Usage: csrc/build.sh [-j]
+# Build the gfx950 libraries (cross-compiles without a GPU).  Usage: csrc/build.sh [--no-tools]
+#   libmars5_hip.so        the product: no environment knobs, no diagnostics, no ablation kernels
+#   libmars5_hip_tools.so  the same sources with -DM5_TOOLS: tuning sweeps / A-B knobs / probes for tools/*.py
 set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
-mkdir -p obj
-pids=()
-for f in gemm gemm16 gemm_skinny attention attention16 rowops ar_decode ar_batch nar_sample util; do
-  if [ ! -f obj/$f.o ] || [ $f.hip -nt obj/$f.o ] || [ common.h -nt obj/$f.o ] || [ ../../include/mars5_hip.h -nt obj/$f.o ]; then
-    hipcc $FLAGS -c $f.hip -o obj/$f.o &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC obj/*.o -o ../libmars5_hip.so
-echo "built $(cd .. && pwd)/libmars5_hip.so"
+SRCS="gemm gemm16 gemm_skinny attention attention16 rowops ar_decode ar_batch nar_sample util"
+build_one() {   # $1 = object dir, $2 = extra flags, $3 = output library
+  mkdir -p $1
+  pids=()
+  for f in $SRCS; do
+    if [ ! -f $1/$f.o ] || [ $f.hip -nt $1/$f.o ] || [ common.h -nt $1/$f.o ] || [ ../../include/mars5_hip.h -nt $1/$f.o ]; then
+      hipcc $FLAGS $2 -c $f.hip -o $1/$f.o &
+      pids+=($!)
+    fi
+  done
+  for p in "${pids[@]}"; do wait $p; done
+  hipcc --offload-arch=gfx950 -shared -fPIC $1/*.o -o $3
+  echo "built $(cd .. && pwd)/$(basename $3)"
+}
+build_one obj "" ../libmars5_hip.so
+if [ "$1" != "--no-tools" ]; then
+  build_one obj_tools "-DM5_TOOLS" ../libmars5_hip_tools.so
+fi

@@ -6,6 +6,16 @@
 
 #define M5_WAVE 64
 
+// Environment knobs (tile-configuration sweeps, first-generation kernels for A/B runs, timing ablations that compute
+// WRONG results, phase clocks) exist only in the tools build (-DM5_TOOLS -> libmars5_hip_tools.so, used by tools/*.py).
+// The product library never reads the environment: a stray variable cannot change what it computes.
+#ifdef M5_TOOLS
+#include <stdlib.h>
+static inline const char* m5_tool_env(const char* name) { return getenv(name); }
+#else
+static inline const char* m5_tool_env(const char*) { return nullptr; }
+#endif
+
 // ---- element types ----------------------------------------------------------------
 // F32T: exact fp32 operands (parity mode; MFMA 16x16x4 f32).  F16T / BF16T: 16-bit
 // operands, fp32 accumulate (MFMA 16x16x32).

@@ -231,7 +231,7 @@ int m5_gemm_skinny_dispatch(int dtype, const void* A, int64_t lda, const void* W
                             void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s);
 
 static bool use_v1_gemm() {   // M5_GEMM_V1=1: A/B the first-generation register-staged kernel
-    static const bool v = [] { const char* e = getenv("M5_GEMM_V1"); return e && e[0] == '1'; }();
+    static const bool v = [] { const char* e = m5_tool_env("M5_GEMM_V1"); return e && e[0] == '1'; }();
     return v;
 }
 

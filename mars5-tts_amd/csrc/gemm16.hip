@@ -131,7 +131,11 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lg = lane >> 4;
+#ifdef M5_TOOLS
     const bool dbg_on = p.dbg && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1);
+#else
+    constexpr bool dbg_on = false;                     // phase clocks exist in the tools build only
+#endif
     unsigned long long* dbg = p.dbg + (blockIdx.x == 0 ? 0 : 8);
     if (dbg_on) { dbg[0] = clock64(); dbg[1] = wall_clock64(); }
 
@@ -915,13 +919,11 @@ extern "C" int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const
     if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
     if (max_le <= 0 || max_le > 16 * XA_MAX_KT || (rows_per_seq % 16) || (K % 64) || (n_heads % 2)) return M5_ERR_UNSUPPORTED;
     if ((lda % 8) || (ldw % 8) || (ld_out % 4) || (((uintptr_t)A | (uintptr_t)W) & 15) || ((uintptr_t)out & 7)) return M5_ERR_UNSUPPORTED;
-    // OFF unless M5_GEMM_XATTN=1.  Measured (tools/xattn_clock.py, tools/nar_step_bench.py): back to back on L2-hot data
+    // The host (mars5_tts_amd/ops.py) only calls this when M5_GEMM_XATTN=1: it is a tested opt-in.  Measured (tools/xattn_clock.py, tools/nar_step_bench.py): back to back on L2-hot data
     // the fused launch takes 20.3 us against 24.8 us for projection + attention launches, but inside the NAR step (memory
     // block of the step cold in HBM, weights streaming) the step gets 65 us SLOWER (3.76 vs 3.69 ms): the cold K / V^T
     // fragments sit in front of the operand DMAs in the in-order load queue, and the region-96x128 tiling this epilogue
     // needs (one head per wave) is slower for this GEMM than the 8-wave tiling the plain projection uses.
-    const char* e = getenv("M5_GEMM_XATTN");
-    if (!(e && e[0] == '1')) return M5_ERR_UNSUPPORTED;
     constexpr int BM = 96, BN = 128;
     Gemm16Params p{};
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias;
@@ -957,12 +959,10 @@ extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const 
         ((uintptr_t)xn & 7)) return M5_ERR_UNSUPPORTED;
     const int64_t need = 256 + (int64_t)tilesM * tilesN * BM * 8;
     if (scratch_bytes < need || ((uintptr_t)scratch & 15)) return M5_ERR_ARG;
-    // OFF unless M5_GEMM_LN=1: measured SLOWER than GEMM + LayerNorm launches on MI355X (3.60 vs 3.50 ms per NAR step,
+    // The host (mars5_tts_amd/ops.py) only calls this when M5_GEMM_LN=1 (a tested opt-in): measured SLOWER than GEMM + LayerNorm launches on MI355X (3.60 vs 3.50 ms per NAR step,
     // tools/nar_step_bench.py): the exchange between the 8 workgroups of a row tile (write-through store, L2-bypassing
     // polls, plus their start skew) costs ~8 us per launch against the 6 us LayerNorm launch it removes.  Kept as a
     // tested opt-in and as the record of that measurement.
-    const char* e = getenv("M5_GEMM_LN");
-    if (!(e && e[0] == '1')) return M5_ERR_UNSUPPORTED;
     Gemm16Params p{};
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
@@ -982,10 +982,12 @@ extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const 
 }
 
 
+#ifdef M5_TOOLS
 extern "C" int m5_debug_gemm_clock(unsigned long long* buf) {   // diagnostics (tools/gemm_clock.py); nullptr disables
     g_gemm_dbg = buf;
     return M5_OK;
 }
+#endif
 
 // Called by m5_gemm (gemm.hip) for F16 / BF16 operands after argument validation.
 int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -1024,7 +1026,7 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     } else {
         p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     }
-    const char* fe = getenv("M5_GEMM_CFG");                  // tuning sweeps only; read per call on purpose
+    const char* fe = m5_tool_env("M5_GEMM_CFG");             // tuning sweeps (tools build only); read per call on purpose
     const int forced = (fe && fe[0]) ? atoi(fe) : -1;
     const int span_div = (sc && sc->vt) ? sc->n_heads * sc->head_dim : 0;
     int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div, epi);

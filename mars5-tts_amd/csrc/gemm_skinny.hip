@@ -185,7 +185,7 @@ int launch_skinny_mt(int epi, const SkinnyParams& p, hipStream_t s) {
     // Non-temporal loads lose ~4 % here (measured, tools/ar_batch_bench.py): a wave instruction covers 64 bytes of
     // each of its 16 rows, so the two halves of a 128-byte line are fetched by consecutive instructions and the
     // line should stay in L2 in between.  M5_SKINNY_NT=1 re-enables them for A/B runs.
-    const char* e = getenv("M5_SKINNY_NT");
+    const char* e = m5_tool_env("M5_SKINNY_NT");
     const bool nt = (e && e[0] == '1');
     if (p.M <= 16) return nt ? launch_skinny<T, 1, true>(epi, p, s) : launch_skinny<T, 1, false>(epi, p, s);
     return nt ? launch_skinny<T, 2, true>(epi, p, s) : launch_skinny<T, 2, false>(epi, p, s);
@@ -199,7 +199,7 @@ bool m5_gemm_skinny_fits(int dtype, int M, int N, int K, int epi, int batch, int
     if (batch != 1 || M > 32 || (N % 16) || (K % 32) || K > 32 * SK_KSW * SK_NW) return false;
     if (epi != M5_EPI_F32 && epi != M5_EPI_DT && epi != M5_EPI_RESIDUAL && epi != M5_EPI_SWIGLU) return false;
     if ((lda % 8) || (ldw % 8)) return false;
-    const char* e = getenv("M5_GEMM_SKINNY");                // tuning / A-B only
+    const char* e = m5_tool_env("M5_GEMM_SKINNY");                // tuning / A-B only
     return !(e && e[0] == '0');
 }
 

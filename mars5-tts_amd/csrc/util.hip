@@ -51,6 +51,7 @@ extern "C" int m5_event_destroy(void* ev) {
     if (!ev) return M5_ERR_ARG;
     return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? M5_OK : M5_ERR_LAUNCH;
 }
+#ifdef M5_TOOLS   // probes behind tools/*.py (dispatch census, launch floor, operand-feed probe, grid barrier): tools library only
 
 // ---- placement census (diagnostics; tools/census.py): where does the dispatcher put the
 // workgroups of a grid with this shape?  Each workgroup records {XCC_ID, HW_ID, start, end clock}
@@ -197,3 +198,5 @@ extern "C" int m5_debug_grid_barrier(uint32_t* scratch, int blocks, int threads,
     M5_CHECK_LAUNCH();
     return M5_OK;
 }
+
+#endif  // M5_TOOLS

@@ -92,7 +92,7 @@ def main():
     T = args.nar_steps
     c_text = torch.tensor(text_full)[None]
     c_codes = ref_codes.permute(0, 2, 1).contiguous()
-    x_l0 = torch.randint(0, 1024, (449,), generator=torch.Generator().manual_seed(2))
+    x_l0 = torch.randint(0, 1024, (899,), generator=torch.Generator().manual_seed(2))      # 449 prompt frames + 450 generated: what the AR hands over
     _x = x_l0[None, :, None].repeat(1, 1, 8)
     batch = (c_text, c_codes, torch.tensor([c_text.shape[1]]), torch.tensor([c_codes.shape[1]]), _x, torch.zeros(1, _x.shape[1], dtype=torch.bool))
     with torch.inference_mode():

@@ -14,18 +14,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_functions():
     src = open(os.path.join(ROOT, "include", "mars5_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(m5_[a-z0-9_]+)\s*\(", src)))
+    tools = "".join(re.findall(r"#ifdef M5_TOOLS(.*?)#endif", src, flags=re.S))
+    prod = re.sub(r"#ifdef M5_TOOLS.*?#endif", "", src, flags=re.S)
+    fn = lambda t: sorted(set(re.findall(r"\b(m5_[a-z0-9_]+)\s*\(", t)))     # noqa: E731
+    return fn(prod), fn(tools)
 
 
 def test_library_exports_every_header_symbol():
+    import ctypes
     from mars5_tts_amd import _lib
-    names = _header_functions()
-    assert len(names) >= 20
+    names, tool_names = _header_functions()
+    assert len(names) >= 20 and len(tool_names) >= 5
     for n in names:
         assert hasattr(_lib.lib, n), f"libmars5_hip.so does not export {n}"
     assert sorted(_lib.PROTOTYPES) == names, "ctypes prototype table and header disagree"
+    assert sorted(_lib.TOOLS_PROTOTYPES) == tool_names
     assert _lib.lib.m5_version() == 1
     assert b"gfx950" in _lib.lib.m5_build_info()
+    # the product library carries no diagnostics export and never reads the environment; the tools library has both
+    for n in tool_names:
+        assert not hasattr(_lib.lib, n), f"product library exports the tools-only symbol {n}"
+    import subprocess
+    undef = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in undef, "libmars5_hip.so imports getenv: an environment variable could change what it computes"
+    tools_lib = ctypes.CDLL(os.path.join(os.path.dirname(_lib.LIB_PATH), "libmars5_hip_tools.so"))
+    for n in names + tool_names:
+        assert hasattr(tools_lib, n), f"libmars5_hip_tools.so does not export {n}"
 
 
 def test_argument_validation_returns_status_codes():

@@ -66,7 +66,7 @@ def test_gemm_epilogues(dev, dt, M, N, K):
 def test_gemm_skinny_decode_shapes(dev, dt, M):
     """The M <= 32 weight-streaming path of m5_gemm (batched AR decode step) at the real projection shapes:
     every epilogue against fp32 torch on the dtype-rounded operands, and against the wide-tile kernel
-    (M5_GEMM_SKINNY=0) to catch layout mistakes that a tolerance could hide."""
+    (reached by padding the call to 40 rows) to catch layout mistakes that a tolerance could hide."""
     from mars5_tts_amd import _lib as L, ops
     from mars5_tts_amd.blocks import interleave_rows
     tol = max(TOL[dt], 8e-3)
@@ -87,23 +87,25 @@ def test_gemm_skinny_decode_shapes(dev, dt, M):
         ad, wd = a.to(dev, dt), w.to(dev, dt)
         bd = bias.to(dev) if bias is not None else None
         outs = []
-        for skinny in ("1", "0"):
-            os.environ["M5_GEMM_SKINNY"] = skinny
+        # the same rows through the skinny kernel (M <= 32) and through the wide-tile kernel (forced by padding the
+        # call to 40 rows: the row count is what m5_gemm dispatches on; rows are independent)
+        for Mc in (M, 40):
+            ac = torch.zeros(Mc, K, device=dev, dtype=dt)
+            ac[:M] = ad
             if epi == L.EPI_RESIDUAL:
-                res0 = _rand((M, N), 5).to(dev)
+                res0 = _rand((Mc, N), 5).to(dev)
                 o = res0.clone()
-                ops.gemm(ad, wd, o, epi)
+                ops.gemm(ac, wd, o, epi)
                 torch.cuda.synchronize()
-                o = (o - res0).cpu()
+                o = (o - res0)[:M].cpu()
             else:
                 No = N // 2 if epi == L.EPI_SWIGLU else N
-                o = torch.zeros(M + 2, No, device=dev, dtype=torch.float32 if epi == L.EPI_F32 else dt)   # 2 guard rows
-                ops.gemm(ad, wd, o[:M], epi, bias=bd)
+                o = torch.zeros(Mc + 2, No, device=dev, dtype=torch.float32 if epi == L.EPI_F32 else dt)   # 2 guard rows
+                ops.gemm(ac, wd, o[:Mc], epi, bias=bd)
                 torch.cuda.synchronize()
-                assert float(o[M:].float().abs().max()) == 0.0, "rows >= M must not be written"
+                assert float(o[Mc:].float().abs().max()) == 0.0, "rows >= M must not be written"
                 o = o[:M].float().cpu()
             outs.append(o)
-        os.environ.pop("M5_GEMM_SKINNY", None)
         r = _rel(outs[0], ref)
         assert r < tol * (2 if epi == L.EPI_SWIGLU else 1), f"M={M} N={N} K={K} epi={epi}: rel err {r}"
         assert _rel(outs[0], outs[1]) < tol, f"M={M} N={N} K={K} epi={epi}: skinny vs wide-tile kernel"

@@ -4,6 +4,7 @@ usage: python tools/ar_step_bench.py "M5_AR_PREFETCH=0" "M5_AR_PREFETCH=1" ...""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("M5_HIP_TOOLS", "1")      # tools run on libmars5_hip_tools.so (knobs, probes; csrc/common.h)
 import torch
 import bench
 from mars5_tts_amd import synth, ops

@@ -4,6 +4,7 @@ first-generation kernel.  Reference: torch fp32 softmax(QK^T * scale + mask) V o
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("M5_HIP_TOOLS", "1")      # tools run on libmars5_hip_tools.so (knobs, probes; csrc/common.h)
 import torch
 import mars5_tts_amd as pkg            # noqa
 from mars5_tts_amd import ops, _lib as L

@@ -4,6 +4,7 @@ hipGraph replay, trivial kernels with and without a global read-modify-write."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("M5_HIP_TOOLS", "1")      # tools run on libmars5_hip_tools.so (knobs, probes; csrc/common.h)
 import torch
 import mars5_tts_amd as pkg            # noqa
 from mars5_tts_amd import ops, _lib as L

@@ -4,6 +4,7 @@ usage: python tools/nar_step_bench.py "M5_NAR_DUAL=0" "M5_NAR_DUAL=1" ..."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("M5_HIP_TOOLS", "1")      # tools run on libmars5_hip_tools.so (knobs, probes; csrc/common.h)
 import torch
 import bench
 from mars5_tts_amd import synth, ops
