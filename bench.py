@@ -43,9 +43,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c5"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default): BASELINE configs[1], one utterance per step.  c3: configs[2], one step = a batch of "
-                         "--batch mixed-length requests through tts_batch_from_codes.  c5: configs[4], one long-form utterance "
+                         "--batch mixed-length requests through tts_batch_from_codes.  c4: configs[3], one step = --batch x N "
+                         "mixed-length requests built on rank 0, scattered over the N ranks (RCCL), run, gathered back and "
+                         "spot-checked (32 x 8 = 256 on a full node).  c5: configs[4], one long-form utterance "
                          "per step (60 s = 4500 generated frames: the AR context passes the 3000-slot rotating KV window)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ar-batch", type=int, default=32)
@@ -152,6 +154,101 @@ def main_c3(args, m, dev, world, rank, barrier):
         "time_split_s_per_step": {k: round(v / args.steps, 3) for k, v in split.items()},
         "last_ar_batch": {k: ar_engine.LAST_STATS.get(k) for k in ("decode_ms", "decode_steps_launched", "batch")},
         "last_nar_batch": {k: nar_engine.LAST_STATS.get(k) for k in ("loop_ms", "steps", "batch", "rows")},
+    }
+    print(json.dumps(out), flush=True)
+
+
+def request_worker(m, base_cfg):
+    """The per-request hot path as the sharded runs call it: a wire-format request in, final (G, 8) codes out."""
+    import dataclasses
+
+    def work(r):
+        cfg = dataclasses.replace(base_cfg, generate_max_len_override=int(r.max_len))
+        torch.manual_seed(int(r.seed))
+        _, final = m.tts_from_ids(r.text_ids, r.ref_codes.T.contiguous()[None].to(m.device), int(r.n_phones_gen), cfg)
+        return final.cpu()
+    return work
+
+
+def c4_requests(m, n: int, n_gen: int, factor: float, seed: int = 11):
+    """SURVEY 8(d) config 4 = config 3's request generator, in the wire format of ``sharding.Request``."""
+    from mars5_tts_amd.sharding import Request
+    texts, trs, refs, max_lens = c3_requests(m, n, n_gen, seed=seed)
+    reqs = []
+    for i in range(n):
+        ids = m.texttok.encode("<|startoftext|>" + trs[i] + ' ' + texts[i].strip() + "<|endoftext|>", allowed_special='all')
+        reqs.append(Request(idx=i, text_ids=torch.tensor(ids, dtype=torch.long), ref_codes=refs[i][0].T.contiguous().cpu(), seed=1000 + i,
+                            n_gen_est=n_gen, n_phones_gen=round(factor * len(texts[i])), max_len=max_lens[i]))
+    return reqs
+
+
+def verify_remote(m, base_cfg, reqs, mine_idx, gathered, k=2):
+    """rank 0 after a gather: recompute up to `k` requests that ran on OTHER ranks (same per-request seed) and require the
+    gathered codes to be identical -- results do not depend on which GPU produced them."""
+    work = request_worker(m, base_cfg)
+    checked = 0
+    for r in reqs:
+        if r.idx in mine_idx:
+            continue
+        ref = work(r)
+        got = gathered[r.idx]
+        assert got.shape == ref.shape and torch.equal(got, ref), f"request {r.idx}: gathered codes differ from a local seed-matched run"
+        checked += 1
+        if checked >= k:
+            break
+    return checked
+
+
+def main_c4(args, m, dev, world, rank, barrier):
+    """One step = args.batch * world requests on rank 0 -> scatter (LPT by estimated cost) -> every rank runs its shard
+    through the batch-1 hot path -> gather on rank 0.  The timed region spans scatter + compute + gather."""
+    import torch.distributed as dist
+    from mars5_tts_amd import sharding as sh
+    from inference import InferenceConfig
+    cfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
+                          eos_estimated_gen_length_factor=100.0, eos_penalty_factor=50.0, eos_penalty_decay=0.5)
+    n_total = args.batch * world
+    reqs = c4_requests(m, n_total, args.n_gen, cfg.eos_estimated_gen_length_factor, seed=11)      # every rank can rebuild them (verification)
+    work = request_worker(m, cfg)
+
+    def step():
+        if world > 1:
+            return sh.run_sharded(reqs if rank == 0 else None, n_total, work, src=0)
+        return [work(r) for r in reqs]
+
+    if args.warmup:
+        work(reqs[0])
+    barrier()
+    t0 = time.perf_counter()
+    outs = None
+    for _ in range(args.steps):
+        outs = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    frames = float(sum(int(o.shape[0]) for o in outs)) * args.steps if rank == 0 else 0.0
+    collective = None
+    if world > 1:
+        elapsed, frames = sh.reduce_timing(elapsed, frames)
+        census = sh.rank_census()
+        parts = sh.lpt_partition([sh.estimate_cost(r) for r in reqs], world)
+        if rank == 0:
+            checked = verify_remote(m, cfg, reqs, set(parts[0]), outs, k=2)
+            collective = dict(backend=sh.LAST_STATS.get("backend"), ranks_seen=sh.LAST_STATS.get("ranks_seen"), census=census,
+                              scatter_bytes=sh.LAST_STATS.get("scatter_bytes"), gather_bytes=sh.LAST_STATS.get("gather_bytes"),
+                              remote_results_rechecked_equal=checked, requests_per_rank=[len(p) for p in parts])
+    if rank != 0:
+        return
+    ref_frames = [int(r.ref_codes.shape[0]) for r in reqs]
+    out = {
+        "metric": "generated audio seconds/sec (RTF), deep-clone", "value": round(frames / 75.0 / elapsed, 4), "unit": "audio_s/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[3]: {n_total} mixed-length deep-clone requests ({args.batch} per GPU) built on rank 0, "
+                               f"scattered over {world} rank(s) by estimated cost, batch-1 hot path per request, results gathered on rank 0; "
+                               f"reference 150-900 frames, {args.n_gen} generated frames each, temperature=0.7 top_k=100, 200 DDPM steps x CFG",
+                   "requests_per_step": n_total, "reference_frames_min_mean_max": [min(ref_frames), round(sum(ref_frames) / len(ref_frames), 1), max(ref_frames)],
+                   "parallelism": f"replicas x{world}, request scatter + result gather over {'RCCL' if world > 1 else 'nothing (single rank)'}"},
+        "collective": collective,
     }
     print(json.dumps(out), flush=True)
 
@@ -369,8 +466,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.workload == "c3":
-        main_c3(args, m, dev, world, rank, barrier)
+    if args.workload in ("c3", "c4"):
+        (main_c3 if args.workload == "c3" else main_c4)(args, m, dev, world, rank, barrier)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -378,21 +475,50 @@ def main():
     for i in range(args.warmup):
         run_utterance(m, ref_codes, cfg, 500 + i)
 
+    # N > 1: the requests of ALL ranks are built on rank 0 and reach their rank through the request scatter (RCCL), the
+    # results go back through the gather -- both OUTSIDE the timed region, which is pure replica compute as for N = 1 --
+    # and rank 0 re-runs a request that another GPU ran to check that placement does not change a single code.
+    shard, all_reqs, work = None, None, None
+    if world > 1:
+        from mars5_tts_amd import sharding as sh
+        tt_ids = m.texttok.encode("<|startoftext|>" + TRANSCRIPT + ' ' + TEXT.strip() + "<|endoftext|>", allowed_special='all')
+        all_reqs = [sh.Request(idx=r * args.steps + i, text_ids=torch.tensor(tt_ids, dtype=torch.long), ref_codes=ref_codes[0].T.contiguous().cpu(),
+                               seed=1000 + r * 10007 + i, n_gen_est=args.n_gen,
+                               n_phones_gen=round(cfg.eos_estimated_gen_length_factor * len(TEXT)), max_len=p_len + args.n_gen)
+                    for r in range(world) for i in range(args.steps)]
+        shard = sh.scatter_requests(all_reqs if rank == 0 else None, src=0)
+        work = request_worker(m, cfg)
+
     barrier()
     t0 = time.perf_counter()
-    lat, frames = [], 0
-    for i in range(args.steps):
-        dt, n_out, _ = run_utterance(m, ref_codes, cfg, 1000 + rank * 10007 + i)
+    lat, frames, results = [], 0, []
+    for i in range(args.steps if shard is None else len(shard)):
+        if shard is None:
+            dt, n_out, _ = run_utterance(m, ref_codes, cfg, 1000 + rank * 10007 + i)
+        else:
+            t1 = time.perf_counter()
+            final = work(shard[i])
+            torch.cuda.synchronize()
+            dt, n_out = time.perf_counter() - t1, int(final.shape[0])
+            results.append((shard[i].idx, final))
         lat.append(dt)
         frames += n_out
     barrier()
     elapsed = time.perf_counter() - t0
+    collective = None
     if world > 1:
         from mars5_tts_amd.sharding import reduce_timing
         elapsed, frames = reduce_timing(elapsed, float(frames))
         lats = [None] * world
         dist.all_gather_object(lats, lat)
         lat = [x for l in lats for x in l]
+        gathered = sh.gather_results(results, len(all_reqs), dst=0)
+        census = sh.rank_census()
+        if rank == 0:
+            checked = verify_remote(m, cfg, all_reqs, {r.idx for r in shard}, gathered, k=1)
+            collective = dict(backend=sh.LAST_STATS.get("backend"), ranks_seen=sh.LAST_STATS.get("ranks_seen"), census=census,
+                              scatter_bytes=sh.LAST_STATS.get("scatter_bytes"), gather_bytes=sh.LAST_STATS.get("gather_bytes"),
+                              remote_results_rechecked_equal=checked, in_timed_region=False)
     audio_s = frames / 75.0
     if rank != 0:
         if world > 1:
@@ -405,8 +531,10 @@ def main():
         "p50_latency_s": round(statistics.median(lat), 4),
         "config": {"workload": workload_name,
                    "ar_prompt_tokens": p_len, "generated_frames_per_utterance": frames / (args.steps * world),
-                   "parallelism": f"replicas x{world} (one utterance stream per GPU, no data-path collective)",
+                   "parallelism": f"replicas x{world} (one utterance stream per GPU; requests scattered / results gathered over "
+                                  f"{'RCCL' if world > 1 else 'nothing at N = 1'} outside the timed region)",
                    "hipgraph": not args.no_graph},
+        "collective": collective,
     }
     if not args.no_roofline:
         roof, ar_roof, nar, kernels = roofline_leg(m, ref_codes, cfg, args.dtype)

@@ -126,25 +126,31 @@ class Mars5TTS:
 
     # ------------------------------------------------------------------ the hot path
     def _prompt(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str], cfg: InferenceConfig) -> dict:
-        """Prompt construction of reference inference.py:222-258."""
+        """Prompt construction of reference inference.py:222-258: tokenise, then ``_prompt_from_ids``."""
+        # both tokenisations are built unconditionally, as in the reference (so ref_transcript=None raises TypeError even
+        # for a shallow clone, SURVEY App. B-10)
         text_tokens = self.texttok.encode("<|startoftext|>" + text.strip() + "<|endoftext|>", allowed_special='all')
         text_tokens_full = self.texttok.encode("<|startoftext|>" + ref_transcript + ' ' + str(text).strip() + "<|endoftext|>",
                                                allowed_special='all')
+        if cfg.deep_clone:
+            text_tokens = text_tokens_full
+        return self._prompt_from_ids(text_tokens, prompt_codec, round(cfg.eos_estimated_gen_length_factor * len(text)), cfg)
+
+    def _prompt_from_ids(self, text_tokens: List[int], prompt_codec: Tensor, n_phones_gen: int, cfg: InferenceConfig) -> dict:
+        """The AR prompt from already tokenised text (deep clone: transcript + text, else text alone) and the reference
+        codes (1, n_q, Lc): text ids, then (deep clone only) the BPE tokens of the reference's codebook-0 codes offset by
+        the text vocabulary (reference inference.py:235-258)."""
+        text_tokens = [int(t) for t in text_tokens]
         prompt_codec = prompt_codec.to(self.device)
-        n_speech_inp = 0
         q0_str = ' '.join([str(t) for t in prompt_codec[0, 0].tolist()])
         speech_tokens = self.speechtok.encode(q0_str.strip())
         spk_ref_codec = prompt_codec[0, :, :].T
         n_text = len(self.texttok.vocab)
-        offset_speech_codes = [p + n_text for p in speech_tokens]
-        if not cfg.deep_clone:
-            offset_speech_codes = offset_speech_codes[:n_speech_inp]
-        else:
-            text_tokens = text_tokens_full
-            n_speech_inp = len(offset_speech_codes)
+        offset_speech_codes = [p + n_text for p in speech_tokens] if cfg.deep_clone else []
+        n_speech_inp = len(offset_speech_codes)
         prompt = torch.tensor(text_tokens + offset_speech_codes, dtype=torch.long, device=self.device)
         return dict(prompt=prompt, first_codec_idx=prompt.shape[-1] - n_speech_inp + 1, spk_ref_codec=spk_ref_codec,
-                    text_tokens=text_tokens, prompt_codec=prompt_codec, n_text=n_text, n_phones_gen=round(cfg.eos_estimated_gen_length_factor * len(text)))
+                    text_tokens=text_tokens, prompt_codec=prompt_codec, n_text=n_text, n_phones_gen=int(n_phones_gen))
 
     def _ar_kwargs(self, cfg: InferenceConfig) -> dict:
         return dict(max_len=cfg.generate_max_len_override if cfg.generate_max_len_override > 1 else 2000,
@@ -195,9 +201,20 @@ class Mars5TTS:
         `rng_hooks` (parity tests): an object with ar_noise(n_steps, V), after_ar(n_iterations), randint(shape),
         uniform(shape) that supplies every random draw instead of the device generator (oracle/fakes.py), and
         optionally nar_on_step(dict), an observer of every reverse step."""
+        return self._tts_core(self._prompt(text, prompt_codec, ref_transcript, cfg), cfg, ar_noise, generator, rng_hooks)
+
+    @torch.inference_mode()
+    def tts_from_ids(self, text_ids, prompt_codec: Tensor, n_phones_gen: int, cfg: InferenceConfig = InferenceConfig(),
+                     generator: Optional[torch.Generator] = None) -> Tuple[Tensor, Tensor]:
+        """``tts_from_codes`` for a request that arrives already tokenised -- the wire format of the multi-GPU request
+        scatter (``mars5_tts_amd.sharding.Request``): `text_ids` = ids of "<|startoftext|>[transcript ]text<|endoftext|>",
+        `n_phones_gen` = the EOS-penalty length estimate round(cfg.eos_estimated_gen_length_factor * len(text))."""
+        ids = text_ids.tolist() if isinstance(text_ids, Tensor) else list(text_ids)
+        return self._tts_core(self._prompt_from_ids(ids, prompt_codec, n_phones_gen, cfg), cfg, None, generator, None)
+
+    def _tts_core(self, pr: dict, cfg: InferenceConfig, ar_noise, generator, rng_hooks) -> Tuple[Tensor, Tensor]:
         T = self.default_T
         diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
-        pr = self._prompt(text, prompt_codec, ref_transcript, cfg)
         if rng_hooks is not None:
             n_steps = self._ar_kwargs(cfg)["max_len"] - int(pr["prompt"].shape[0])
             ar_noise = rng_hooks.ar_noise(max(n_steps, 1), self.n_vocab)

@@ -23,6 +23,8 @@ class Request:
     ref_codes: torch.Tensor     # (Lc, 8) int64 Encodec codes of the reference audio
     seed: int                   # per-utterance RNG seed (placement-independent results)
     n_gen_est: int = 450        # expected generated frames (cost model only)
+    n_phones_gen: int = 0       # EOS-penalty length estimate: round(factor * len(text)) (inference.py:268)
+    max_len: int = -1           # InferenceConfig.generate_max_len_override for this request (-1: the default cap)
 
 
 def estimate_cost(req: Request) -> float:
@@ -47,6 +49,9 @@ def lpt_partition(costs: Sequence[float], world: int) -> List[List[int]]:
     return parts
 
 
+LAST_STATS: dict = {}        # bytes moved by the last scatter_requests / gather_results of this process, rank census
+
+
 def _dev(group=None) -> torch.device:
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
@@ -63,10 +68,11 @@ def reduce_timing(elapsed_s: float, units: float, group=None) -> Tuple[float, fl
 
 
 def _pack(reqs: List[Request]) -> torch.Tensor:
-    """[n, then per request: idx, seed, n_gen_est, Lt, Lc, text_ids..., ref_codes (row-major)...]"""
+    """[n, then per request: idx, seed, n_gen_est, n_phones_gen, max_len, Lt, Lc, text_ids..., ref_codes (row-major)...]"""
     parts = [torch.tensor([len(reqs)], dtype=torch.int64)]
     for r in reqs:
-        parts.append(torch.tensor([r.idx, r.seed, r.n_gen_est, r.text_ids.numel(), r.ref_codes.shape[0]], dtype=torch.int64))
+        parts.append(torch.tensor([r.idx, r.seed, r.n_gen_est, r.n_phones_gen, r.max_len, r.text_ids.numel(), r.ref_codes.shape[0]],
+                                  dtype=torch.int64))
         parts.append(r.text_ids.reshape(-1).to(torch.int64).cpu())
         parts.append(r.ref_codes.reshape(-1).to(torch.int64).cpu())
     return torch.cat(parts)
@@ -76,13 +82,13 @@ def _unpack(buf: torch.Tensor) -> List[Request]:
     buf = buf.cpu()
     n, p, out = int(buf[0]), 1, []
     for _ in range(n):
-        idx, seed, n_gen, lt, lc = (int(v) for v in buf[p:p + 5])
-        p += 5
+        idx, seed, n_gen, n_ph, max_len, lt, lc = (int(v) for v in buf[p:p + 7])
+        p += 7
         text = buf[p:p + lt].clone()
         p += lt
         codes = buf[p:p + lc * 8].reshape(lc, 8).clone()
         p += lc * 8
-        out.append(Request(idx, text, codes, seed, n_gen))
+        out.append(Request(idx, text, codes, seed, n_gen, n_ph, max_len))
     return out
 
 
@@ -105,6 +111,8 @@ def scatter_requests(requests: Optional[List[Request]], src: int = 0, group=None
     if rank == src:
         chunks = [torch.cat([p, torch.zeros(width - p.numel(), dtype=torch.int64)]).to(dev) for p in payloads]
     dist.scatter(mine, chunks, src=src, group=group)
+    LAST_STATS["scatter_bytes"] = int(sizes.sum()) * 8           # payload int64 words over all ranks (padding excluded)
+    LAST_STATS["scatter_bytes_this_rank"] = int(sizes[rank]) * 8
     return _unpack(mine[: int(sizes[rank])])
 
 
@@ -125,8 +133,10 @@ def gather_results(results: List[Tuple[int, torch.Tensor]], n_total: int, dst: i
     mine = torch.cat([buf, torch.zeros(w - buf.numel(), dtype=torch.int64)]).to(dev)
     bins = [torch.zeros(w, dtype=torch.int64, device=dev) for _ in range(world)] if rank == dst else None
     dist.gather(mine, bins, dst=dst, group=group)
+    LAST_STATS["gather_bytes_this_rank"] = int(buf.numel()) * 8
     if rank != dst:
         return None
+    LAST_STATS["gather_bytes"] = sum(8 * (1 + sum(2 + g * 8 for g in _gather_lengths(b))) for b in bins)   # payload words, padding excluded
     out: List[Optional[torch.Tensor]] = [None] * n_total
     for b in bins:
         b = b.cpu()
@@ -138,6 +148,34 @@ def gather_results(results: List[Tuple[int, torch.Tensor]], n_total: int, dst: i
             p += g * 8
     assert all(o is not None for o in out), "gather_results: missing utterances"
     return out  # type: ignore[return-value]
+
+
+def _gather_lengths(b: torch.Tensor) -> List[int]:
+    """frame counts of the results packed in one rank's gather payload"""
+    b = b.cpu()
+    n, p, out = int(b[0]), 1, []
+    for _ in range(n):
+        g = int(b[p + 1])
+        out.append(g)
+        p += 2 + g * 8
+    return out
+
+
+def rank_census(group=None) -> List[dict]:
+    """Every rank contributes (rank, local device index, device count it sees, cuda-or-not) through ONE all_gather over
+    the job's backend (RCCL on the GPU box): the returned list, identical on every rank, is the evidence that the
+    collective saw `world` distinct ranks / devices."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = _dev(group)
+    on_gpu = dev.type == "cuda"
+    mine = torch.tensor([rank, torch.cuda.current_device() if on_gpu else -1, torch.cuda.device_count() if on_gpu else 0, int(on_gpu)],
+                        dtype=torch.int64, device=dev)
+    allv = [torch.zeros(4, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(allv, mine, group=group)
+    census = [dict(rank=int(v[0]), device=int(v[1]), devices_visible=int(v[2]), gpu=bool(int(v[3]))) for v in allv]
+    LAST_STATS["ranks_seen"] = len({c["rank"] for c in census})
+    LAST_STATS["backend"] = dist.get_backend(group)
+    return census
 
 
 def run_sharded(requests: Optional[List[Request]], n_total: int, worker: Callable[[Request], torch.Tensor],

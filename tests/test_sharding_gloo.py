@@ -78,6 +78,107 @@ def test_scatter_gather_world2_gloo():
     assert ok.value == 1
 
 
+# ---------------------------------------------------------------- the real host path behind the scatter / gather
+def _cpu_tts(tiny_vocab):
+    """A Mars5TTS whose host logic is the product's (prompt assembly from wire-format ids, BPE hand-off, prompt skipping)
+    and whose two device stages are deterministic CPU stand-ins driven by the global RNG (what run_sharded seeds)."""
+    import io
+    import inference as inf
+    from mars5_tts_amd import minbpe
+
+    def fake_begin(model, c_text, c_codes, T, dsh=None, div_mode=0, diff=None):
+        return None
+
+    def fake_ar(texttok, speechtok, codeclm, xx, ss_gen, first_codex_idx, max_len=1500, **kw):
+        n = min(int(max_len) - int(xx.shape[0]), 9 + int(ss_gen.shape[0]) % 5)
+        n_text = len(texttok.vocab)
+        new = torch.randint(n_text, n_text + 1024, (max(n, 0),))           # global generator: seeded per request by run_sharded
+        return torch.cat([xx.cpu(), new])
+
+    def fake_nar(model, batch, diff, T, dtype=None, retain_quant0=True, dsh=None, generator=None, session=None, **kw):
+        c_codes, x = batch[1], batch[4]
+        out = x.clone()
+        out[..., 1:] = torch.randint(0, 1024, out[..., 1:].shape)
+        if dsh.deep_clone:
+            out = torch.cat([c_codes.to(out.dtype), out], dim=1)
+        return out
+
+    inf.begin_inference, inf.ar_generate, inf.perform_simple_inference = fake_begin, fake_ar, fake_nar
+    m = inf.Mars5TTS.__new__(inf.Mars5TTS)
+    m.device = torch.device("cpu")
+    m.codec = m.vocos = False
+    m.texttok = minbpe.RegexTokenizer()
+    m.texttok.load(io.BytesIO(tiny_vocab["texttok.model"].encode()))
+    m.speechtok = minbpe.CodebookTokenizer()
+    m.speechtok.load(io.BytesIO(tiny_vocab["speechtok.model"].encode()))
+    m.n_vocab = len(m.texttok.vocab) + len(m.speechtok.vocab)
+    m.n_text_vocab = len(m.texttok.vocab) + 1
+    m.diffusion_n_classes = 1025
+    m.codeclm = m.codecnar = None
+    m.default_T, m.sr, m.latent_sr = 4, 24000, 75
+    m._expansion = m.speechtok.expansion_table()
+    return m, inf
+
+
+def _host_requests(m, n=6):
+    from mars5_tts_amd import synth
+    reqs = []
+    for i in range(n):
+        text, tr = f"Request number {i} says hello.", "A transcript " * (1 + i % 3)
+        ids = m.texttok.encode("<|startoftext|>" + tr + ' ' + text.strip() + "<|endoftext|>", allowed_special='all')
+        ref = synth.make_ref_codes(20 + 7 * i, seed=50 + i, merge_friendly=True)
+        reqs.append(sh.Request(i, torch.tensor(ids, dtype=torch.long), ref[0].T.contiguous(), seed=500 + i, n_gen_est=12,
+                               n_phones_gen=len(text), max_len=len(ids) + ref.shape[-1] + 12))
+    return reqs
+
+
+def _host_worker(rank: int, world: int, port: int, ok):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        from mars5_tts_amd import synth
+        m, inf = _cpu_tts(synth.make_vocab(30, 63))
+        cfg = inf.InferenceConfig(deep_clone=True, temperature=0.7, top_k=100)
+        reqs = _host_requests(m)
+        work = bench.request_worker(m, cfg)                       # the worker bench.py --workload c4 / --gpus N uses
+        out = sh.run_sharded(reqs if rank == 0 else None, len(reqs), work, src=0)
+        census = sh.rank_census()
+        assert [c["rank"] for c in census] == list(range(world)) and sh.LAST_STATS["ranks_seen"] == world
+        if rank == 0:
+            assert sh.LAST_STATS["scatter_bytes"] == sum(sh._pack([r]).numel() - 1 for r in reqs) * 8 + 8 * world
+            parts = sh.lpt_partition([sh.estimate_cost(r) for r in reqs], world)
+            assert bench.verify_remote(m, cfg, reqs, set(parts[0]), out, k=2) == 2
+            for r in reqs:                                        # and the whole batch equals a single-process run
+                assert torch.equal(out[r.idx], work(r)), r.idx
+                assert out[r.idx].shape[1] == 8 and out[r.idx].shape[0] >= 1
+            assert sh.LAST_STATS["gather_bytes"] == sum(8 * (2 + o.numel()) for o in out) + 8 * world
+            ok.value = 1
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_run_drives_the_real_host_path_world2_gloo():
+    """``bench.request_worker`` (= ``Mars5TTS.tts_from_ids``: prompt assembly from the wire-format ids, AR stage, BPE
+    hand-off, NAR stage, prompt skipping) behind ``run_sharded`` on two gloo ranks: results identical to a single-process
+    run, byte counters consistent with the payloads, census sees both ranks.  The two device stages are CPU stand-ins
+    (no GPU here); on the GPU box the same code runs with the HIP engines over RCCL (``bench.py --workload c4``)."""
+    ctx = mp.get_context("spawn")
+    ok = ctx.Value("i", 0)
+    port = _free_port()
+    procs = [ctx.Process(target=_host_worker, args=(r, 2, port, ok)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert ok.value == 1
+
+
 def test_lpt_partition_properties():
     costs = [5.0, 1.0, 4.0, 4.0, 2.0, 9.0, 0.5]
     for world in (1, 2, 3, 8):
