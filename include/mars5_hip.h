@@ -267,6 +267,13 @@ typedef struct {
 } M5NarSampleArgs;
 int m5_nar_sample(const M5NarSampleArgs* a, void* stream);
 
+/* AR -> NAR hand-off on device (reference inference.py:272-275 with speechtok.decode_int, minbpe/codebook.py:88-126):
+ * tokens[i] (global AR ids, i < n) -> speech-vocabulary id max(tokens[i] - n_text, 0) -> the run of codebook-0 codes that
+ * BPE token was merged from: vals[off[id] .. off[id + 1]) (CSR over n_vocab ids; special tokens have empty runs),
+ * concatenated in order into out[0 .. *total) (at most out_cap are written; *total is the full length). */
+int m5_expand_tokens(const int64_t* tokens, int n, int n_text, const int32_t* off, const int64_t* vals, int n_vocab,
+                     int64_t* out, int out_cap, int32_t* total, void* stream);
+
 int m5_add_int(int32_t* p, int32_t delta, void* stream);
 
 /* hipGraph helpers (capture the launches issued between begin/end on `stream`). */

@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
+from mars5_tts_amd import ops
 from mars5_tts_amd.ar_generate import ar_generate, ar_generate_batch
 from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, begin_inference, perform_batch_inference, perform_simple_inference
 from mars5_tts_amd.minbpe import GPT4_SPLIT_PATTERN, CodebookTokenizer, RegexTokenizer
@@ -78,6 +79,7 @@ class Mars5TTS:
         self.latent_sr = 75
         self.vocos = vocos if vocos is not None else _load_vocos(self.device)
         self._expansion = self.speechtok.expansion_table()
+        self._exp_csr = None                 # device copy of the expansion table, built on first use
 
     # ------------------------------------------------------------------ hub loading
     @classmethod
@@ -161,11 +163,14 @@ class Mars5TTS:
 
     def _handoff(self, pr: dict, ar_codes: Tensor, cfg: InferenceConfig):
         """AR -> NAR hand-off (reference inference.py:262-285): token ids -> L0 frames through the BPE
-        expansion table (same result as speechtok.decode_int on the id list, inference.py:272-275), then
-        the ``perform_simple_inference`` batch tuple."""
-        output_tokens = (ar_codes - pr["n_text"]).clamp(min=0)[pr["first_codec_idx"]:].cpu().tolist()
-        frames = [c for tk in output_tokens for c in self._expansion[tk]]
-        gen_codes_decoded = torch.tensor(frames, dtype=torch.long, device=self.device)
+        expansion table on the device (same result as speechtok.decode_int on the id list, inference.py:272-275),
+        then the ``perform_simple_inference`` batch tuple."""
+        # on device: one kernel through the CSR expansion table + a 4-byte read-back of the frame count (m5_expand_tokens)
+        if getattr(self, "_exp_csr", None) is None:
+            off, vals, mx = self.speechtok.expansion_csr()
+            self._exp_csr = (off.to(self.device), vals.to(self.device), mx)
+        off, vals, mx = self._exp_csr
+        gen_codes_decoded = ops.expand_tokens(ar_codes[pr["first_codec_idx"]:].to(self.device).contiguous(), pr["n_text"], off, vals, mx)
         text_tokens, prompt_codec = pr["text_tokens"], pr["prompt_codec"]
         c_text = torch.tensor(text_tokens, dtype=torch.long, device=self.device)[None]
         c_codes = prompt_codec.permute(0, 2, 1)

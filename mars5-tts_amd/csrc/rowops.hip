@@ -281,6 +281,44 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const typename T::stora
 
 __global__ void add_int_kernel(int32_t* p, int32_t delta) { *p += delta; }
 
+// AR -> NAR hand-off on device (reference inference.py:272-275: (ar_codes - n_text).clamp(0)[first:] through
+// speechtok.decode_int, minbpe/codebook.py:88-126): every BPE token id expands to the run of codebook-0 codes it was merged
+// from (CSR table off / vals; special tokens expand to nothing).  One workgroup: lengths -> block scan -> scatter.
+__global__ __launch_bounds__(1024) void expand_tokens_kernel(const int64_t* tokens, int n, int n_text, const int32_t* off, const int64_t* vals,
+                                                             int n_vocab, int64_t* out, int out_cap, int32_t* total) {
+    __shared__ int wsum[16];
+    __shared__ int blk;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        int t = 0, len = 0;
+        if (i < n) {
+            const int64_t v = tokens[i] - n_text;
+            t = (int)(v < 0 ? 0 : v);
+            len = (t < n_vocab) ? off[t + 1] - off[t] : 0;
+        }
+        int inc = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) wsum[wv] = inc;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wv; ++w) woff += wsum[w];
+        if (tid == 1023) blk = woff + inc;
+        const int excl = base + woff + inc - len;
+        for (int j = 0; j < len; ++j)
+            if (excl + j < out_cap) out[excl + j] = vals[off[t] + j];
+        __syncthreads();
+        base += blk;
+        __syncthreads();
+    }
+    if (tid == 0) *total = base;
+}
+
 }  // namespace
 
 extern "C" int m5_layernorm(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
@@ -363,6 +401,14 @@ extern "C" int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int
         case M5_BF16: hipLaunchKernelGGL(rope_cache_kernel<BF16T>, dim3(M), dim3(256), 0, s, (const uint16_t*)qkv, M, n_heads, pos0, rope, (uint16_t*)q_out, (uint16_t*)kcache, (uint16_t*)vcache, cache_hs, window, (uint16_t*)vt_out, vt_hs, vt_ds); break;
         default: return M5_ERR_ARG;
     }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_expand_tokens(const int64_t* tokens, int n, int n_text, const int32_t* off, const int64_t* vals, int n_vocab,
+                                int64_t* out, int out_cap, int32_t* total, void* stream) {
+    if (!tokens || !off || !vals || !out || !total || n < 0 || n_vocab <= 0 || out_cap < 0) return M5_ERR_ARG;
+    hipLaunchKernelGGL(expand_tokens_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tokens, n, n_text, off, vals, n_vocab, out, out_cap, total);
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

@@ -241,6 +241,18 @@ class CodebookTokenizer(_BPEBase):
             table[idx] = table[a] + table[b]
         return table
 
+    def expansion_csr(self):
+        """``expansion_table`` as CSR arrays for the device hand-off (``m5_expand_tokens``): (off int32 (V+1,), vals int64,
+        longest run)."""
+        import torch
+        table = self.expansion_table()
+        off = [0]
+        vals: List[int] = []
+        for run in table:
+            vals.extend(run)
+            off.append(len(vals))
+        return torch.tensor(off, dtype=torch.int32), torch.tensor(vals or [0], dtype=torch.int64), max((len(r) for r in table), default=1)
+
 
 def train_merges(seqs: List[List[int]], n_merges: int, first_new_id: int) -> List[_Pair]:
     """Tiny BPE trainer (most frequent adjacent pair first); used only to make synthetic

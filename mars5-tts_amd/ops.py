@@ -178,6 +178,19 @@ def nar_sample(args: L.NarSampleArgs, stream: Optional[int] = None) -> None:
     check(lib.m5_nar_sample(C.byref(args), _s(stream)), "m5_nar_sample")
 
 
+def expand_tokens(tokens: torch.Tensor, n_text: int, off: torch.Tensor, vals: torch.Tensor, max_run: int,
+                  stream: Optional[int] = None) -> torch.Tensor:
+    """AR token ids (n,) int64 -> codebook-0 frames (G,) int64 through the CSR expansion table (off int32 (V+1,), vals int64):
+    one launch, then a 4-byte read-back of G (the NAR buffers are sized by it)."""
+    assert tokens.dtype == torch.int64 and off.dtype == torch.int32 and vals.dtype == torch.int64 and tokens.is_contiguous()
+    n = int(tokens.shape[0])
+    cap = max(n * max(max_run, 1), 1)
+    out = torch.empty(cap, dtype=torch.int64, device=tokens.device)
+    total = torch.zeros(1, dtype=torch.int32, device=tokens.device)
+    check(lib.m5_expand_tokens(_p(tokens), n, n_text, _p(off), _p(vals), off.shape[0] - 1, _p(out), cap, _p(total), _s(stream)), "m5_expand_tokens")
+    return out[: int(total.item())]
+
+
 def add_int(p: torch.Tensor, delta: int, stream: Optional[int] = None) -> None:
     assert p.dtype == torch.int32
     check(lib.m5_add_int(_p(p), delta, _s(stream)), "m5_add_int")

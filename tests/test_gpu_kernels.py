@@ -709,3 +709,28 @@ def test_graph_capture_replay(dev):
     gr.launch(st.cuda_stream)
     e1.record(st.cuda_stream)
     assert e0.elapsed_ms(e1) >= 0.0
+
+
+def test_expand_tokens_vs_host_table(dev, tiny_bundle):
+    """m5_expand_tokens (AR -> NAR hand-off on device) against the host expansion of the same BPE tokenizer -- which
+    tests/test_oracle_golden.py pins to the reference's ``decode_int`` (tokenizer_cases.npz): merged tokens, plain codes,
+    special tokens (empty runs), text ids (clamped to code 0 like the reference's ``.clamp(min=0)``), more than one
+    1024-token chunk, and the empty sequence."""
+    import io
+    from mars5_tts_amd import minbpe, ops
+    st = minbpe.CodebookTokenizer()
+    st.load(io.BytesIO(tiny_bundle.ar_ckpt["vocab"]["speechtok.model"].encode()))
+    table = st.expansion_table()
+    off, vals, mx = st.expansion_csr()
+    assert mx >= 2, "the tiny speech tokenizer must contain merges"
+    n_text = tiny_bundle.n_text
+    g = torch.Generator().manual_seed(4)
+    for n in (0, 1, 37, 1024, 2500):
+        sp = torch.randint(0, len(table), (n,), generator=g)
+        toks = sp + n_text
+        if n > 5:
+            toks[3] = 5                                   # a text id: clamps to speech id 0
+            toks[4] = n_text + st.special_tokens["<|endofspeech|>"]
+        want = [c for t in (toks - n_text).clamp(min=0).tolist() for c in table[t]]
+        got = ops.expand_tokens(toks.to(dev), n_text, off.to(dev), vals.to(dev), mx)
+        assert got.cpu().tolist() == want, f"n={n}"

@@ -81,7 +81,8 @@ def test_scatter_gather_world2_gloo():
 # ---------------------------------------------------------------- the real host path behind the scatter / gather
 def _cpu_tts(tiny_vocab):
     """A Mars5TTS whose host logic is the product's (prompt assembly from wire-format ids, BPE hand-off, prompt skipping)
-    and whose two device stages are deterministic CPU stand-ins driven by the global RNG (what run_sharded seeds)."""
+    and whose device stages (AR decode, token expansion kernel, NAR refinement) are deterministic CPU stand-ins driven by
+    the global RNG (what run_sharded seeds)."""
     import io
     import inference as inf
     from mars5_tts_amd import minbpe
@@ -103,7 +104,14 @@ def _cpu_tts(tiny_vocab):
             out = torch.cat([c_codes.to(out.dtype), out], dim=1)
         return out
 
+    def fake_expand(tokens, n_text, off, vals, max_run, stream=None):       # CPU stand-in of m5_expand_tokens (same CSR table)
+        out = []
+        for t in (tokens - n_text).clamp(min=0).tolist():
+            out.extend(vals[int(off[t]):int(off[t + 1])].tolist())
+        return torch.tensor(out, dtype=torch.long)
+
     inf.begin_inference, inf.ar_generate, inf.perform_simple_inference = fake_begin, fake_ar, fake_nar
+    inf.ops.expand_tokens = fake_expand
     m = inf.Mars5TTS.__new__(inf.Mars5TTS)
     m.device = torch.device("cpu")
     m.codec = m.vocos = False
