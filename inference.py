@@ -54,6 +54,22 @@ class InferenceConfig():
     ref_audio_pad: float = 0
 
 
+@dataclass
+class ReferenceHandle:
+    """What depends only on the reference audio (and, per text, on the text) -- computed once by
+    ``Mars5TTS.prepare_reference`` and reused by every request that clones the same voice (reference
+    inference.py:174-199, mars5/model.py:71-92,246-261 recompute all of it per call):
+    the reference's BPE speech tokens, the AR and NAR speaker vectors, and a small LRU of NAR conditioning states
+    (text encoder output for all 200 steps + cross-attention K / V of 16 layers, ~1 GB each) keyed by the text ids."""
+    prompt_codec: Tensor                      # (1, n_q, Lc) on the device
+    ref_transcript: Optional[str]
+    speech_tokens: List[int]
+    ar_spk: Tensor                            # (dim_ar,) fp32
+    nar_spk: Tensor                           # (dim_nar,) fp32
+    max_cond: int = 2
+    cond: Dict[tuple, object] = dataclasses.field(default_factory=dict)     # (text ids, cfg key) -> NARSession holding the state
+
+
 class Mars5TTS:
     def __init__(self, ar_ckpt, nar_ckpt, device: str = None, codec=None, vocos=None) -> None:
         if device is None:
@@ -126,8 +142,24 @@ class Mars5TTS:
         spk_reference = self.codec.encode(ref_audio[None].to(self.device))[0][0].permute(0, 2, 1)
         return self.codeclm.get_spk_embedding(spk_reference)
 
+    # ------------------------------------------------------------------ per-reference cache
+    @torch.inference_mode()
+    def prepare_reference(self, prompt_codec: Tensor, ref_transcript: Optional[str] = None, max_cond: int = 2) -> ReferenceHandle:
+        """Everything a request needs from the reference alone.  prompt_codec (1, n_q, Lc) Encodec codes of the reference
+        audio (``codec.encode(audio)[0][0]``).  Pass the handle to ``tts_from_codes(..., ref_handle=h)``: results are
+        identical to calls without it (the same kernels run on the same inputs, only once)."""
+        prompt_codec = prompt_codec.to(self.device)
+        q0_str = ' '.join([str(t) for t in prompt_codec[0, 0].tolist()])
+        speech_tokens = self.speechtok.encode(q0_str.strip())
+        codes = prompt_codec[0].T.contiguous()
+        ar_spk = self.codeclm.engine().spk(codes)
+        nar_spk = self.codecnar.engine().spk(codes)
+        torch.cuda.current_stream(self.device).synchronize()
+        return ReferenceHandle(prompt_codec, ref_transcript, speech_tokens, ar_spk, nar_spk, max_cond)
+
     # ------------------------------------------------------------------ the hot path
-    def _prompt(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str], cfg: InferenceConfig) -> dict:
+    def _prompt(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str], cfg: InferenceConfig,
+                ref_handle: Optional[ReferenceHandle] = None) -> dict:
         """Prompt construction of reference inference.py:222-258: tokenise, then ``_prompt_from_ids``."""
         # both tokenisations are built unconditionally, as in the reference (so ref_transcript=None raises TypeError even
         # for a shallow clone, SURVEY App. B-10)
@@ -136,23 +168,27 @@ class Mars5TTS:
                                                allowed_special='all')
         if cfg.deep_clone:
             text_tokens = text_tokens_full
-        return self._prompt_from_ids(text_tokens, prompt_codec, round(cfg.eos_estimated_gen_length_factor * len(text)), cfg)
+        return self._prompt_from_ids(text_tokens, prompt_codec, round(cfg.eos_estimated_gen_length_factor * len(text)), cfg, ref_handle)
 
-    def _prompt_from_ids(self, text_tokens: List[int], prompt_codec: Tensor, n_phones_gen: int, cfg: InferenceConfig) -> dict:
+    def _prompt_from_ids(self, text_tokens: List[int], prompt_codec: Tensor, n_phones_gen: int, cfg: InferenceConfig,
+                         ref_handle: Optional[ReferenceHandle] = None) -> dict:
         """The AR prompt from already tokenised text (deep clone: transcript + text, else text alone) and the reference
         codes (1, n_q, Lc): text ids, then (deep clone only) the BPE tokens of the reference's codebook-0 codes offset by
         the text vocabulary (reference inference.py:235-258)."""
         text_tokens = [int(t) for t in text_tokens]
-        prompt_codec = prompt_codec.to(self.device)
-        q0_str = ' '.join([str(t) for t in prompt_codec[0, 0].tolist()])
-        speech_tokens = self.speechtok.encode(q0_str.strip())
+        if ref_handle is not None:
+            prompt_codec, speech_tokens = ref_handle.prompt_codec, ref_handle.speech_tokens
+        else:
+            prompt_codec = prompt_codec.to(self.device)
+            q0_str = ' '.join([str(t) for t in prompt_codec[0, 0].tolist()])
+            speech_tokens = self.speechtok.encode(q0_str.strip())
         spk_ref_codec = prompt_codec[0, :, :].T
         n_text = len(self.texttok.vocab)
         offset_speech_codes = [p + n_text for p in speech_tokens] if cfg.deep_clone else []
         n_speech_inp = len(offset_speech_codes)
         prompt = torch.tensor(text_tokens + offset_speech_codes, dtype=torch.long, device=self.device)
         return dict(prompt=prompt, first_codec_idx=prompt.shape[-1] - n_speech_inp + 1, spk_ref_codec=spk_ref_codec,
-                    text_tokens=text_tokens, prompt_codec=prompt_codec, n_text=n_text, n_phones_gen=int(n_phones_gen))
+                    text_tokens=text_tokens, prompt_codec=prompt_codec, n_text=n_text, n_phones_gen=int(n_phones_gen), ref_handle=ref_handle)
 
     def _ar_kwargs(self, cfg: InferenceConfig) -> dict:
         return dict(max_len=cfg.generate_max_len_override if cfg.generate_max_len_override > 1 else 2000,
@@ -200,13 +236,19 @@ class Mars5TTS:
     @torch.inference_mode()
     def tts_from_codes(self, text: str, prompt_codec: Tensor, ref_transcript: Optional[str],
                        cfg: InferenceConfig = InferenceConfig(), ar_noise: Optional[Tensor] = None,
-                       generator: Optional[torch.Generator] = None, rng_hooks=None) -> Tuple[Tensor, Tensor]:
+                       generator: Optional[torch.Generator] = None, rng_hooks=None,
+                       ref_handle: Optional[ReferenceHandle] = None) -> Tuple[Tensor, Tensor]:
         """``tts`` between the codec and the vocoder (reference inference.py:222-301):
         prompt_codec (1, n_q, seq_len) Encodec codes in -> (AR L0 codes, final (S_out, 8) codes) out.
+        `ref_handle` (``prepare_reference``): reuse what was computed for this reference (prompt_codec / ref_transcript
+        may then be None).
         `rng_hooks` (parity tests): an object with ar_noise(n_steps, V), after_ar(n_iterations), randint(shape),
         uniform(shape) that supplies every random draw instead of the device generator (oracle/fakes.py), and
         optionally nar_on_step(dict), an observer of every reverse step."""
-        return self._tts_core(self._prompt(text, prompt_codec, ref_transcript, cfg), cfg, ar_noise, generator, rng_hooks)
+        if ref_handle is not None:
+            prompt_codec = ref_handle.prompt_codec
+            ref_transcript = ref_handle.ref_transcript if ref_transcript is None else ref_transcript
+        return self._tts_core(self._prompt(text, prompt_codec, ref_transcript, cfg, ref_handle), cfg, ar_noise, generator, rng_hooks)
 
     @torch.inference_mode()
     def tts_from_ids(self, text_ids, prompt_codec: Tensor, n_phones_gen: int, cfg: InferenceConfig = InferenceConfig(),
@@ -225,12 +267,20 @@ class Mars5TTS:
             ar_noise = rng_hooks.ar_noise(max(n_steps, 1), self.n_vocab)
         # the NAR stage's conditioning work (text encoder for all 200 steps, cross-attention K / V) does not depend on the
         # AR output: enqueue it on the NAR stream now, it runs beside the AR decode
+        h = pr.get("ref_handle")
+        key = (tuple(pr["text_tokens"]), cfg.nar_guidance_w, cfg.x_0_temp, cfg.deep_clone, cfg.q0_override_steps) if h is not None else None
         nar_sess = begin_inference(self.codecnar, torch.tensor(pr["text_tokens"], dtype=torch.long, device=self.device)[None],
-                                   pr["prompt_codec"].permute(0, 2, 1), diff.num_timesteps, dsh=self._dsh(cfg), diff=diff)
+                                   pr["prompt_codec"].permute(0, 2, 1), diff.num_timesteps, dsh=self._dsh(cfg), diff=diff,
+                                   spk_vec=h.nar_spk if h is not None else None, cond_from=h.cond.get(key) if h is not None else None)
+        if h is not None and key not in h.cond:
+            while len(h.cond) >= max(h.max_cond, 1):
+                h.cond.pop(next(iter(h.cond)))                 # oldest first
+            if h.max_cond > 0:
+                h.cond[key] = nar_sess
         ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
                                fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
                                n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
-                               generator=generator, **self._ar_kwargs(cfg))
+                               generator=generator, spk_vec=h.ar_spk if h is not None else None, **self._ar_kwargs(cfg))
         gen_codes_decoded, batch, skip_front = self._handoff(pr, ar_codes, cfg)
         hook_kw = {}
         if rng_hooks is not None:

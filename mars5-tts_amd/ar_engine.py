@@ -118,7 +118,7 @@ class ARSession:
         self.ended_on_eos = False
 
     # ------------------------------------------------------------------ prefill
-    def prefill(self, prompt: torch.Tensor, ref_codes: torch.Tensor) -> None:
+    def prefill(self, prompt: torch.Tensor, ref_codes: torch.Tensor, spk_vec: Optional[torch.Tensor] = None) -> None:
         """prompt (P,) int64 global ids; ref_codes (Lc, 8) int64.  Runs the speaker encoder and
         the 26-layer stack over [spk_vec, tok_0..tok_{P-1}] (positions 0..P), filling the cache
         and leaving the last row's residual in ``xdec``."""
@@ -133,7 +133,8 @@ class ARSession:
         with torch.cuda.stream(self.stream):
             prompt = prompt.to(dev)
             ref_codes = ref_codes.to(dev).contiguous()
-            spk = m.spk(ref_codes, stream=st)                                    # (D,) fp32
+            # (D,) fp32; a cached vector of the same reference (Mars5TTS.prepare_reference) is the same tensor by construction
+            spk = m.spk(ref_codes, stream=st) if spk_vec is None else spk_vec.to(dev)
             table = torch.cat([m.embed, spk[None]], dim=0)                       # plumbing: one extra row
             idx = torch.cat([torch.tensor([s.n_vocab], device=dev, dtype=torch.int64), prompt])
             x = torch.empty(M, D, dtype=torch.float32, device=dev)

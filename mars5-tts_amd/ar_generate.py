@@ -18,7 +18,7 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
                 typical_p=1.0, eos_penalty_factor=1.0, eos_penalty_decay=0, n_phones_gen=None, vocode=True,
                 beam_width: int = 1, beam_length_penalty=2, use_kv_cache: bool = True,
                 noise: Optional[Tensor] = None, use_graph: bool = True, div_mode: int = 0,
-                generator: Optional[torch.Generator] = None) -> Tensor:
+                generator: Optional[torch.Generator] = None, spk_vec: Optional[Tensor] = None) -> Tensor:
     """Autoregressively complete `xx` (seq_len,) with the `codeclm` language model; `ss_gen`
     (ref_len, 8) is the speaker reference.  Returns the full sequence (prompt + generated),
     EOS not appended.  `fp16`, `beam_length_penalty` and `use_kv_cache` are accepted for
@@ -27,7 +27,8 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
 
     Extensions (keyword-only in spirit): `noise` (n_steps, V) Exp(1) draws to use instead of
     the device generator (parity tests), `use_graph`, `div_mode`, `generator` (a private device
-    generator instead of the global one: per-utterance RNG streams for batched serving).
+    generator instead of the global one: per-utterance RNG streams for batched serving), `spk_vec` (the speaker
+    vector of `ss_gen` computed earlier, ``codeclm.get_spk_embedding``: skips the speaker encoder).
     """
     assert xx.dim() == 1, "Only batch size of 1 is currently supported."
     assert beam_width == 1, "Only beam size of 1 is currently supported."
@@ -78,7 +79,7 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
                            eos_penalty_factor=float(eos_penalty_factor), eos_penalty_decay=float(eos_penalty_decay),
                            n_phones_gen=n_phones_gen, div_mode=div_mode)
     sess.configure_sampler(cfg, n_text, eos_idx, noise_d)
-    sess.prefill(xx, ss_gen)
+    sess.prefill(xx, ss_gen, spk_vec=spk_vec)
     out = sess.decode(use_graph=use_graph, noise_fill=fill)
     if gen is not None:
         n_iter = (int(out.shape[-1]) - P) + (1 if sess.ended_on_eos else 0)      # loop iterations the reference executes

@@ -111,7 +111,8 @@ def _same_tables(a, b) -> bool:
     return all(torch.equal(x.detach().cpu().float(), y.detach().cpu().float()) for x, y in zip(a, b))
 
 
-def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode: int = 0, diff=None) -> NARSession:
+def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode: int = 0, diff=None,
+                    spk_vec: Optional[Tensor] = None, cond_from: Optional[NARSession] = None) -> NARSession:
     """Start the part of ``perform_simple_inference`` that depends only on the conditioning (text ids (1,Lt),
     reference codes (1,Lc,8)) and the schedule -- speaker vector, text encoder for every step and guidance branch,
     cross-attention K / V -- on the session's own stream and return without waiting.  ``tts()`` calls this BEFORE the
@@ -120,7 +121,10 @@ def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode
     eng = model.engine()
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
     sess = NARSession(eng, cfg, diff_tables=_tables(diff))
-    sess.prepare_cond(c_text[0], c_codes[0].to(eng.dev), times)
+    if cond_from is not None and cond_from.cfg == cfg and cond_from.times == list(times) and _same_tables(cond_from.diff_tables, sess.diff_tables):
+        sess.adopt_cond(cond_from)          # same text, reference, schedule: nothing to recompute (Mars5TTS.prepare_reference)
+    else:
+        sess.prepare_cond(c_text[0], c_codes[0].to(eng.dev), times, spk_vec=spk_vec)
     return sess
 
 

@@ -156,7 +156,16 @@ class NARSession:
         self.s_out = self.S - self.row_offset
         assert self.S <= self.m.pe.shape[0]
 
-    def prepare_cond(self, c_text: torch.Tensor, c_codes: torch.Tensor, times: Optional[List[int]] = None) -> None:
+    def adopt_cond(self, other: "NARSession") -> None:
+        """Take over the conditioning state another session computed for the SAME (text ids, reference codes, schedule,
+        guidance setting): per-layer cross-attention memories, timestep vectors, schedule constants.  Read-only in the
+        loop, so sessions may share it; the donor's work must be complete (its stream synchronised)."""
+        assert other.cfg == self.cfg and other.m is self.m
+        self.times, self.nb, self.t_dec, self.mems, self.consts = other.times, other.nb, other.t_dec, other.mems, other.consts
+        self._keep = getattr(other, "_keep", [])
+
+    def prepare_cond(self, c_text: torch.Tensor, c_codes: torch.Tensor, times: Optional[List[int]] = None,
+                     spk_vec: Optional[torch.Tensor] = None) -> None:
         """Everything that depends only on the conditioning (text ids, reference codes) and the
         schedule - independent of the AR output, so a server can run it beside the AR decode:
         speaker vectors, timestep MLPs, the text encoder for every (step, cond/uncond) pair and the
@@ -177,7 +186,7 @@ class NARSession:
             Lt = int(c_text.shape[0])
             Le = Lt + 1
             # -- speaker vectors (t-independent) and timestep MLPs for every scheduled t
-            spk_c = mdl.spk(c_codes, stream=st)
+            spk_c = mdl.spk(c_codes, stream=st) if spk_vec is None else spk_vec.to(dev)
             rows = [spk_c]
             if guided:
                 rows.append(mdl.uncond_speaker(stream=st))

@@ -429,6 +429,37 @@ def test_tts_batch_equals_sequential_seeded_calls(dev, tiny_bundle):
     print("generated frames per request:", [int(a.shape[0]) for a, _ in seq])
 
 
+def test_reference_handle_gives_identical_codes(dev, tiny_bundle):
+    """``prepare_reference`` caches what depends on the reference only (speech tokens, AR / NAR speaker
+    vectors) and, per text, the NAR conditioning state.  Exact by construction: seeded calls with the handle -- first use,
+    conditioning-cache hit on the same text, a different text, eviction beyond max_cond -- must return the codes of
+    the plain call, bit for bit."""
+    from inference import InferenceConfig
+    from mars5_tts_amd import synth
+    m = _tiny_tts(tiny_bundle, dev, torch.bfloat16)
+    ref = synth.make_ref_codes(60, seed=9)
+    tr = "We meet at noon."
+    cfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100, generate_max_len_override=200)
+    texts = ["The quick brown rat.", "The quick brown rat.", "Another sentence entirely.", "Third one.", "The quick brown rat."]
+    plain = []
+    for i, t in enumerate(texts):
+        torch.manual_seed(70 + i)
+        plain.append(m.tts_from_codes(t, ref, tr, cfg))
+    h = m.prepare_reference(ref, tr, max_cond=2)
+    for i, t in enumerate(texts):
+        torch.manual_seed(70 + i)
+        gen, final = m.tts_from_codes(t, None, None, cfg, ref_handle=h)
+        assert torch.equal(gen.cpu(), plain[i][0].cpu()) and torch.equal(final.cpu(), plain[i][1].cpu()), f"request {i} ({t!r})"
+        assert len(h.cond) <= 2
+    for deep in (False,):                                    # shallow clone through the same handle (no speech prompt)
+        cfg_s = InferenceConfig(deep_clone=deep, temperature=0.7, top_k=100, generate_max_len_override=60)
+        torch.manual_seed(5)
+        a = m.tts_from_codes("Hello there.", ref, tr, cfg_s)
+        torch.manual_seed(5)
+        b = m.tts_from_codes("Hello there.", None, None, cfg_s, ref_handle=h)
+        assert torch.equal(a[0].cpu(), b[0].cpu()) and torch.equal(a[1].cpu(), b[1].cpu())
+
+
 def test_ar_generator_left_where_reference_leaves_it(dev, tiny_bundle):
     """After ``ar_generate`` the device generator must sit where the reference leaves it: one
     Exp(1) draw of (V,) per executed loop iteration (ar_generate.py:115), including the iteration that
