@@ -87,7 +87,7 @@ def _cpu_tts(tiny_vocab):
     import inference as inf
     from mars5_tts_amd import minbpe
 
-    def fake_begin(model, c_text, c_codes, T, dsh=None, div_mode=0, diff=None):
+    def fake_begin(model, c_text, c_codes, T, dsh=None, div_mode=0, diff=None, **kw):
         return None
 
     def fake_ar(texttok, speechtok, codeclm, xx, ss_gen, first_codex_idx, max_len=1500, **kw):
