@@ -184,6 +184,8 @@ def expand_tokens(tokens: torch.Tensor, n_text: int, off: torch.Tensor, vals: to
     one launch, then a 4-byte read-back of G (the NAR buffers are sized by it)."""
     assert tokens.dtype == torch.int64 and off.dtype == torch.int32 and vals.dtype == torch.int64 and tokens.is_contiguous()
     n = int(tokens.shape[0])
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=tokens.device)
     cap = max(n * max(max_run, 1), 1)
     out = torch.empty(cap, dtype=torch.int64, device=tokens.device)
     total = torch.zeros(1, dtype=torch.int32, device=tokens.device)
