@@ -313,6 +313,10 @@ int m5_debug_gemm_clock(unsigned long long* buf);
  * times; mode 0 LDS-DMA, 1 global_load -> ds_write, 2 global loads only.  tools/feed_probe.py. */
 int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int iters, int row_bytes, int mode, int blocks, int threads,
                         float* sink, void* stream);
+
+/* Diagnostics: workgroup b streams chunk (b + shift) % blocks of buf (chunk_bytes each; nt = non-temporal loads): pairs of
+ * launches with equal / different shifts measure whether an XCD's L2 keeps lines across a kernel boundary.  tools/l2_retention.py. */
+int m5_debug_l2_touch(const void* buf, int64_t chunk_bytes, int blocks, int threads, int shift, int nt, float* sink, void* stream);
 #endif /* M5_TOOLS */
 
 #ifdef __cplusplus

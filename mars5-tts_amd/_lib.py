@@ -144,6 +144,7 @@ TOOLS_PROTOTYPES = {
     "m5_debug_feed_probe": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "m5_debug_launch_chain": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "m5_debug_grid_barrier": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "m5_debug_l2_touch": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
 }
 
 

@@ -199,4 +199,34 @@ extern "C" int m5_debug_grid_barrier(uint32_t* scratch, int blocks, int threads,
     return M5_OK;
 }
 
+
+// ---- L2-retention probe (diagnostics; tools/l2_retention.py): does data a launch pulled into an XCD's L2 still hit there
+// in the NEXT launch of the stream?  Workgroup b streams chunk (b + shift) % gridDim.x of the buffer (plain or nt 16-byte
+// loads).  A timed launch (shift 0) right after a warming launch with shift 0 finds its chunk where the same XCD left it;
+// after shift 1 the chunk was left in the neighbouring XCD's L2; after a launch over another buffer it is cold.  That
+// decides whether producer -> consumer XCD affinity / same-stream prefetch can pay on this part.
+namespace {
+template <bool NT>
+__global__ void l2_touch_kernel(const unsigned char* buf, int64_t chunk_bytes, int shift, float* sink) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int64_t c = (blockIdx.x + shift) % gridDim.x;
+    const u32x4* p = reinterpret_cast<const u32x4*>(buf + c * chunk_bytes);
+    const int n = (int)(chunk_bytes / 16);
+    unsigned acc = 0;
+#pragma unroll 8
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const u32x4 v = NT ? __builtin_nontemporal_load(p + i) : p[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = 1.f;
+}
+}  // namespace
+extern "C" int m5_debug_l2_touch(const void* buf, int64_t chunk_bytes, int blocks, int threads, int shift, int nt, float* sink, void* stream) {
+    if (!buf || !sink || chunk_bytes <= 0 || (chunk_bytes % 16) || blocks <= 0 || threads <= 0 || threads > 1024) return M5_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (nt) hipLaunchKernelGGL(l2_touch_kernel<true>, dim3(blocks), dim3(threads), 0, s, (const unsigned char*)buf, chunk_bytes, shift, sink);
+    else hipLaunchKernelGGL(l2_touch_kernel<false>, dim3(blocks), dim3(threads), 0, s, (const unsigned char*)buf, chunk_bytes, shift, sink);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
 #endif  // M5_TOOLS
