@@ -76,7 +76,7 @@ def nar_step_consts(times: List[int], num_classes: int = 1025, timesteps: int = 
     for t in times:
         tm1 = max(t - 1, 0)
         rows.append(torch.stack([lca[tm1], l1mca[tm1] - lnK, la[t], l1ma[t] - lnK, lca[t], l1mca[t] - lnK,
-                                 torch.tensor(float(t)), torch.tensor(0.0)]))
+                                 torch.tensor(float(t), device="cpu"), torch.tensor(0.0, device="cpu")]))
     return torch.stack(rows).float().contiguous()
 
 
