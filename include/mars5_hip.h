@@ -129,6 +129,22 @@ int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, i
                          int M, int n_heads, int K, const int64_t* mem_table, int max_le, int rows_per_seq,
                          const int32_t* step, float scale, void* out, int64_t ld_out, void* stream);
 
+/* Cross-attention against a short memory with the projections absorbed into the memory (16-bit engines; NAR decoder,
+ * model.py:179-203).  Per head h: scores = x (K_h Wq_h / 8)^T + K_h bq_h / 8 =: x A_h^T + c_h and
+ * out = sum_h softmax(scores_h) (V_h Wo_h^T) + bo =: P B + bo, so a layer needs two GEMMs of width n_heads * Lp instead of
+ * q-projection + attention + out-projection.
+ *  - m5_xattn_absorb builds, for the memory block of the device step index *step, A [n_heads*Lp][D] (16-bit), c [n_heads*Lp]
+ *    (fp32; padded keys -1e30) and B^T [D][n_heads*Lp] (16-bit) of every (layer, sequence) in ONE launch.
+ *    tab_seq [n_layers*n_seq][8] (device int64): {K base, V base (both [H][Le][64] inside a step block), Le, step stride
+ *    (elements), A out, c out, B^T out, 0};  tab_layer [n_layers][4]: {WqT ([H][D][64]: Wq[h*64+d][n] at [h][n][d]),
+ *    Wo ([D][D] row-major), bq (fp32 [D]) or 0, 0}.  Lp = 48 or 64 >= every Le.
+ *  - m5_xattn_scores: P[b] = per-head softmax(X[b] A[b]^T + c[b]) (16-bit [M][n_heads*Lp], row stride ldp) for `batch`
+ *    sequences (strides sX, sA_tab, sc_tab, sP in elements).  Then m5_gemm(P, B^T, EPI_RESIDUAL, batch) finishes the block. */
+int m5_xattn_absorb(int dtype, const int64_t* tab_seq, const int64_t* tab_layer, int n_layers, int n_seq, int n_heads,
+                    int D, int Lp, const int32_t* step, float scale, void* stream);
+int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                    void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, void* stream);
+
 /* x[M][N] += A . W^T + bias (the RESIDUAL epilogue of m5_gemm) with the LayerNorm that follows it in every pre-LN
  * block (model.py:179-203: norm2 / norm3 / the next layer's norm1) fused into the same launch:
  * xn = LayerNorm(x_new; gamma, beta, eps) in the operand type.  The workgroups of a row tile exchange per-tile

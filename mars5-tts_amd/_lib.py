@@ -112,6 +112,8 @@ PROTOTYPES = {
     "m5_gemm_q_cross_attn": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, f32, vp, i64, vp]),
     "m5_gemm_residual_ln": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, f32, vp, i64, vp, i64,
                                        vp, C.c_int, vp]),
+    "m5_xattn_absorb": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
+    "m5_xattn_scores": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "m5_layernorm": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
     "m5_rmsnorm": (C.c_int, [C.c_int, vp, i64, vp, f32, vp, i64, C.c_int, C.c_int, vp]),
     "m5_attention": (C.c_int, [C.c_int, C.POINTER(AttnArgs), vp]),

@@ -35,6 +35,7 @@ class EncLayerW:
     ca_q_w: Optional[torch.Tensor] = None; ca_q_b: Optional[torch.Tensor] = None
     ca_kv_w: Optional[torch.Tensor] = None; ca_kv_b: Optional[torch.Tensor] = None
     ca_out_w: Optional[torch.Tensor] = None; ca_out_b: Optional[torch.Tensor] = None
+    ca_q_wT: Optional[torch.Tensor] = None
     n3_w: Optional[torch.Tensor] = None; n3_b: Optional[torch.Tensor] = None
 
 
@@ -61,6 +62,11 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str, dt: torch.dtype, dev, cross:
         lw.ca_kv_w = cw[D:].to(device=dev, dtype=dt).contiguous()
         lw.ca_kv_b = cb[D:].to(device=dev, dtype=torch.float32).contiguous()
         lw.ca_out_w = W(f"{p}.multihead_attn.out_proj.weight")
+        # absorbed cross-attention (csrc/xattn_absorb.hip): Wq as [H][D][64] (Wq[h*64+d][n] at [h][n][d]), K and V weights apart
+        if dt != torch.float32:
+            H = D // 64
+            lw.ca_q_wT = lw.ca_q_w.view(H, 64, D).permute(0, 2, 1).contiguous()
+            lw.ca_k_w, lw.ca_v_w = lw.ca_kv_w[:D], lw.ca_kv_w[D:]
         lw.ca_out_b = Fv(f"{p}.multihead_attn.out_proj.bias")
         lw.n3_w, lw.n3_b = Fv(f"{p}.norm3.weight"), Fv(f"{p}.norm3.bias")
     return lw
@@ -164,6 +170,7 @@ class CrossMemory:
     Le: int
     Lep: int
     Bm: int          # memory batch entries per step (2 = cond, uncond)
+    v_rows: Optional[torch.Tensor] = None     # V as rows (T*Bm, H, Le, 64), for the absorbed path (16-bit engines)
 
 
 def cross_memory_table(mems, dev) -> tuple:
@@ -181,22 +188,125 @@ def cross_memory_table(mems, dev) -> tuple:
     return torch.tensor(rows, dtype=torch.int64).to(dev), max(m.Le for m in mems)
 
 
+class AbsorbedCross:
+    """Operands of the absorbed cross-attention (csrc/xattn_absorb.hip) for all decoder layers and a CONTIGUOUS run of
+    workspace sequences [s0, s0 + n_seq) whose memories share the padded length Lp (48 if Le <= 48, else 64): built for the
+    current reverse step by ONE launch (`build`), then each layer's block is a scores GEMM with per-head softmax and a P.B
+    GEMM with the residual epilogue, both batched over the sequences.  Lp is a function of the utterance's own Le, so an
+    utterance is computed with the same arithmetic alone and inside any batch."""
+
+    def __init__(self, layers, mems_per_layer, s0: int, D: int, dt: torch.dtype, dev):
+        H = D // 64
+        self.H, self.D, self.dt, self.s0 = H, D, dt, s0
+        self.n_seq = sum(mem.Bm for mem in mems_per_layer[0])
+        self.n_layers = len(layers)
+        self.Lp = self.lp_of(mems_per_layer[0][0].Le)
+        assert all(self.lp_of(m.Le) == self.Lp for m in mems_per_layer[0])
+        N = H * self.Lp
+        self.A = torch.zeros(self.n_layers, self.n_seq, N, D, dtype=dt, device=dev)
+        self.c = torch.zeros(self.n_layers, self.n_seq, N, dtype=torch.float32, device=dev)
+        self.Bt = torch.zeros(self.n_layers, self.n_seq, D, N, dtype=dt, device=dev)
+        rows, lrows = [], []
+        es = self.A.element_size()
+        for l, (lw, mems) in enumerate(zip(layers, mems_per_layer)):
+            s = 0
+            for mem in mems:
+                for b in range(mem.Bm):
+                    rows.append([mem.k.data_ptr() + b * H * mem.Le * 64 * es, mem.v_rows.data_ptr() + b * H * mem.Le * 64 * es, mem.Le,
+                                 mem.Bm * H * mem.Le * 64, self.A[l, s].data_ptr(), self.c[l, s].data_ptr(), self.Bt[l, s].data_ptr(), 0])
+                    s += 1
+            lrows.append([lw.ca_q_wT.data_ptr(), lw.ca_out_w.data_ptr(), lw.ca_q_b.data_ptr() if lw.ca_q_b is not None else 0, 0])
+        self.tab_seq = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.tab_layer = torch.tensor(lrows, dtype=torch.int64).to(dev)
+
+    @staticmethod
+    def lp_of(Le: int) -> int:
+        """padded memory length of the absorbed path; 0 = not eligible (longer memories keep the unfused path: beyond
+        64 keys the absorbed operands are wider than the projections they replace)"""
+        return 48 if Le <= 48 else (64 if Le <= 64 else 0)
+
+    def build(self, step_ptr: torch.Tensor, stream=None) -> None:
+        ops.xattn_absorb(self.dt, self.tab_seq, self.tab_layer, self.n_layers, self.n_seq, self.H, self.D, self.Lp, step_ptr, 64 ** -0.5,
+                         stream=stream)
+
+    def block(self, l: int, x: torch.Tensor, lw: EncLayerW, ws: "SeqWorkspace", stream=None) -> None:
+        """x[rows of my sequences] += cross-attention of ws.xn (= LN2(x)) against layer l's memory: two launches."""
+        N = self.H * self.Lp
+        r0, rows = self.s0 * ws.Sr, self.n_seq * ws.Sr
+        P = ws.hff.view(-1)[r0 * N: (r0 + rows) * N].view(rows, N)        # the feed-forward scratch is free here (N <= FF)
+        ops.xattn_scores(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq, stream=stream)
+        ops.gemm(P, self.Bt[l, 0], x[r0:], L.EPI_RESIDUAL, bias=lw.ca_out_b, M=ws.Sr, batch=self.n_seq, sA=ws.Sr * N, sW=self.D * N,
+                 sC=ws.Sr * self.D, sBias=0, stream=stream)
+
+
+def make_cross_plan(layers, mems_per_layer, D: int, dt: torch.dtype, dev) -> list:
+    """Split the workspace's sequences (in order; mems_per_layer[l] = one CrossMemory per utterance) into maximal runs of
+    utterances that take the same cross-attention path: ("absorbed", AbsorbedCross) for 16-bit engines and memories of
+    <= 64 rows (one run per padded length), ("plain", s0, s1, utterance indices) otherwise."""
+    plan, s = [], 0
+    mems0 = mems_per_layer[0]
+    i = 0
+    while i < len(mems0):
+        cls = AbsorbedCross.lp_of(mems0[i].Le) if (dt != torch.float32 and mems0[i].v_rows is not None) else 0
+        j = i
+        while j < len(mems0) and (AbsorbedCross.lp_of(mems0[j].Le) if (dt != torch.float32 and mems0[j].v_rows is not None) else 0) == cls:
+            j += 1
+        n = sum(m.Bm for m in mems0[i:j])
+        if cls:
+            plan.append(("absorbed", AbsorbedCross(layers, [ml[i:j] for ml in mems_per_layer], s, D, dt, dev)))
+        else:
+            plan.append(("plain", s, s + n, list(range(i, j))))
+        s += n
+        i = j
+    return plan
+
+
+def _plain_cross(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, s0: int, s1: int, step_ptr: torch.Tensor, stream=None) -> None:
+    """q-projection, attention per utterance against its pre-projected memory, out-projection (+residual) for the
+    workspace sequences [s0, s1) -- the reference's operation order."""
+    H, S, Sr, D = ws.H, ws.S, ws.Sr, ws.D
+    esz = ws.q.element_size()
+    r0, rows = s0 * Sr, (s1 - s0) * Sr
+    sc = ws.scatter(True, False, False)
+    sc.q = ws.q.data_ptr() + s0 * H * Sr * 64 * esz
+    ops.gemm(ws.xn[r0:r0 + rows], lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=sc, stream=stream)
+    b0 = s0
+    for mem in mems:
+        a = L.AttnArgs(q=ws.q.data_ptr() + b0 * H * Sr * 64 * esz, q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64,
+                       k=mem.k.data_ptr(), k_bs=H * mem.Le * 64, k_hs=mem.Le * 64, k_rs=64,
+                       vt=mem.vt.data_ptr(), vt_bs=H * 64 * mem.Lep, vt_hs=64 * mem.Lep, vt_ds=mem.Lep,
+                       o=ws.att.data_ptr() + b0 * Sr * D * esz, o_bs=Sr * D, o_rs=D, B=mem.Bm, H=H, Sq=S, Sk=mem.Le, key_len=None,
+                       causal=0, scale=64 ** -0.5, kv_index=step_ptr.data_ptr(),
+                       kv_index_stride_k=mem.Bm * H * mem.Le * 64, kv_index_stride_v=mem.Bm * H * 64 * mem.Lep)
+        ops.attention(ws.dt, a, stream=stream)
+        b0 += mem.Bm
+    assert b0 == s1
+    ops.gemm(ws.att[r0:r0 + rows], lw.ca_out_w, x[r0:r0 + rows], L.EPI_RESIDUAL, bias=lw.ca_out_b, stream=stream)
+
+
 def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
-                     normed: bool = False, next_ln=None, xa=None) -> bool:
+                     normed: bool = False, next_ln=None, xa=None, plan=None, layer: int = 0) -> bool:
     """x = x + out_proj(SDPA(q_proj(LN2(x)), memory K/V of step *step_ptr)).
-    `mems`: one CrossMemory covering all ws.B sequences, or a list of them (one per utterance, each
-    covering its Bm consecutive sequences of the workspace; memories of different utterances have
-    different lengths, so the attention is launched per utterance while the projections stay batched)."""
+    `mems`: one CrossMemory covering all ws.B sequences, or a list of them (one per utterance, each covering its Bm
+    consecutive sequences of the workspace).  `plan` (``make_cross_plan``): per run of utterances either the absorbed
+    form (two batched GEMMs; operands built at the top of the step) or the reference's operation order."""
     H, S, Sr, D = ws.H, ws.S, ws.Sr, ws.D
     if not normed:
         ops.layernorm(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, stream=stream)
+    if isinstance(mems, CrossMemory):
+        mems = [mems]
+    if plan is not None:
+        for seg in plan:
+            if seg[0] == "absorbed":
+                seg[1].block(layer, x, lw, ws, stream)
+            else:
+                _plain_cross(x, lw, ws, [mems[u] for u in seg[3]], seg[1], seg[2], step_ptr, stream)
+        return False
     # xa = (memory table, longest memory) built before any graph capture: query projection + attention in one launch
     if xa is not None and ws.dt != torch.float32 and \
             ops.gemm_q_cross_attn(ws.xn, lw.ca_q_w, lw.ca_q_b, H, xa[0], xa[1], Sr, step_ptr, 64 ** -0.5, ws.att, stream=stream):
         return residual_gemm(ws.att, lw.ca_out_w, x, lw.ca_out_b, ws, next_ln, stream)
     ops.gemm(ws.xn, lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=ws.scatter(True, False, False), stream=stream)
-    if isinstance(mems, CrossMemory):
-        mems = [mems]
     b0 = 0
     esz = ws.q.element_size()
     for mem in mems:
@@ -213,12 +323,12 @@ def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, ste
 
 
 def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
-                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None, xa=None) -> bool:
+                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None, xa=None, plan=None, layer: int = 0) -> bool:
     """One pre-LN decoder layer.  Each residual GEMM tries to leave the NEXT LayerNorm's output in ws.xn (fused
     epilogue); `normed` says the caller (previous layer) already did that for norm1, the return value says whether
     `next_ln` (the following layer's norm1) has been applied on exit."""
     n = self_attn_block(x, lw, ws, key_len, stream, normed=normed, next_ln=(lw.n2_w, lw.n2_b))
-    n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b), xa=xa)
+    n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b), xa=xa, plan=plan, layer=layer)
     return ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream, normed=n, next_ln=next_ln)
 
 

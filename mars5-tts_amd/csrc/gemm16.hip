@@ -59,6 +59,7 @@ struct Gemm16Params {
 };
 constexpr int EPI_RESIDUAL_LN = 101;
 constexpr int EPI_Q_CROSS = 102;
+constexpr int EPI_SOFTMAX_HEADS = 103;           // C (16-bit) = per-head softmax over the wave's TN*16 columns of acc + bias (xattn_absorb.hip)
 constexpr int XA_MAX_KT = 4;                     // fused cross-attention: at most 4 key tiles of 16 (memory length <= 64)
 
 template <typename T>
@@ -654,6 +655,59 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         return;
     }
 
+    // ---- absorbed cross-attention scores (xattn_absorb.hip): the wave's TN*16 columns are ONE head's (padded) key block;
+    // acc + c is the scaled score, its softmax over those columns leaves as 16-bit probabilities (the A operand of the
+    // P.B GEMM).  Padded keys carry c = -1e30 -> probability exactly 0.  A row's values sit in the 4 lane groups of a lane's
+    // l15 (4 consecutive columns per 16-column tile each): two xor-shuffles finish max and sum.
+    if constexpr (EPI == EPI_SOFTMAX_HEADS) {
+        constexpr int RB = TN * 32, RBS = RB + 16, CPR = RB / 16, RPP = 64 / CPR;
+        static_assert(NW * TM * 16 * RBS <= NSTAGE * STAGE, "the output tile is staged in the (dead) K-loop stages");
+        __syncthreads();
+        unsigned char* ws = lds + wave * (TM * 16 * RBS);
+        const float* biasp = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
+        float bvs[TN][4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bvs[j][r] = biasp ? biasp[min(nw + j * 16 + lg * 4 + r, p.N - 1)] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float v[TN][4];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[j][r] = (acc[i][j][r] + bvs[j][r]) * 1.4426950408889634f; mx = fmaxf(mx, v[j][r]); }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[j][r] = __builtin_amdgcn_exp2f(v[j][r] - mx); sum += v[j][r]; }
+            sum += __shfl_xor(sum, 16);
+            sum += __shfl_xor(sum, 32);
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float o[4] = {v[j][0] * inv, v[j][1] * inv, v[j][2] * inv, v[j][3] * inv};
+                *reinterpret_cast<uint2*>(ws + (i * 16 + l15) * RBS + (j * 16 + lg * 4) * 2) = pack4<T>(o);
+            }
+        }
+        const int rr = lane / CPR, ch = lane - rr * CPR;
+        st* Cd = reinterpret_cast<st*>(p.C) + (int64_t)bz * p.sC;
+        const int mrow0 = m0 + wm * TM * 16, ocol = nw + ch * 8;
+#pragma unroll
+        for (int pass = 0; pass < (TM * 16 + RPP - 1) / RPP; ++pass) {
+            const int r = pass * RPP + rr;
+            if (rr < RPP && r < TM * 16 && mrow0 + r < p.M && ocol < p.N) {
+                const uint4 val = *reinterpret_cast<const uint4*>(ws + r * RBS + ch * 16);
+                *reinterpret_cast<uint4*>(Cd + (int64_t)(mrow0 + r) * p.ldc + ocol) = val;
+            }
+        }
+        return;
+    }
+
     // ---- 16-bit outputs (plain / SiLU / SwiGLU): stage the wave's output tile through LDS and store
     // whole 16-byte row chunks.  Straight from the accumulator layout a SwiGLU store instruction writes
     // 16 rows x 16 bytes (4 bytes per lane); measured 10 us of a 47 us K = 1024 SwiGLU launch went into
@@ -835,6 +889,10 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
     if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
     p.nblk = (int)nblk;
     p.group_m = max(1, GROUP_M * 128 / BM);
+    if (const char* be = m5_tool_env("M5_GEMM_BAND")) {      // experiment: one band of tile rows per XCD (row-local producer/consumer L2 affinity)
+        const int rows = atoi(be);
+        if (rows > 0) p.group_m = max(1, rows / BM);
+    }
     const dim3 grid(p.nblk), blk(WM * WN * 64);
 #define M5_G16(E) hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC>), grid, blk, 0, s, p)
     switch (epi) {
@@ -939,6 +997,38 @@ extern "C" int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const
     const dim3 grid(p.nblk), blk(256);
     if (dtype == M5_F16) hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_Q_CROSS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((gemm16_kernel<BF16T, EPI_Q_CROSS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, (hipStream_t)stream, p);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+// Scores + per-head softmax of the absorbed cross-attention (include/mars5_hip.h, xattn_absorb.hip): P[b] = softmax_heads(
+// X[b] A[b]^T + c[b]) for `batch` sequences, head blocks of Lp = 48 or 64 columns (one per wave), 96-row tiles.
+extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                               void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, void* stream) {
+    if (!X || !A || !c || !P || M <= 0 || n_heads <= 0 || K <= 0 || batch <= 0) return M5_ERR_ARG;
+    if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
+    if ((Lp != 48 && Lp != 64) || (n_heads % 2) || (K % 64)) return M5_ERR_UNSUPPORTED;
+    if ((ldx % 8) || (sX % 8) || (sA_tab % 8) || (ldp % 8) || (sP % 8) || (((uintptr_t)X | (uintptr_t)A | (uintptr_t)P) & 15)) return M5_ERR_ARG;
+    Gemm16Params p{};
+    p.A = (const unsigned char*)X; p.W = (const unsigned char*)A; p.bias = c; p.C = (unsigned char*)P;
+    p.lda = ldx; p.ldw = K; p.ldc = ldp; p.sA = sX; p.sW = sA_tab; p.sC = sP; p.sBias = sc_tab;
+    p.M = M; p.N = n_heads * Lp; p.K = K;
+    p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
+    p.vec16 = 1; p.vec_c = 1;
+    const int BN = 2 * Lp;
+    p.tilesM = (M + 95) / 96; p.tilesN = p.N / BN;
+    const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
+    if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
+    p.nblk = (int)nblk; p.group_m = max(1, GROUP_M * 128 / 96);
+    const dim3 grid(p.nblk), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == M5_F16) {
+        if (Lp == 48) hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 3, 128, 4, 1>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, s, p);
+    } else {
+        if (Lp == 48) hipLaunchKernelGGL((gemm16_kernel<BF16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 3, 128, 4, 1>), grid, blk, 0, s, p);
+        else hipLaunchKernelGGL((gemm16_kernel<BF16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, s, p);
+    }
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

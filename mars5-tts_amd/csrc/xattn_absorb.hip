@@ -1,0 +1,130 @@
+// Cross-attention against a SHORT memory with the projections absorbed into the memory (NAR decoder, reference
+// mars5/model.py:179-203: nn.MultiheadAttention(tgt, memory) of every decoder layer; the text memory has Le ~ 20-60 rows
+// while the target has ~1.4k).
+//
+// Per head h:  S_h = (x Wq_h^T + bq_h) K_h^T / 8 = x (K_h Wq_h / 8)^T + (K_h bq_h / 8)      =: x A_h^T + c_h
+//              y   = sum_h softmax(S_h) V_h Wo_h^T + bo = sum_h P_h (V_h Wo_h^T) + bo       =: P B + bo
+// with Wq_h = rows h*64..h*64+63 of the query projection and Wo_h = columns h*64.. of the output projection.  A (H*Lp x D)
+// and B^T (D x H*Lp) depend on the memory only, so they are built once per reverse step for all layers by ONE launch of
+// this kernel; the decoder layer then runs two GEMMs (x A^T with a per-head softmax epilogue, P B with the residual
+// epilogue) of N = K = H*Lp = 768 (Lp = 48) instead of q-projection (N = 1024) + attention launch + out-projection
+// (K = 1024): one launch and a quarter of the flops less per layer, and no q / attention-output round trip.
+// Exact in exact arithmetic; in 16-bit operands the rounding points move from q and softmax(S) V to A and B (same count,
+// same magnitude) -- bounded against the oracle by tests/test_gpu_parity16.py.  fp32 parity mode keeps the unfused order.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) _Float16 h8a_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 b8a_t;
+typedef __attribute__((ext_vector_type(4))) float f4a_t;
+
+namespace {
+
+template <typename T>
+__device__ inline f4a_t mfma_a(const uint4& a, const uint4& b, f4a_t c);
+template <>
+__device__ inline f4a_t mfma_a<F16T>(const uint4& a, const uint4& b, f4a_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8a_t*>(&a), *reinterpret_cast<const h8a_t*>(&b), c, 0, 0, 0);
+}
+template <>
+__device__ inline f4a_t mfma_a<BF16T>(const uint4& a, const uint4& b, f4a_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const b8a_t*>(&a), *reinterpret_cast<const b8a_t*>(&b), c, 0, 0, 0);
+}
+
+// grid (H, n_seq * n_layers, 2): blockIdx.z = 0 builds A and c, 1 builds B^T, of head blockIdx.x for (layer, sequence)
+// blockIdx.y.  256 threads = 4 waves; wave w owns a quarter of the 1024-wide model dimension.
+// MFMA 16x16x32 with the gemm16 operand order: mfma(Pfrag, Qfrag) -> acc[r] = C[row of Q = l15][row of P = 4 lg + r].
+template <typename T, int JT>      // JT = Lp / 16 key tiles (3 or 4)
+__global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, const int64_t* tab_layer, int n_seq, int D, const int32_t* step,
+                                                     float scale) {
+    using st = typename T::storage;
+    constexpr int Lp = JT * 16;
+    const int h = blockIdx.x, ls = blockIdx.y, which = blockIdx.z;
+    const int layer = ls / n_seq;
+    const int64_t* ts = tab_seq + (int64_t)ls * 8;
+    const int64_t* tl = tab_layer + (int64_t)layer * 4;
+    const int le = (int)ts[2];
+    const int64_t stp = *step;
+    const int H = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
+    const int nq = D / 4;                                   // model-dimension columns per wave
+    // memory rows of this head at this step: [Le][64], 16-bit
+    const st* mem = reinterpret_cast<const st*>(which == 0 ? ts[0] : ts[1]) + stp * ts[3] + (int64_t)h * le * 64;
+    uint4 mf[JT][2];                                        // fragments of the memory rows: row 16 jt + l15, k chunk 4 ks + lg
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int j = jt * 16 + l15;
+            mf[jt][ks] = (j < le) ? *reinterpret_cast<const uint4*>(mem + (int64_t)j * 64 + (ks * 4 + lg) * 8) : make_uint4(0, 0, 0, 0);
+        }
+    if (which == 0) {
+        // A[h Lp + j][n] = scale * sum_d K[j][d] WqT[h][n][d]      (WqT: [H][D][64], d contiguous)
+        const st* wq = reinterpret_cast<const st*>(tl[0]) + (int64_t)h * D * 64;
+        st* A = reinterpret_cast<st*>(ts[4]) + (int64_t)h * Lp * D;
+        for (int nt = 0; nt < nq / 16; ++nt) {
+            const int n0 = wave * nq + nt * 16;
+            uint4 wf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(wq + (int64_t)(n0 + l15) * 64 + (ks * 4 + lg) * 8);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                f4a_t acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mfma_a<T>(wf[0], mf[jt][0], acc);      // acc[r] = C[j = 16 jt + l15][n = n0 + 4 lg + r]
+                acc = mfma_a<T>(wf[1], mf[jt][1], acc);
+                st o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r] * scale);
+                *reinterpret_cast<uint2*>(A + (int64_t)(jt * 16 + l15) * D + n0 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+            }
+        }
+        // c[h Lp + j] = scale * K[j] . bq[h 64 ..]  (fp32);  padded keys: -1e30 (their softmax weight is exactly 0)
+        if (threadIdx.x < Lp) {
+            const int j = threadIdx.x;
+            float cv = -1e30f;
+            if (j < le) {
+                const float* bq = reinterpret_cast<const float*>(tl[2]) + h * 64;
+                float s = 0.f;
+                for (int d = 0; d < 64; ++d) s = fmaf(T::to_f32(mem[(int64_t)j * 64 + d]), bq ? bq[d] : 0.f, s);
+                cv = s * scale;
+            }
+            reinterpret_cast<float*>(ts[5])[h * Lp + j] = cv;
+        }
+    } else {
+        // Bt[n][h Lp + j] = sum_d Wo[n][h 64 + d] V[j][d]
+        const st* wo = reinterpret_cast<const st*>(tl[1]) + h * 64;
+        st* Bt = reinterpret_cast<st*>(ts[6]) + h * Lp;
+        const int ldb = H * Lp;
+        for (int nt = 0; nt < nq / 16; ++nt) {
+            const int n0 = wave * nq + nt * 16;
+            uint4 wf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(wo + (int64_t)(n0 + l15) * D + (ks * 4 + lg) * 8);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                f4a_t acc = {0.f, 0.f, 0.f, 0.f};
+                acc = mfma_a<T>(mf[jt][0], wf[0], acc);      // acc[r] = C[n = n0 + l15][j = 16 jt + 4 lg + r]
+                acc = mfma_a<T>(mf[jt][1], wf[1], acc);
+                st o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r]);
+                *reinterpret_cast<uint2*>(Bt + (int64_t)(n0 + l15) * ldb + jt * 16 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int m5_xattn_absorb(int dtype, const int64_t* tab_seq, const int64_t* tab_layer, int n_layers, int n_seq, int n_heads,
+                               int D, int Lp, const int32_t* step, float scale, void* stream) {
+    if (!tab_seq || !tab_layer || !step || n_layers <= 0 || n_seq <= 0 || n_heads <= 0) return M5_ERR_ARG;
+    if ((dtype != M5_F16 && dtype != M5_BF16) || (Lp != 48 && Lp != 64) || (D % 64)) return M5_ERR_UNSUPPORTED;
+    const dim3 grid(n_heads, n_seq * n_layers, 2);
+    hipStream_t s = (hipStream_t)stream;
+#define M5_ABS(TT, JT) hipLaunchKernelGGL((absorb_kernel<TT, JT>), grid, dim3(256), 0, s, tab_seq, tab_layer, n_seq, D, step, scale)
+    if (dtype == M5_F16) { if (Lp == 48) M5_ABS(F16T, 3); else M5_ABS(F16T, 4); }
+    else { if (Lp == 48) M5_ABS(BF16T, 3); else M5_ABS(BF16T, 4); }
+#undef M5_ABS
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}

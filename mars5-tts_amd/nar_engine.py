@@ -30,8 +30,8 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .blocks import (LAYERNORM_EPS, CrossMemory, SeqWorkspace, SpeakerEncoder, cross_attn_block, cross_memory_table, decoder_layer,
-                     encoder_layer, ff_block, pack_layer, residual_gemm, round_up, self_attn_block)
+from .blocks import (LAYERNORM_EPS, AbsorbedCross, CrossMemory, SeqWorkspace, SpeakerEncoder, cross_attn_block, cross_memory_table,
+                     decoder_layer, encoder_layer, ff_block, make_cross_plan, pack_layer, residual_gemm, round_up, self_attn_block)
 from .synth import NARShape
 from .tables import log_eps, nar_step_consts, reverse_schedule, sine_pe, timestep_inputs
 
@@ -212,8 +212,18 @@ class NARSession:
             # -- cross-attention K / V^T of every decoder layer for every step
             Lep = round_up(Le, 64)
             self.mems: List[CrossMemory] = []
+            # short memory: K and V as rows for the absorbed form (blocks.AbsorbedCross); M5_NAR_ABSORB=0: A/B knob (tools/nar_step_bench.py)
+            absorbed = dt != torch.float32 and AbsorbedCross.lp_of(Le) > 0 and os.environ.get("M5_NAR_ABSORB", "1") != "0"
             for lw in mdl.dec:
                 k = torch.empty(T * nb, H, Le, 64, dtype=dt, device=dev)
+                if absorbed:
+                    v_rows = torch.empty(T * nb, H, Le, 64, dtype=dt, device=dev)
+                    for w, b, dst in ((lw.ca_k_w, lw.ca_kv_b[:D], k), (lw.ca_v_w, lw.ca_kv_b[D:], v_rows)):
+                        sc = L.QkvScatter(q=None, k=dst.data_ptr(), vt=None, rows_per_batch=Le, n_heads=H, head_dim=64,
+                                          q_bs=0, q_hs=0, q_rs=0, k_bs=H * Le * 64, k_hs=Le * 64, k_rs=64, vt_bs=0, vt_hs=0, vt_ds=0)
+                        ops.gemm(mem, w, None, L.EPI_QKV, bias=b, scatter=sc, stream=st)
+                    self.mems.append(CrossMemory(k, None, Le, Lep, nb, v_rows=v_rows))
+                    continue
                 vt = torch.zeros(T * nb, H, 64, Lep, dtype=dt, device=dev)
                 sc = L.QkvScatter(q=None, k=k.data_ptr(), vt=vt.data_ptr(), rows_per_batch=Le, n_heads=H, head_dim=64,
                                   q_bs=0, q_hs=0, q_rs=0, k_bs=H * Le * 64, k_hs=Le * 64, k_rs=64,
@@ -244,7 +254,9 @@ class NARSession:
             self.logits = torch.empty(nb * self.s_out, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
-            self.xa = [cross_memory_table(mem, dev) for mem in self.mems]       # per layer, for the fused q-projection + cross-attention
+            # cross-attention path of this utterance: absorbed operands (rebuilt per step by one launch) or the reference order
+            self.plan = make_cross_plan(mdl.dec, [[mem] for mem in self.mems], D, dt, dev)
+            self.xa = [cross_memory_table(mem, dev) if mem.vt is not None else None for mem in self.mems]   # opt-in fused q-proj + attention
             # Deep clone: the prompt frames (row_offset of S rows) are never sampled, so in the LAST decoder layer their
             # rows are needed only as keys / values.  That layer's queries, projections and feed-forward run on the
             # s_out generated rows of each branch, gathered into a compact workspace (exact: every kernel is row-wise).
@@ -279,7 +291,7 @@ class NARSession:
                 self.x_l[:, so:].zero_()                                  # pad rows: finite, never read as keys
         xl = self.x_l.view(nb * so_r, D)
         residual_gemm(wl.att, lw.out_w, xl, lw.out_b, wl, None, st)
-        cross_attn_block(xl, lw, wl, mem, self.step_ptr, st)
+        cross_attn_block(xl, lw, wl, mem, self.step_ptr, st, plan=self.plan, layer=len(mdl.dec) - 1)
         ff_block(xl, lw, wl, lw.n3_w, lw.n3_b, st)
         ops.layernorm(xl, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf_l, stream=st)
 
@@ -290,6 +302,9 @@ class NARSession:
         hx = self.h.view(nb * Sr, D)
         layers = list(zip(mdl.dec, self.mems))
         self.ws.ln_tag, self.ws.ln_tag_step = 0, self.step_ptr      # fused LN launches: tag = f(step counter, call index)
+        for seg in self.plan:
+            if seg[0] == "absorbed":
+                seg[1].build(self.step_ptr, st)                     # A, c, B^T of all 16 layers for this step's memory block
         if self.ws0 is not None:
             ops.chunked_embed(self.h[:1], mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
                               rows=S, stream=st)
@@ -298,7 +313,7 @@ class NARSession:
             with torch.cuda.stream(self.stream):
                 self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
             nxt = (mdl.dec[1].n1_w, mdl.dec[1].n1_b) if len(mdl.dec) > 1 else None
-            normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b), xa=self.xa[0])
+            normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b), xa=self.xa[0], plan=self.plan, layer=0)
             normed = ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st, normed=normed, next_ln=nxt)
             layers = layers[1:]
             l0 = 1
@@ -313,7 +328,7 @@ class NARSession:
                 self._last_layer_compact(lw, mem, normed, st)
                 break
             nxt = (mdl.dec[l + 1].n1_w, mdl.dec[l + 1].n1_b) if l + 1 < len(mdl.dec) else None
-            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l])
+            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l], plan=self.plan, layer=l)
         so = self.s_out
         if compact:
             hf, hrow = self.hf_l, [b * self.ws_l.Sr for b in range(nb)]
@@ -418,6 +433,11 @@ class NARBatchSession:
         dev, dt = mdl.dev, mdl.dt
         D, FF, K, Q = s.dim, s.dim_ff, s.n_quant, s.n_codebooks
         assert len(items) >= 1
+        # utterances that take the same cross-attention path sit next to each other in the workspace (one batched launch
+        # pair per path); results go back in the caller's order
+        cls = lambda it: AbsorbedCross.lp_of(int(it["c_text"].shape[0]) + 1) if dt != torch.float32 else 0     # noqa: E731
+        self._order = sorted(range(len(items)), key=lambda i: cls(items[i]))
+        items = [items[i] for i in self._order]
         self.subs = []
         for it in items:
             sub = NARSession(mdl, self.cfg, self.stream, self.diff_tables)
@@ -446,7 +466,7 @@ class NARBatchSession:
             self.logits = torch.empty(self.R, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
-            self.xa = [cross_memory_table([sub.mems[l] for sub in self.subs], dev) for l in range(len(mdl.dec))]
+            self.plan = make_cross_plan(mdl.dec, [[sub.mems[l] for sub in self.subs] for l in range(len(mdl.dec))], D, dt, dev)
         self.graph = None
 
     def enqueue_forward(self, st: int) -> None:
@@ -457,8 +477,11 @@ class NARBatchSession:
             ops.chunked_embed(self.h[u * nb:(u + 1) * nb], mdl.res_tables, sub.x, None, mdl.pos_alpha, mdl.pe, add=t_dec,
                               add_index=self.step_ptr, rows=sub.S, stream=st)
         hx = self.h.view(-1, D)
+        for seg in self.plan:
+            if seg[0] == "absorbed":
+                seg[1].build(self.step_ptr, st)
         for l, lw in enumerate(mdl.dec):
-            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, xa=self.xa[l])
+            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l)
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         for u, sub in enumerate(self.subs):
             so = sub.s_out
@@ -486,8 +509,9 @@ class NARBatchSession:
         with torch.cuda.stream(self.stream):
             for u, sub in enumerate(self.subs):
                 shape = (1, sub.S, Q, s.n_quant)
-                u1 = uniforms[u](shape)
-                u2 = uniforms[u](shape) if t > 0 else u1
+                draw = uniforms[self._order[u]]                # uniforms are in the caller's order
+                u1 = draw(shape)
+                u2 = draw(shape) if t > 0 else u1
                 lc = self.logits[self.row0[u]:]
                 lu = self.logits[self.row0[u] + sub.s_out:] if self.nb == 2 else None
                 a = L.NarSampleArgs(logits_c=lc.data_ptr(), logits_u=lu.data_ptr() if lu is not None else None,
@@ -511,4 +535,7 @@ class NARBatchSession:
         self.stream.synchronize()
         LAST_STATS.update(loop_ms=ev0.elapsed_ms(ev1), steps=n, S=[sub.S for sub in self.subs], s_out=[sub.s_out for sub in self.subs],
                           Le=[sub.mems[0].Le for sub in self.subs], nb=self.nb, batch=len(self.subs), rows=self.ws.M)
-        return [sub.x for sub in self.subs]
+        out = [None] * len(self.subs)
+        for u, sub in enumerate(self.subs):
+            out[self._order[u]] = sub.x
+        return out

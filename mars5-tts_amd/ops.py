@@ -63,6 +63,22 @@ def gemm_q_cross_attn(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
     return True
 
 
+def xattn_absorb(dtype: torch.dtype, tab_seq: torch.Tensor, tab_layer: torch.Tensor, n_layers: int, n_seq: int, n_heads: int, D: int, Lp: int,
+                 step: torch.Tensor, scale: float, stream: Optional[int] = None) -> None:
+    """Build the absorbed cross-attention operands (A, c, B^T) of every (layer, sequence) for the memory block of step *step."""
+    assert tab_seq.dtype == torch.int64 and tab_layer.dtype == torch.int64 and tab_seq.is_contiguous() and tab_layer.is_contiguous()
+    check(lib.m5_xattn_absorb(DT_CODE[dtype], _p(tab_seq), _p(tab_layer), n_layers, n_seq, n_heads, D, Lp, _p(step), scale, _s(stream)),
+          "m5_xattn_absorb")
+
+
+def xattn_scores(x: torch.Tensor, sX: int, a_tab: torch.Tensor, c_tab: torch.Tensor, p_out: torch.Tensor, sP: int, M: int, n_heads: int,
+                 Lp: int, batch: int, stream: Optional[int] = None) -> None:
+    """p_out[b] = per-head softmax(x[b] a_tab[b]^T + c_tab[b]): x (rows, K) with batch stride sX rows*K elements given in elements."""
+    N, K = n_heads * Lp, x.shape[-1]
+    check(lib.m5_xattn_scores(DT_CODE[x.dtype], _p(x), x.stride(-2), sX, _p(a_tab), N * K, _p(c_tab), N, _p(p_out), p_out.stride(-2), sP,
+                              M, n_heads, Lp, K, batch, _s(stream)), "m5_xattn_scores")
+
+
 def gemm_residual_ln(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor,
                      beta: torch.Tensor, eps: float, xn: torch.Tensor, scratch: torch.Tensor, tag: int = 0,
                      tag_step: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> bool:

@@ -320,6 +320,65 @@ def test_gemm_q_cross_attention_fused(dev, dt):
     os.environ.pop("M5_GEMM_XATTN", None)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("les", [[39, 20], [57, 64], [48, 70, 39]])
+def test_absorbed_cross_attention_vs_reference_order(dev, dt, les):
+    """blocks.AbsorbedCross (m5_xattn_absorb + m5_xattn_scores + residual GEMM) against the reference's operation order
+    (q-projection, per-head softmax(q k^T / 8) v, out-projection + bias, residual add) in fp32 torch on the same 16-bit
+    operands: two layers, utterances with different memory lengths in one workspace (padded lengths 48 and 64, and a
+    memory of 70 rows that must take the plain path), two guidance branches each, the memory block of device step 1."""
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.blocks import CrossMemory, EncLayerW, SeqWorkspace, cross_attn_block, make_cross_plan
+    H, D, FF, S, T, step_i, Bm, NL = 4, 256, 768, 150, 3, 1, 2, 2
+    U = len(les)
+    ws = SeqWorkspace(U * Bm, S, D, FF, dt, dev, row_pad=64)
+    Sr = ws.Sr
+    layers, mems_per_layer, refs = [], [], []
+    x0 = _rand((U * Bm * Sr, D), 1, 2.0)
+    xn = _q(_rand((U * Bm * Sr, D), 2), dt)
+    for l in range(NL):
+        wq = _q(_rand((D, D), 10 + l, 3.0 / math.sqrt(D)), dt)
+        wo = _q(_rand((D, D), 20 + l, 3.0 / math.sqrt(D)), dt)
+        bq, bo = _rand((D,), 30 + l, 0.5), _rand((D,), 40 + l, 0.5)
+        lw = EncLayerW(in_w=None, in_b=None, out_w=None, out_b=None, act_w=None, l2_w=None, l2_b=None, n1_w=None, n1_b=None, n2_w=None, n2_b=None)
+        lw.ca_q_w, lw.ca_q_b = wq.to(dev, dt), bq.to(dev)
+        lw.ca_out_w, lw.ca_out_b = wo.to(dev, dt), bo.to(dev)
+        lw.ca_q_wT = lw.ca_q_w.view(H, 64, D).permute(0, 2, 1).contiguous()
+        layers.append(lw)
+        mems, ref = [], x0.clone()
+        q = _q(xn @ wq.T + bq, dt).view(U * Bm, Sr, H, 64)
+        for u, le in enumerate(les):
+            lep = (le + 63) // 64 * 64
+            k = _q(_rand((T * Bm, H, le, 64), 100 + 10 * l + u, 2.0), dt)
+            v = _q(_rand((T * Bm, H, le, 64), 200 + 10 * l + u), dt)
+            vt = torch.zeros(T * Bm, H, 64, lep)
+            vt[..., :le] = v.transpose(-1, -2)
+            mems.append(CrossMemory(k.to(dev, dt), vt.to(dev, dt), le, lep, Bm, v_rows=v.to(dev, dt)))
+            for b in range(Bm):
+                sq = u * Bm + b
+                sc = torch.einsum("shd,hnd->hsn", q[sq], k[step_i * Bm + b]) * 0.125
+                o = _q(torch.einsum("hsn,hnd->shd", torch.softmax(sc, -1), v[step_i * Bm + b]).reshape(Sr, D), dt)
+                ref[sq * Sr:(sq + 1) * Sr] += o @ wo.T + bo
+        mems_per_layer.append(mems)
+        refs.append(ref)
+    plan = make_cross_plan(layers, mems_per_layer, D, dt, dev)
+    kinds = [seg[0] for seg in plan]
+    assert kinds.count("plain") == sum(1 for le in les if le > 64) and "absorbed" in kinds
+    step = torch.tensor([step_i], dtype=torch.int32, device=dev)
+    for seg in plan:
+        if seg[0] == "absorbed":
+            seg[1].build(step)
+    ws.xn.copy_(xn.to(dev, dt))
+    for l in range(NL):
+        x = x0.clone().to(dev)
+        cross_attn_block(x, layers[l], ws, mems_per_layer[l], step, None, normed=True, plan=plan, layer=l)
+        torch.cuda.synchronize()
+        for sq in range(U * Bm):
+            got, want = x[sq * Sr: sq * Sr + S].cpu(), refs[l][sq * Sr: sq * Sr + S]
+            r = _rel(got - x0[sq * Sr: sq * Sr + S], want - x0[sq * Sr: sq * Sr + S])
+            assert r < (1e-2 if dt == torch.float16 else 5e-2), f"layer {l} sequence {sq} (Le {les[sq // Bm]}): rel err {r}"
+
+
 # ------------------------------------------------------------------------------ gathers / rope
 def test_gather_and_chunked(dev):
     from mars5_tts_amd import ops
