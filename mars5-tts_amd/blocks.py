@@ -200,8 +200,8 @@ class AbsorbedCross:
         self.H, self.D, self.dt, self.s0 = H, D, dt, s0
         self.n_seq = sum(mem.Bm for mem in mems_per_layer[0])
         self.n_layers = len(layers)
-        self.Lp = self.lp_of(mems_per_layer[0][0].Le)
-        assert all(self.lp_of(m.Le) == self.Lp for m in mems_per_layer[0])
+        self.Lp = self.lp_of(mems_per_layer[0][0].Le, H)
+        assert self.Lp and all(self.lp_of(m.Le, H) == self.Lp for m in mems_per_layer[0])
         N = H * self.Lp
         self.A = torch.zeros(self.n_layers, self.n_seq, N, D, dtype=dt, device=dev)
         self.c = torch.zeros(self.n_layers, self.n_seq, N, dtype=torch.float32, device=dev)
@@ -220,10 +220,16 @@ class AbsorbedCross:
         self.tab_layer = torch.tensor(lrows, dtype=torch.int64).to(dev)
 
     @staticmethod
-    def lp_of(Le: int) -> int:
-        """padded memory length of the absorbed path; 0 = not eligible (longer memories keep the unfused path: beyond
-        64 keys the absorbed operands are wider than the projections they replace)"""
-        return 48 if Le <= 48 else (64 if Le <= 64 else 0)
+    def lp_of(Le: int, H: int) -> int:
+        """padded memory length of the absorbed path for a model with H heads; 0 = not eligible (longer memories keep the
+        unfused path: beyond 64 keys the absorbed operands are wider than the projections they replace).  H * Lp is the K
+        of the P.B GEMM (whole 64-deep K-steps) and two heads share a workgroup tile of the scores GEMM."""
+        if H % 2:
+            return 0
+        for lp in (48, 64):
+            if Le <= lp and (H * lp) % 64 == 0:
+                return lp
+        return 0
 
     def build(self, step_ptr: torch.Tensor, stream=None) -> None:
         ops.xattn_absorb(self.dt, self.tab_seq, self.tab_layer, self.n_layers, self.n_seq, self.H, self.D, self.Lp, step_ptr, 64 ** -0.5,
@@ -233,6 +239,7 @@ class AbsorbedCross:
         """x[rows of my sequences] += cross-attention of ws.xn (= LN2(x)) against layer l's memory: two launches."""
         N = self.H * self.Lp
         r0, rows = self.s0 * ws.Sr, self.n_seq * ws.Sr
+        assert N <= ws.FF
         P = ws.hff.view(-1)[r0 * N: (r0 + rows) * N].view(rows, N)        # the feed-forward scratch is free here (N <= FF)
         ops.xattn_scores(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq, stream=stream)
         ops.gemm(P, self.Bt[l, 0], x[r0:], L.EPI_RESIDUAL, bias=lw.ca_out_b, M=ws.Sr, batch=self.n_seq, sA=ws.Sr * N, sW=self.D * N,
@@ -247,9 +254,11 @@ def make_cross_plan(layers, mems_per_layer, D: int, dt: torch.dtype, dev) -> lis
     mems0 = mems_per_layer[0]
     i = 0
     while i < len(mems0):
-        cls = AbsorbedCross.lp_of(mems0[i].Le) if (dt != torch.float32 and mems0[i].v_rows is not None) else 0
+        H = D // 64
+        cls_of = lambda m: AbsorbedCross.lp_of(m.Le, H) if (dt != torch.float32 and m.v_rows is not None) else 0     # noqa: E731
+        cls = cls_of(mems0[i])
         j = i
-        while j < len(mems0) and (AbsorbedCross.lp_of(mems0[j].Le) if (dt != torch.float32 and mems0[j].v_rows is not None) else 0) == cls:
+        while j < len(mems0) and cls_of(mems0[j]) == cls:
             j += 1
         n = sum(m.Bm for m in mems0[i:j])
         if cls:

@@ -889,10 +889,6 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
     if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
     p.nblk = (int)nblk;
     p.group_m = max(1, GROUP_M * 128 / BM);
-    if (const char* be = m5_tool_env("M5_GEMM_BAND")) {      // experiment: one band of tile rows per XCD (row-local producer/consumer L2 affinity)
-        const int rows = atoi(be);
-        if (rows > 0) p.group_m = max(1, rows / BM);
-    }
     const dim3 grid(p.nblk), blk(WM * WN * 64);
 #define M5_G16(E) hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC>), grid, blk, 0, s, p)
     switch (epi) {

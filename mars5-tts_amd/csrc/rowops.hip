@@ -46,16 +46,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                                             float eps, typename T::storage* y, int64_t ldy, int M,
-                                                            int n_affine, int64_t affine_stride, int64_t y_affine_stride, int band_rows) {
+                                                            int n_affine, int64_t affine_stride, int64_t y_affine_stride) {
     using st = typename T::storage;
     constexpr int D = 256 * NV;
-    const int lane = threadIdx.x & 63;
-    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (band_rows > 0) {       // experiment (tools): workgroup b (XCD b % 8) takes rows of band b % 8, like the GEMMs under M5_GEMM_BAND
-        const int in_band = (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
-        if (in_band >= band_rows) return;
-        row = (blockIdx.x & 7) * band_rows + in_band;
-    }
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (int64_t)row * ldx;
     float4 v[NV];
@@ -114,13 +108,7 @@ bool launch_ln_vec(const float* x, int64_t ldx, const float* gamma, const float*
         (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
         return false;
     dim3 grid((M + 3) / 4);
-    int band_rows = 0;
-    if (const char* be = m5_tool_env("M5_GEMM_BAND")) {
-        band_rows = atoi(be);
-        if (band_rows > 0 && band_rows % 4 == 0 && (int64_t)band_rows * 8 >= M) grid = dim3(8 * (band_rows / 4));
-        else band_rows = 0;
-    }
-#define M5_LNV(NV) hipLaunchKernelGGL((layernorm_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (st*)y, ldy, M, n_affine, affine_stride, y_affine_stride, band_rows)
+#define M5_LNV(NV) hipLaunchKernelGGL((layernorm_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (st*)y, ldy, M, n_affine, affine_stride, y_affine_stride)
     switch (D / 256) {
         case 1: M5_LNV(1); break;
         case 2: M5_LNV(2); break;

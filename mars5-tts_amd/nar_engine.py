@@ -213,7 +213,7 @@ class NARSession:
             Lep = round_up(Le, 64)
             self.mems: List[CrossMemory] = []
             # short memory: K and V as rows for the absorbed form (blocks.AbsorbedCross); M5_NAR_ABSORB=0: A/B knob (tools/nar_step_bench.py)
-            absorbed = dt != torch.float32 and AbsorbedCross.lp_of(Le) > 0 and os.environ.get("M5_NAR_ABSORB", "1") != "0"
+            absorbed = dt != torch.float32 and AbsorbedCross.lp_of(Le, H) > 0 and H * 64 <= FF and os.environ.get("M5_NAR_ABSORB", "1") != "0"
             for lw in mdl.dec:
                 k = torch.empty(T * nb, H, Le, 64, dtype=dt, device=dev)
                 if absorbed:
@@ -435,7 +435,7 @@ class NARBatchSession:
         assert len(items) >= 1
         # utterances that take the same cross-attention path sit next to each other in the workspace (one batched launch
         # pair per path); results go back in the caller's order
-        cls = lambda it: AbsorbedCross.lp_of(int(it["c_text"].shape[0]) + 1) if dt != torch.float32 else 0     # noqa: E731
+        cls = lambda it: AbsorbedCross.lp_of(int(it["c_text"].shape[0]) + 1, D // 64) if dt != torch.float32 else 0     # noqa: E731
         self._order = sorted(range(len(items)), key=lambda i: cls(items[i]))
         items = [items[i] for i in self._order]
         self.subs = []
