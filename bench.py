@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--n-gen", type=int, default=450)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default): BASELINE configs[1], one utterance per step.  c3: configs[2], one step = a batch of "
@@ -292,14 +293,17 @@ def run_utterance(m, ref_codes, cfg, seed):
 
 # ------------------------------------------------------------------------------------ roofline
 def roofline_leg(m, ref_codes, cfg, dtype_name):
-    """Per-kernel HIP-event timings on the engine's own stream, same shapes as the timed
-    region: an eager (un-captured) replay of NAR reverse steps with an event pair around every
-    GEMM / attention launch, plus the event-timed AR decode graph replays of the last utterance."""
+    """Per-kernel durations of one NAR reverse step IN the captured step graph: the forward of a session with the bench
+    shapes is captured with a HIP event node before and after every launch (each kernel class: GEMMs by epilogue and
+    shape, attention, LayerNorm, the absorbed cross-attention operand build, embedding) and replayed; the events give each
+    launch's duration under graph replay, i.e. as the timed region runs it (the event nodes themselves add a fraction of
+    a microsecond between launches).  If this HIP build refuses event nodes in a capture, the same spies time an eager
+    replay instead (`timing: "eager"`, ~3 us per launch pessimistic).  Plus the event-timed AR decode graph replays
+    of the last utterance."""
     from mars5_tts_amd import ar_engine, nar_engine, ops
     from mars5_tts_amd import _lib as L
     from mars5_tts_amd.nar_engine import NARConfig, NARSession
     eng = m.codecnar.engine()
-    dev = eng.dev
     ns = dict(nar_engine.LAST_STATS)
     ars = dict(ar_engine.LAST_STATS)
     S, s_out, Le = ns["S"], ns["s_out"], ns["Le"]
@@ -314,64 +318,110 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     mm[:off] = 1
     sess.prepare(c_text, ref_codes[0].T.contiguous(), x, z, mm, off, [199, 150, 100, 50])
     st = sess.stream.cuda_stream
+    es = 2 if dtype_name != "f32" else 4
     rec = []
-    orig_gemm, orig_attn = ops.gemm, ops.attention
+    names_epi = {L.EPI_F32: "F32", L.EPI_RESIDUAL: "RESIDUAL", L.EPI_SWIGLU: "SWIGLU", L.EPI_QKV: "QKV", L.EPI_DT: "DT", L.EPI_SILU_DT: "SILU"}
+    orig = {k: getattr(ops, k) for k in ("gemm", "attention", "layernorm", "xattn_scores", "xattn_absorb", "chunked_embed")}
 
-    def gemm_spy(a, w, out, epi, **kw):
-        e0, e1 = ops.Event(), ops.Event()
-        e0.record(st)
-        orig_gemm(a, w, out, epi, **kw)
-        e1.record(st)
-        Mv = kw.get("M") or a.shape[-2]
-        rec.append(("gemm", epi, 2.0 * Mv * w.shape[-2] * w.shape[-1] * kw.get("batch", 1), e0, e1, (Mv, w.shape[-2], w.shape[-1])))
+    def timed(fn, label, flops, hbm_bytes):
+        def w(*a, **kw):
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record(st)
+            fn(*a, **kw)
+            e1.record(st)
+            lab, fl, by = label(*a, **kw), flops(*a, **kw), hbm_bytes(*a, **kw)
+            rec.append((lab, fl, by, e0, e1))
+        return w
 
-    def attn_spy(dt, args, **kw):
-        e0, e1 = ops.Event(), ops.Event()
-        e0.record(st)
-        orig_attn(dt, args, **kw)
-        e1.record(st)
-        rec.append(("attn", args.Sk, 4.0 * args.B * args.H * args.Sq * args.Sk * 64, e0, e1, (args.Sq, args.Sk)))
+    def gemm_label(a, w_, out, epi, **kw):
+        Mv = (kw.get("M") or a.shape[-2]) * kw.get("batch", 1)
+        return f"gemm16_kernel<EPI_{names_epi.get(epi, epi)}> M={Mv} N={w_.shape[-2]} K={w_.shape[-1]}"
 
-    ops.gemm, ops.attention = gemm_spy, attn_spy
+    def gemm_flops(a, w_, out, epi, **kw):
+        return 2.0 * (kw.get("M") or a.shape[-2]) * kw.get("batch", 1) * w_.shape[-2] * w_.shape[-1]
+
+    def gemm_bytes(a, w_, out, epi, **kw):
+        Mv = (kw.get("M") or a.shape[-2]) * kw.get("batch", 1)
+        N, K = w_.shape[-2], w_.shape[-1]
+        c = Mv * N * (8 if epi == L.EPI_RESIDUAL else (4 if epi == L.EPI_F32 else es)) // (2 if epi == L.EPI_SWIGLU else 1)
+        return float(Mv * K * es + N * K * es * kw.get("batch", 1) + c)
+
+    ops.gemm = timed(orig["gemm"], gemm_label, gemm_flops, gemm_bytes)
+    ops.attention = timed(orig["attention"], lambda dt, a_, **kw: f"attn16_kernel Sq={a_.Sq} Sk={a_.Sk}",
+                          lambda dt, a_, **kw: 4.0 * a_.B * a_.H * a_.Sq * a_.Sk * 64,
+                          lambda dt, a_, **kw: float(a_.B * a_.H * (2 * a_.Sq + 2 * a_.Sk) * 64 * es))
+    ops.layernorm = timed(orig["layernorm"], lambda x_, g_, b_, eps, out, **kw: f"layernorm_vec_kernel D={x_.shape[-1]} affine={kw.get('n_affine', 1)}",
+                          lambda *a, **kw: 0.0,
+                          lambda x_, g_, b_, eps, out, **kw: float((kw.get("M") or x_.shape[0]) * x_.shape[-1] * (4 + out.element_size() * kw.get("n_affine", 1))))
+    ops.xattn_scores = timed(orig["xattn_scores"], lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, **kw: f"gemm16_kernel<EPI_SOFTMAX_HEADS> M={M * batch} N={H * Lp} K={x_.shape[-1]}",
+                             lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, **kw: 2.0 * M * batch * H * Lp * x_.shape[-1],
+                             lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, **kw: float(M * batch * (x_.shape[-1] + H * Lp) * es + batch * H * Lp * x_.shape[-1] * es))
+    ops.xattn_absorb = timed(orig["xattn_absorb"], lambda dt, ts, tl, nl, nsq, H, D, Lp, step, scale, **kw: f"absorb_kernel layers={nl} seq={nsq} Lp={Lp}",
+                             lambda dt, ts, tl, nl, nsq, H, D, Lp, step, scale, **kw: 2.0 * 2 * nl * nsq * H * Lp * D * 64,
+                             lambda dt, ts, tl, nl, nsq, H, D, Lp, step, scale, **kw: float(nl * (2 * D * D * es + nsq * 2 * H * Lp * D * es)))
+    ops.chunked_embed = timed(orig["chunked_embed"], lambda out, *a, **kw: "chunked_embed_kernel", lambda *a, **kw: 0.0,
+                              lambda out, *a, **kw: float(out.numel() * 4 * 2))
+    timing = "graph"
     try:
-        for _ in range(3):
+        try:
+            sess.stream.synchronize()
+            ops.Graph.begin(st)
             sess.enqueue_forward(st)
-            ops.add_int(sess.step_ptr, 1, stream=st)
-        sess.stream.synchronize()
+            gr = ops.Graph().end(st)
+            for _ in range(3):
+                gr.launch(st)
+                ops.add_int(sess.step_ptr, 1, stream=st)
+            sess.stream.synchronize()
+            per = [(lab, fl, by, e0.elapsed_ms(e1)) for lab, fl, by, e0, e1 in rec]
+            if not per or min(t for *_, t in per) < 0 or sum(t for *_, t in per) <= 0:
+                raise RuntimeError("event nodes gave no usable timings")
+        except Exception:
+            timing = "eager"
+            rec.clear()
+            sess.step_ptr.zero_()
+            for _ in range(3):
+                sess.enqueue_forward(st)
+                ops.add_int(sess.step_ptr, 1, stream=st)
+            sess.stream.synchronize()
+            per = [(lab, fl, by, e0.elapsed_ms(e1)) for lab, fl, by, e0, e1 in rec]
     finally:
-        ops.gemm, ops.attention = orig_gemm, orig_attn
-    names = {L.EPI_F32: "gemm16_kernel<EPI_F32> (7 heads, batched)", L.EPI_RESIDUAL: "gemm16_kernel<EPI_RESIDUAL> (out_proj / cross out_proj / linear2)",
-             L.EPI_SWIGLU: "gemm16_kernel<EPI_SWIGLU>", L.EPI_QKV: "gemm16_kernel<EPI_QKV> (self qkv / cross q)"}
+        for k, v in orig.items():
+            setattr(ops, k, v)
+    n_rep = 1 if timing == "graph" else 3          # the captured events hold the LAST replay; the eager list holds all three
     agg = {}
-    for kind, key, flops, e0, e1, shp in rec:
-        nm = names.get(key, f"gemm epi {key}") if kind == "gemm" else ("attn16_kernel self" if key > 64 * 4 else "attn16_kernel cross")
-        a = agg.setdefault(nm, dict(ms=0.0, flops=0.0, n=0, shape=shp))
-        a["ms"] += e0.elapsed_ms(e1)
-        a["flops"] += flops
+    for lab, fl, by, ms in per:
+        a = agg.setdefault(lab, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+        a["ms"] += ms
+        a["flops"] += fl
+        a["bytes"] += by
         a["n"] += 1
-    kernels = {k: dict(launches=v["n"], avg_us=round(1e3 * v["ms"] / v["n"], 2), tflops=round(v["flops"] / v["ms"] / 1e9, 1),
-                       example_shape=list(v["shape"])) for k, v in agg.items()}
+    kernels = {k: dict(launches_per_step=v["n"] // n_rep, avg_us=round(1e3 * v["ms"] / v["n"], 2), tflops=round(v["flops"] / v["ms"] / 1e9, 1),
+                       alg_gbs=round(v["bytes"] / v["ms"] / 1e6, 1), step_share_us=round(1e3 * v["ms"] / n_rep, 1)) for k, v in agg.items()}
     peak = PEAK_MFMA_TFLOPS[dtype_name]
     dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
-    achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
+    mfma_bound = dom[1]["flops"] > 0
     traffic = None
     try:        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json), same shapes
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        key = {"RESIDUAL": "gemm16 residual (out_proj / cross out_proj / linear2 mean)", "SWIGLU": "gemm16 swiglu 2816x6144x1024",
-               "QKV": "gemm16 qkv 2816x3072x1024", "attn16_kernel self": "attn16 self B2 H16 S1349"}
-        for k, v in key.items():
-            if k in dom[0] and dtype_name == "bf16" and S == 1349:
-                traffic = tj[v]["bytes_per_launch"]
+        for k, v in tj.items():
+            if isinstance(v, dict) and v.get("label") == dom[0] and dtype_name == "bf16":
+                traffic = v["bytes_per_launch"]
     except Exception:
         traffic = None
-    roof = dict(bound="mfma", kernel=dom[0], achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
-                traffic=traffic, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_timed=dom[1]["n"])
+    if mfma_bound:
+        achieved = dom[1]["flops"] / dom[1]["ms"] / 1e9
+        roof = dict(bound="mfma", kernel=dom[0], achieved=round(achieved, 1), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4))
+    else:
+        achieved = dom[1]["bytes"] / dom[1]["ms"] / 1e6
+        roof = dict(bound="hbm", kernel=dom[0], achieved=round(achieved, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(achieved / PEAK_HBM_GBS, 4))
+    roof.update(traffic=traffic, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_per_step=dom[1]["n"] // n_rep, timing=timing,
+                alg_per_launch=(dom[1]["flops"] if mfma_bound else dom[1]["bytes"]) / dom[1]["n"])
     # NAR loop as a whole (graph replay + RNG + sample kernel), from the last timed utterance
     step_ms = ns["loop_ms"] / ns["steps"]
-    nar = dict(ms_per_step=round(step_ms, 3), tflops=round(eng.flops_per_step(S, Le, s_out) / step_ms / 1e9, 1), S=S, Le=Le)
+    nar = dict(ms_per_step=round(step_ms, 3), tflops=round(eng.flops_per_step(S, Le, s_out) / step_ms / 1e9, 1), S=S, Le=Le,
+               frac_of_mfma_peak=round(eng.flops_per_step(S, Le, s_out) / step_ms / 1e9 / peak, 4))
     # AR decode: algorithmic bytes per token (weights once + KV read/write) / event-timed step
     ae = m.codeclm.engine()
-    es = 2 if dtype_name != "f32" else 4
     kv_per_pos = ae.shape.n_layers * ae.shape.nhead * 64 * 2 * es
     W = ae.shape.sliding_window                 # cached positions actually read per step: min(length, window)
     lens = range(int(ars["prefill_len"]), int(ars["final_len"]) + 1)
@@ -382,6 +432,97 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     ar = dict(bound="hbm", kernel="AR decode step (132 launches: 26 x {gemv qkv+rope, attn_decode, gemv wo, gemv w13+swiglu, gemv w2} + head + sampler, hipGraph)", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
               frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_token=int(bytes_tok), us_per_token=round(1e3 * tok_ms, 1))
     return roof, ar, nar, kernels
+
+
+# ------------------------------------------------------------------------------------ parity of the timed configuration
+def parity_leg(m, bundle, ref_codes, dtype_name, n_ar=48):
+    """The oracle as CHECKER of the configuration that was just timed (never inside the timed region): the engine's
+    greedy AR tokens for the bench prompt, teacher-forced through the oracle on the GPU (reference autocast rounding in
+    the bench dtype), and one NAR decoder pass + reverse step at the bench shape against the fp32 oracle.  The full
+    450-step / both-dtype version with asserted tolerances is tests/test_gpu_parity16.py."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mars5_oracle as O
+    from mars5_tts_amd import _lib as L
+    from mars5_tts_amd.ar_engine import ARSamplingConfig, ARSession
+    from mars5_tts_amd.nar_engine import NARConfig, NARSession
+    from mars5_tts_amd.ops import DT_NAME
+    dt = DT_NAME[dtype_name]
+    odt = None if dtype_name == "f32" else dt
+    dev = m.device
+    eng = m.codeclm.engine()
+    a, n = bundle.ar_shape, bundle.nar_shape
+    tt = m.texttok.encode("<|startoftext|>" + TRANSCRIPT + ' ' + TEXT.strip() + "<|endoftext|>", allowed_special='all')
+    sp = m.speechtok.encode(' '.join(str(t) for t in ref_codes[0, 0].tolist()))
+    n_text = len(m.texttok.vocab)
+    prompt = torch.tensor(tt + [s_ + n_text for s_ in sp], dtype=torch.long)
+    ref = ref_codes[0].T.contiguous()
+    P, V = int(prompt.shape[0]), a.n_vocab
+    eos_sp = m.speechtok.special_tokens["<|endofspeech|>"]
+    kw = dict(temperature=0.7, topk=1, top_p=0.2, alpha_frequency=3.0, alpha_presence=0.4, penalty_window=100, eos_penalty_factor=50.0,
+              eos_penalty_decay=0.5, n_phones_gen=100 * len(TEXT))
+    se = ARSession(eng, P + n_ar)
+    se.configure_sampler(ARSamplingConfig(**kw), n_text, n_text + eos_sp, torch.ones(n_ar, V, device=dev))
+    se.prefill(prompt, ref)
+    sv = se.stream.cuda_stream
+    logits = []
+    for i in range(n_ar):
+        if i:
+            se.enqueue_layers(sv)
+        se.enqueue_head_and_sample(sv)
+        se.stream.synchronize()
+        logits.append(se.logits.clone())
+    toks = se.tokens[: int(se.state.cpu()[L.ST_NTOK])].clone()
+    n_gen = int(toks.shape[0]) - P
+    out = {"dtype": dtype_name, "oracle_device": str(dev)}
+    with torch.device(dev), torch.inference_mode():
+        sd = {k: v.to(dev) for k, v in bundle.ar_ckpt["model"].items()}
+        if odt is not None:
+            sd = O.round_linear_weights(sd, odt)
+        p = O.ARSamplingParams(temperature=0.7, top_k=1, top_p=0.2, alpha_frequency=3.0, alpha_presence=0.4, penalty_window=100,
+                               eos_penalty_factor=50.0, eos_penalty_decay=0.5, n_phones_gen=100 * len(TEXT))
+        _, lo, choices = O.ar_generate_oracle(sd, a.nhead, n_text, bundle.n_speech, eos_sp, prompt.to(dev), ref.to(dev), P + n_ar, p,
+                                              noise=torch.ones(n_ar, V), forced=toks, dt=odt)
+        err = [float((logits[i] - lo[i]).abs().max()) for i in range(n_gen)]
+        flips = [i for i in range(n_gen) if choices[i] != int(toks[P + i])]
+        out.update(ar_steps=n_gen, ar_max_abs_dlogit=round(max(err), 5), ar_max_abs_logit=round(max(float(l.abs().max()) for l in lo), 2),
+                   ar_greedy_agreement=round((n_gen - len(flips)) / n_gen, 4), ar_first_divergence=flips[0] if flips else None)
+        del sd, lo
+        # ---- NAR: one decoder pass and one reverse step at the bench shape
+        nengine = m.codecnar.engine()
+        g = torch.Generator().manual_seed(3)
+        S, off, t = 2 * ref.shape[0] - 1 + 450, 2 * ref.shape[0] - 1, 100
+        K = n.n_quant
+        c_text = torch.tensor(tt, dtype=torch.long)
+        x = torch.randint(0, 1024, (S, 8), generator=g, device="cpu")
+        x_known = torch.zeros(S, 8, dtype=torch.long, device="cpu")
+        mk = torch.zeros(S, 8, dtype=torch.uint8, device="cpu")
+        mk[:, 0] = 1
+        mk[:off] = 1
+        x_known[:off] = x[:off]
+        x_known[:, 0] = x[:, 0]
+        gg = torch.Generator(device=dev).manual_seed(11)
+        u1 = torch.rand((1, S, 8, K), generator=gg, device=dev)
+        u2 = torch.rand((1, S, 8, K), generator=gg, device=dev)
+        draws = iter([u1, u2])
+        sess = NARSession(nengine, NARConfig(T=200, x_0_temp=0.7, guidance_w=3.0, deep_clone=True, q0_override_steps=20))
+        sess.prepare(c_text, ref, x, x_known, mk, off, [t])
+        sess.step(lambda shp: next(draws), use_graph=True)
+        sess.stream.synchronize()
+        so = S - off
+        lg = sess.logits[:, :, :K]
+        sdn = {k: v.to(dev) for k, v in bundle.nar_ckpt["model"].items()}
+        if odt is not None:
+            sdn = O.round_linear_weights(sdn, odt)
+        lc = O.nar_forward(sdn, n.nhead, c_text.to(dev), ref.to(dev), x.to(dev), t, False)
+        lu = O.nar_forward(sdn, n.nhead, c_text.to(dev), ref.to(dev), x.to(dev), t, True)
+        zmax = float(torch.maximum(lc.abs().max(), lu.abs().max()))
+        e_rel = max(float((lg[:so] - lc[off:, 1:]).abs().max()), float((lg[so:] - lu[off:, 1:]).abs().max())) / zmax
+        refx = O.reverse_step(O.diffusion_tables(K, 200), lc, lu, x.to(dev), x_known.to(dev), mk.to(dev).bool(), t, u1[0], u2[0], 3.0, 0.7)
+        refx[:, 0] = x_known[:, 0].to(dev)
+        out.update(nar_S=S, nar_max_rel_dlogit=round(e_rel, 5), nar_max_abs_logit=round(zmax, 2),
+                   nar_id_agreement=round(float((sess.x[off:, 1:] == refx[off:, 1:]).float().mean()), 4),
+                   nar_known_ids_equal=bool((sess.x[:off] == refx[:off]).all()))
+    return out
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
@@ -408,7 +549,7 @@ def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=40.0):
         O.codeclm_step(sd_ar, prompt, ref, st, 1, nh, recompute_spk=True)
         t_prefill = time.perf_counter() - t0
         toks, n_tok, t_acc = prompt, 0, 0.0
-        while n_tok < 6 and (time.perf_counter() - t_start) < budget_s * 0.5:
+        while n_tok < 32 and (time.perf_counter() - t_start) < budget_s * 0.6:
             toks = torch.cat([toks, torch.tensor([n_text + 5 + n_tok])])
             t0 = time.perf_counter()
             O.codeclm_step(sd_ar, toks, ref, st, 2 + n_tok, nh, recompute_spk=True)
@@ -417,15 +558,32 @@ def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=40.0):
         t_tok = t_acc / max(n_tok, 1)
         S = ref.shape[0] + ref.shape[0] - 1 + n_gen
         x = torch.randint(0, 1025, (S, 8), generator=torch.Generator().manual_seed(0))
-        t0 = time.perf_counter()
-        O.nar_forward(sd_nar, bundle.nar_shape.nhead, torch.tensor(tt), ref, x, 100, False)
-        t_step = 2.0 * (time.perf_counter() - t0)
+        n_fwd, t_fwd = 0, 0.0
+        while n_fwd < 3 and (n_fwd == 0 or (time.perf_counter() - t_start) < budget_s):
+            t0 = time.perf_counter()
+            O.nar_forward(sd_nar, bundle.nar_shape.nhead, torch.tensor(tt), ref, x, 100 + n_fwd, n_fwd % 2 == 1)     # cond / uncond alternate
+            t_fwd += time.perf_counter() - t0
+            n_fwd += 1
+        t_step = 2.0 * t_fwd / n_fwd
     total = t_prefill + n_gen * t_tok + 200 * t_step
     audio_s = (n_gen - 1) / 75.0
-    return dict(value=round(audio_s / total, 5), unit="audio_s/s", cores=cores, kind="port",
+    cpu_name = "unknown"
+    try:
+        cpu_name = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+    except Exception:
+        pass
+    ratio = None
+    try:        # one-off same-host timing of the UNMODIFIED reference functions vs this port (oracle/time_ref_vs_port.py, build container)
+        rj = json.load(open(os.path.join(ROOT, "profiles", "r2_ref_vs_port_cpu.json")))
+        ratio = round(rj["port_extrapolated_s_per_utterance"] / rj["reference_extrapolated_s_per_utterance"], 3)
+    except Exception:
+        pass
+    return dict(value=round(audio_s / total, 5), unit="audio_s/s", cores=cores, kind="port", host_cpu=cpu_name, host_logical_cpus=os.cpu_count(),
+                port_over_reference_time=ratio,
                 sample=(f"oracle/mars5_oracle.py (torch-CPU fp32 port of the reference path with the reference's cost model) on this host, "
                         f"{cores} threads: AR prefill P={prompt.shape[0]} {t_prefill:.2f}s + {n_tok} decode tokens at {t_tok:.3f}s/token, "
-                        f"one NAR forward at S={S} x2 (CFG) = {t_step:.2f}s/step; extrapolated to {n_gen} tokens + 200 steps = {total:.0f}s/utterance"))
+                        f"{n_fwd} NAR forwards at S={S} -> x2 (CFG) = {t_step:.2f}s/step; extrapolated to {n_gen} tokens + 200 steps = {total:.0f}s/utterance; "
+                        f"port/reference time ratio measured once on the build host: {ratio} (profiles/r2_ref_vs_port_cpu.json)"))
 
 
 def main():
@@ -544,6 +702,8 @@ def main():
         out["nar_loop"] = nar
         out["kernels"] = kernels
         out["time_split_ms"] = {"ar_decode": round(ar_engine.LAST_STATS["decode_ms"], 1), "nar_loop": round(nar["ms_per_step"] * 200, 1)}
+    if world == 1 and not args.no_parity and args.workload == "c2":
+        out["parity"] = parity_leg(m, bundle, ref_codes, args.dtype)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_leg(m, bundle, ref_codes, cfg, args.n_gen)
     print(json.dumps(out), flush=True)

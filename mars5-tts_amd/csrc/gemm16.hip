@@ -1012,19 +1012,27 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
     p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     p.vec16 = 1; p.vec_c = 1;
     const int BN = 2 * Lp;
-    p.tilesM = (M + 95) / 96; p.tilesN = p.N / BN;
+    // tile shape: 96 x 2Lp with 4 waves and 4 stages (one workgroup per CU), or -- tools build, M5_XATTN_CFG=1 / 2 -- 64 x 2Lp /
+    // 128 x 2Lp with 8 waves, 2 stages and two workgroups per CU
+    int cfg = 0;
+    if (const char* ce = m5_tool_env("M5_XATTN_CFG")) cfg = atoi(ce);
+    const int BM = cfg == 1 ? 64 : (cfg == 2 ? 128 : 96);
+    p.tilesM = (M + BM - 1) / BM; p.tilesN = p.N / BN;
     const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
     if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
-    p.nblk = (int)nblk; p.group_m = max(1, GROUP_M * 128 / 96);
-    const dim3 grid(p.nblk), blk(256);
+    p.nblk = (int)nblk; p.group_m = max(1, GROUP_M * 128 / BM);
+    const dim3 grid(p.nblk);
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == M5_F16) {
-        if (Lp == 48) hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 3, 128, 4, 1>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((gemm16_kernel<F16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, s, p);
-    } else {
-        if (Lp == 48) hipLaunchKernelGGL((gemm16_kernel<BF16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 3, 128, 4, 1>), grid, blk, 0, s, p);
-        else hipLaunchKernelGGL((gemm16_kernel<BF16T, EPI_SOFTMAX_HEADS, 2, 2, 3, 4, 128, 4, 1>), grid, blk, 0, s, p);
-    }
+#define M5_XS(TT, WMv, TMv, TNv, NSv, OCv) hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv>), grid, dim3(WMv * 128), 0, s, p)
+#ifdef M5_TOOLS
+#define M5_XS_CFG(TT, TNv) do { if (cfg == 1) M5_XS(TT, 4, 1, TNv, 2, 2); else if (cfg == 2) M5_XS(TT, 4, 2, TNv, 2, 2); else M5_XS(TT, 2, 3, TNv, 4, 1); } while (0)
+#else
+#define M5_XS_CFG(TT, TNv) M5_XS(TT, 2, 3, TNv, 4, 1)
+#endif
+    if (dtype == M5_F16) { if (Lp == 48) M5_XS_CFG(F16T, 3); else M5_XS_CFG(F16T, 4); }
+    else { if (Lp == 48) M5_XS_CFG(BF16T, 3); else M5_XS_CFG(BF16T, 4); }
+#undef M5_XS_CFG
+#undef M5_XS
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

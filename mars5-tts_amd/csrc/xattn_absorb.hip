@@ -61,20 +61,28 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
         // A[h Lp + j][n] = scale * sum_d K[j][d] WqT[h][n][d]      (WqT: [H][D][64], d contiguous)
         const st* wq = reinterpret_cast<const st*>(tl[0]) + (int64_t)h * D * 64;
         st* A = reinterpret_cast<st*>(ts[4]) + (int64_t)h * Lp * D;
-        for (int nt = 0; nt < nq / 16; ++nt) {
-            const int n0 = wave * nq + nt * 16;
-            uint4 wf[2];
+        // 4 column tiles per trip: their 8 weight fragments are requested before the first MFMA (the loop is latency-bound)
+        for (int nt0 = 0; nt0 < nq / 16; nt0 += 4) {
+            uint4 wf[4][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(wq + (int64_t)(n0 + l15) * 64 + (ks * 4 + lg) * 8);
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                f4a_t acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mfma_a<T>(wf[0], mf[jt][0], acc);      // acc[r] = C[j = 16 jt + l15][n = n0 + 4 lg + r]
-                acc = mfma_a<T>(wf[1], mf[jt][1], acc);
-                st o[4];
+                for (int ks = 0; ks < 2; ++ks)
+                    wf[u][ks] = *reinterpret_cast<const uint4*>(wq + (int64_t)(wave * nq + min(nt0 + u, nq / 16 - 1) * 16 + l15) * 64 + (ks * 4 + lg) * 8);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r] * scale);
-                *reinterpret_cast<uint2*>(A + (int64_t)(jt * 16 + l15) * D + n0 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+            for (int u = 0; u < 4; ++u) {
+                if (nt0 + u >= nq / 16) break;
+                const int n0 = wave * nq + (nt0 + u) * 16;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    f4a_t acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = mfma_a<T>(wf[u][0], mf[jt][0], acc);      // acc[r] = C[j = 16 jt + l15][n = n0 + 4 lg + r]
+                    acc = mfma_a<T>(wf[u][1], mf[jt][1], acc);
+                    st o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r] * scale);
+                    *reinterpret_cast<uint2*>(A + (int64_t)(jt * 16 + l15) * D + n0 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+                }
             }
         }
         // c[h Lp + j] = scale * K[j] . bq[h 64 ..]  (fp32);  padded keys: -1e30 (their softmax weight is exactly 0)
@@ -94,20 +102,27 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
         const st* wo = reinterpret_cast<const st*>(tl[1]) + h * 64;
         st* Bt = reinterpret_cast<st*>(ts[6]) + h * Lp;
         const int ldb = H * Lp;
-        for (int nt = 0; nt < nq / 16; ++nt) {
-            const int n0 = wave * nq + nt * 16;
-            uint4 wf[2];
+        for (int nt0 = 0; nt0 < nq / 16; nt0 += 4) {
+            uint4 wf[4][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) wf[ks] = *reinterpret_cast<const uint4*>(wo + (int64_t)(n0 + l15) * D + (ks * 4 + lg) * 8);
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                f4a_t acc = {0.f, 0.f, 0.f, 0.f};
-                acc = mfma_a<T>(mf[jt][0], wf[0], acc);      // acc[r] = C[n = n0 + l15][j = 16 jt + 4 lg + r]
-                acc = mfma_a<T>(mf[jt][1], wf[1], acc);
-                st o[4];
+                for (int ks = 0; ks < 2; ++ks)
+                    wf[u][ks] = *reinterpret_cast<const uint4*>(wo + (int64_t)(wave * nq + min(nt0 + u, nq / 16 - 1) * 16 + l15) * D + (ks * 4 + lg) * 8);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r]);
-                *reinterpret_cast<uint2*>(Bt + (int64_t)(n0 + l15) * ldb + jt * 16 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+            for (int u = 0; u < 4; ++u) {
+                if (nt0 + u >= nq / 16) break;
+                const int n0 = wave * nq + (nt0 + u) * 16;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    f4a_t acc = {0.f, 0.f, 0.f, 0.f};
+                    acc = mfma_a<T>(mf[jt][0], wf[u][0], acc);      // acc[r] = C[n = n0 + l15][j = 16 jt + 4 lg + r]
+                    acc = mfma_a<T>(mf[jt][1], wf[u][1], acc);
+                    st o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r]);
+                    *reinterpret_cast<uint2*>(Bt + (int64_t)(n0 + l15) * ldb + jt * 16 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+                }
             }
         }
     }

@@ -9,7 +9,8 @@ for s in "$@"; do
     test) timeout 1500 python -m pytest tests -m gpu -x -q -s --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" $OUT/pytest.log | tail -3 ;;
     parity) timeout 1200 python -m pytest tests/test_gpu_parity16.py -m gpu -q -s --durations=10 > $OUT/parity.log 2>&1; echo "parity rc=$?"; grep -E "^AR |^NAR |^nar_sample|passed|failed|Error|assert" $OUT/parity.log | tail -30 ;;
     arpf) timeout 600 python tools/ar_step_bench.py ${ARPF:-"M5_AR_PREFETCH=0" "M5_AR_PREFETCH=2,M5_AR_PREFETCH_WGS=256" "M5_AR_PREFETCH=1,M5_AR_PREFETCH_WGS=256" "M5_AR_PREFETCH=2,M5_AR_PREFETCH_WGS=512" "M5_AR_PREFETCH=1,M5_AR_PREFETCH_WGS=512"} > $OUT/arpf.log 2>&1; echo "arpf rc=$?"; grep round $OUT/arpf.log ;;
-    narab) timeout 600 python tools/nar_step_bench.py ${NARAB:-"M5_NAR_ABSORB=0" "M5_NAR_ABSORB=1"} > $OUT/narab.log 2>&1; echo "narab rc=$?"; grep round $OUT/narab.log ;;
+    narab) timeout 600 python tools/nar_step_bench.py ${NARAB:-"M5_NAR_ABSORB=0" "M5_NAR_ABSORB=1" "M5_NAR_ABSORB=1,M5_XATTN_CFG=1" "M5_NAR_ABSORB=1,M5_XATTN_CFG=2"} > $OUT/narab.log 2>&1; echo "narab rc=$?"; grep round $OUT/narab.log ;;
+    attn) bash tools/attn_ablate.sh > $OUT/attn_ablate.log 2>&1; echo "attn rc=$?"; grep -E "^==|nar self|nar cross" $OUT/attn_ablate.log ;;
     c4) timeout 600 python bench.py --workload c4 --batch ${C4B:-4} --steps 1 --warmup 1 > $OUT/c4.json 2> $OUT/c4.err; echo "c4 rc=$?"; cat $OUT/c4.json; tail -2 $OUT/c4.err ;;
     bench) timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -2 $OUT/bench.err ;;
     benchq) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "bench rc=$?"; cat $OUT/benchq.json; tail -2 $OUT/benchq.err ;;
