@@ -293,13 +293,11 @@ def run_utterance(m, ref_codes, cfg, seed):
 
 # ------------------------------------------------------------------------------------ roofline
 def roofline_leg(m, ref_codes, cfg, dtype_name):
-    """Per-kernel durations of one NAR reverse step IN the captured step graph: the forward of a session with the bench
-    shapes is captured with a HIP event node before and after every launch (each kernel class: GEMMs by epilogue and
-    shape, attention, LayerNorm, the absorbed cross-attention operand build, embedding) and replayed; the events give each
-    launch's duration under graph replay, i.e. as the timed region runs it (the event nodes themselves add a fraction of
-    a microsecond between launches).  If this HIP build refuses event nodes in a capture, the same spies time an eager
-    replay instead (`timing: "eager"`, ~3 us per launch pessimistic).  Plus the event-timed AR decode graph replays
-    of the last utterance."""
+    """Per-kernel durations of the NAR reverse step at the bench shapes: the forward of a fresh session is replayed eagerly
+    with a HIP event pair around every launch of every kernel class (GEMMs by epilogue and shape, attention, LayerNorm, the
+    absorbed cross-attention operand build, embedding) on the engine's own stream; the dominant class by total time is
+    reported against its roofline (profiles/ holds the rocprofv3 summary of the same command for cross-checking).  Plus the
+    event-timed AR decode graph replays of the last utterance."""
     from mars5_tts_amd import ar_engine, nar_engine, ops
     from mars5_tts_amd import _lib as L
     from mars5_tts_amd.nar_engine import NARConfig, NARSession
@@ -361,33 +359,29 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
                              lambda dt, ts, tl, nl, nsq, H, D, Lp, step, scale, **kw: float(nl * (2 * D * D * es + nsq * 2 * H * Lp * D * es)))
     ops.chunked_embed = timed(orig["chunked_embed"], lambda out, *a, **kw: "chunked_embed_kernel", lambda *a, **kw: 0.0,
                               lambda out, *a, **kw: float(out.numel() * 4 * 2))
-    timing = "graph"
+    # Eager replay of three steps, an event pair around every launch.  (Event nodes INSIDE the captured step graph would give
+    # replay-context timings, but this HIP build cannot query events recorded during capture: hipEventSynchronize fails with
+    # invalid handle, measured in round 2.)  A pair brackets the launch plus the two packet hand-overs around it; that
+    # overhead is measured with pairs around nothing and subtracted.
     try:
-        try:
-            sess.stream.synchronize()
-            ops.Graph.begin(st)
+        cal = []
+        for _ in range(64):
+            e0, e1 = ops.Event(), ops.Event()
+            e0.record(st)
+            e1.record(st)
+            cal.append((e0, e1))
+        sess.stream.synchronize()
+        pair_overhead_ms = sorted(e0.elapsed_ms(e1) for e0, e1 in cal)[len(cal) // 2]
+        for _ in range(3):
             sess.enqueue_forward(st)
-            gr = ops.Graph().end(st)
-            for _ in range(3):
-                gr.launch(st)
-                ops.add_int(sess.step_ptr, 1, stream=st)
-            sess.stream.synchronize()
-            per = [(lab, fl, by, e0.elapsed_ms(e1)) for lab, fl, by, e0, e1 in rec]
-            if not per or min(t for *_, t in per) < 0 or sum(t for *_, t in per) <= 0:
-                raise RuntimeError("event nodes gave no usable timings")
-        except Exception:
-            timing = "eager"
-            rec.clear()
-            sess.step_ptr.zero_()
-            for _ in range(3):
-                sess.enqueue_forward(st)
-                ops.add_int(sess.step_ptr, 1, stream=st)
-            sess.stream.synchronize()
-            per = [(lab, fl, by, e0.elapsed_ms(e1)) for lab, fl, by, e0, e1 in rec]
+            ops.add_int(sess.step_ptr, 1, stream=st)
+        sess.stream.synchronize()
+        per = [(lab, fl, by, max(e0.elapsed_ms(e1) - pair_overhead_ms, 1e-4)) for lab, fl, by, e0, e1 in rec]
     finally:
         for k, v in orig.items():
             setattr(ops, k, v)
-    n_rep = 1 if timing == "graph" else 3          # the captured events hold the LAST replay; the eager list holds all three
+    timing = f"eager replay, HIP-event pair per launch minus the empty-pair overhead ({1e3 * pair_overhead_ms:.2f} us)"
+    n_rep = 3
     agg = {}
     for lab, fl, by, ms in per:
         a = agg.setdefault(lab, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
