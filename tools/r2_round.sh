@@ -11,6 +11,7 @@ for s in "$@"; do
     arpf) timeout 600 python tools/ar_step_bench.py ${ARPF:-"M5_AR_PREFETCH=0" "M5_AR_PREFETCH=2,M5_AR_PREFETCH_WGS=256" "M5_AR_PREFETCH=1,M5_AR_PREFETCH_WGS=256" "M5_AR_PREFETCH=2,M5_AR_PREFETCH_WGS=512" "M5_AR_PREFETCH=1,M5_AR_PREFETCH_WGS=512"} > $OUT/arpf.log 2>&1; echo "arpf rc=$?"; grep round $OUT/arpf.log ;;
     narab) timeout 600 python tools/nar_step_bench.py ${NARAB:-"M5_NAR_ABSORB=0" "M5_NAR_ABSORB=1" "M5_NAR_ABSORB=1,M5_XATTN_CFG=1" "M5_NAR_ABSORB=1,M5_XATTN_CFG=2"} > $OUT/narab.log 2>&1; echo "narab rc=$?"; grep round $OUT/narab.log ;;
     attn) bash tools/attn_ablate.sh > $OUT/attn_ablate.log 2>&1; echo "attn rc=$?"; grep -E "^==|nar self|nar cross" $OUT/attn_ablate.log ;;
+    c3) timeout 900 python bench.py --workload c3 --batch 32 --steps 1 --warmup 1 > $OUT/c3.json 2> $OUT/c3.err; echo "c3 rc=$?"; cat $OUT/c3.json; tail -2 $OUT/c3.err ;;
     c4) timeout 600 python bench.py --workload c4 --batch ${C4B:-4} --steps 1 --warmup 1 > $OUT/c4.json 2> $OUT/c4.err; echo "c4 rc=$?"; cat $OUT/c4.json; tail -2 $OUT/c4.err ;;
     bench) timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -2 $OUT/bench.err ;;
     benchq) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "bench rc=$?"; cat $OUT/benchq.json; tail -2 $OUT/benchq.err ;;
