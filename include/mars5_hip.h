@@ -290,6 +290,12 @@ int m5_nar_sample(const M5NarSampleArgs* a, void* stream);
 int m5_expand_tokens(const int64_t* tokens, int n, int n_text, const int32_t* off, const int64_t* vals, int n_vocab,
                      int64_t* out, int out_cap, int32_t* total, void* stream);
 
+/* Silence trim on device (reference mars5/trim.py:110-178, librosa.effects.trim semantics with centred reflect-padded
+ * frames): y mono fp32 [n]; power: scratch of n_frames = 1 + n / hop floats (left holding the frame powers);
+ * bounds[0..1] = [start, end) in samples (0, 0 when everything is silent).  Needs n > frame_length / 2. */
+int m5_trim_bounds(const float* y, int n, int frame_length, int hop, float top_db, float* power, int n_frames,
+                   int32_t* bounds, void* stream);
+
 int m5_add_int(int32_t* p, int32_t delta, void* stream);
 
 /* hipGraph helpers (capture the launches issued between begin/end on `stream`). */

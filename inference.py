@@ -23,7 +23,7 @@ from mars5_tts_amd.ar_generate import ar_generate, ar_generate_batch
 from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, begin_inference, perform_batch_inference, perform_simple_inference
 from mars5_tts_amd.minbpe import GPT4_SPLIT_PATTERN, CodebookTokenizer, RegexTokenizer
 from mars5_tts_amd.model import CodecLM, ResidualTransformer
-from mars5_tts_amd.trim import trim
+from mars5_tts_amd.trim import trim, trim_device
 
 
 @dataclass
@@ -127,11 +127,14 @@ class Mars5TTS:
     @torch.inference_mode()
     def vocode(self, tokens: Tensor) -> Tensor:
         """(seq_len, n_q) Encodec codes -> waveform (1, T), through the injected Vocos model (reference inference.py:160-172)."""
+        return self._vocode_device(tokens).cpu().squeeze()[None]
+
+    def _vocode_device(self, tokens: Tensor) -> Tensor:
         _need(self.vocos, "vocos")
         tokens = tokens.T.to(self.device)
         features = self.vocos.codes_to_features(tokens)
         bandwidth_id = torch.tensor([1], device=self.device)
-        return self.vocos.decode(features, bandwidth_id=bandwidth_id).cpu().squeeze()[None]
+        return self.vocos.decode(features, bandwidth_id=bandwidth_id)
 
     @torch.inference_mode()
     def get_speaker_embedding(self, ref_audio: Tensor) -> Tensor:
@@ -367,9 +370,13 @@ class Mars5TTS:
         ref_audio = F.pad(ref_audio, (int(self.sr * cfg.ref_audio_pad), 0))
         prompt_codec = self.codec.encode(ref_audio[None].to(self.device))[0][0]
         gen_codes_decoded, final_output = self.tts_from_codes(text, prompt_codec, ref_transcript, cfg, rng_hooks=rng_hooks)
-        final_audio = self.vocode(final_output).squeeze()
-        final_audio, _ = trim(final_audio.cpu(), top_db=cfg.trim_db)
-        return gen_codes_decoded, final_audio
+        # vocoder output stays on the device for the silence trim (m5_trim_bounds); only the trimmed waveform goes to the host
+        final_audio = self._vocode_device(final_output).squeeze()
+        if final_audio.device.type == "cuda":
+            final_audio, _ = trim_device(final_audio.to(torch.float32), top_db=cfg.trim_db)
+        else:
+            final_audio, _ = trim(final_audio, top_db=cfg.trim_db)
+        return gen_codes_decoded, final_audio.cpu()
 
 
 def _need(obj, name):

@@ -129,6 +129,7 @@ PROTOTYPES = {
     "m5_ar_attn_combine_batch": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, vp, i32, vp, i64, vp]),
     "m5_nar_sample": (C.c_int, [C.POINTER(NarSampleArgs), vp]),
     "m5_expand_tokens": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
+    "m5_trim_bounds": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32, vp, C.c_int, vp, vp]),
     "m5_add_int": (C.c_int, [vp, i32, vp]),
     "m5_graph_begin": (C.c_int, [vp]),
     "m5_graph_end": (C.c_int, [vp, C.POINTER(vp)]),

@@ -281,6 +281,47 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(const typename T::stora
 
 __global__ void add_int_kernel(int32_t* p, int32_t delta) { *p += delta; }
 
+// Silence trim on device (reference mars5/trim.py:110-178 = librosa.effects.trim: centred frames of frame_length samples
+// every hop samples over the REFLECT-padded mono signal, frame power in dB relative to the loudest frame; leading /
+// trailing frames more than top_db below it are cut).  Kernel 1: one workgroup per frame -> mean power.  Kernel 2: one
+// workgroup -> reference power (max), first / last frame above the threshold -> [start, end) in samples.
+__global__ __launch_bounds__(256) void frame_power_kernel(const float* y, int n, int frame_length, int hop, float* power) {
+    __shared__ float red[4];
+    const int f = blockIdx.x, pad = frame_length / 2;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < frame_length; i += 256) {
+        int src = f * hop + i - pad;
+        if (src < 0) src = -src;                                  // reflect (no edge repeat), like F.pad(mode="reflect")
+        if (src >= n) src = 2 * (n - 1) - src;
+        const float v = y[src];
+        s += v * v;
+    }
+    const float tot = block_sum<4>(s, red);
+    if (threadIdx.x == 0) power[f] = tot / (float)frame_length;
+}
+__global__ __launch_bounds__(256) void trim_bounds_kernel(const float* power, int n_frames, int n, int hop, float top_db, int32_t* bounds) {
+    __shared__ float red[4];
+    __shared__ int lo_s, hi_s;
+    float mx = 0.f;
+    for (int f = threadIdx.x; f < n_frames; f += 256) mx = fmaxf(mx, power[f]);
+    const float ref = block_max<4>(mx, red);
+    if (threadIdx.x == 0) { lo_s = 0x7fffffff; hi_s = -1; }
+    __syncthreads();
+    const float ref_db = 10.0f * log10f(fmaxf(1e-10f, ref));
+    int lo = 0x7fffffff, hi = -1;
+    for (int f = threadIdx.x; f < n_frames; f += 256) {
+        const float db = 10.0f * log10f(fmaxf(1e-10f, power[f])) - ref_db;
+        if (db > -top_db) { lo = min(lo, f); hi = max(hi, f); }
+    }
+    atomicMin(&lo_s, lo);
+    atomicMax(&hi_s, hi);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (hi_s < 0) { bounds[0] = 0; bounds[1] = 0; }
+        else { bounds[0] = lo_s * hop; bounds[1] = min(n, (hi_s + 1) * hop); }
+    }
+}
+
 // AR -> NAR hand-off on device (reference inference.py:272-275: (ar_codes - n_text).clamp(0)[first:] through
 // speechtok.decode_int, minbpe/codebook.py:88-126): every BPE token id expands to the run of codebook-0 codes it was merged
 // from (CSR table off / vals; special tokens expand to nothing).  One workgroup: lengths -> block scan -> scatter.
@@ -409,6 +450,17 @@ extern "C" int m5_expand_tokens(const int64_t* tokens, int n, int n_text, const 
                                 int64_t* out, int out_cap, int32_t* total, void* stream) {
     if (!tokens || !off || !vals || !out || !total || n < 0 || n_vocab <= 0 || out_cap < 0) return M5_ERR_ARG;
     hipLaunchKernelGGL(expand_tokens_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tokens, n, n_text, off, vals, n_vocab, out, out_cap, total);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_trim_bounds(const float* y, int n, int frame_length, int hop, float top_db, float* power, int n_frames,
+                              int32_t* bounds, void* stream) {
+    if (!y || !power || !bounds || n <= 0 || frame_length <= 0 || hop <= 0) return M5_ERR_ARG;
+    if (n <= frame_length / 2 || n_frames != 1 + n / hop || (frame_length % 2)) return M5_ERR_UNSUPPORTED;     // reflect padding needs n > pad
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(frame_power_kernel, dim3(n_frames), dim3(256), 0, s, y, n, frame_length, hop, power);
+    hipLaunchKernelGGL(trim_bounds_kernel, dim3(1), dim3(256), 0, s, power, n_frames, n, hop, top_db, bounds);
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

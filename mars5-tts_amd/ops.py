@@ -209,6 +209,17 @@ def expand_tokens(tokens: torch.Tensor, n_text: int, off: torch.Tensor, vals: to
     return out[: int(total.item())]
 
 
+def trim_bounds(y: torch.Tensor, top_db: float, frame_length: int = 2048, hop_length: int = 512, stream: Optional[int] = None) -> torch.Tensor:
+    """[start, end) (int32 (2,), device) of the non-silent part of the mono fp32 device signal y (n,): two launches."""
+    assert y.dtype == torch.float32 and y.dim() == 1 and y.is_contiguous()
+    n = int(y.shape[0])
+    nf = 1 + n // hop_length
+    power = torch.empty(nf, dtype=torch.float32, device=y.device)
+    bounds = torch.zeros(2, dtype=torch.int32, device=y.device)
+    check(lib.m5_trim_bounds(_p(y), n, frame_length, hop_length, float(top_db), _p(power), nf, _p(bounds), _s(stream)), "m5_trim_bounds")
+    return bounds
+
+
 def add_int(p: torch.Tensor, delta: int, stream: Optional[int] = None) -> None:
     assert p.dtype == torch.int32
     check(lib.m5_add_int(_p(p), delta, _s(stream)), "m5_add_int")

@@ -40,6 +40,19 @@ def trim(y, top_db: float = 60, ref=torch.max, frame_length: int = 2048, hop_len
     return yt[..., start:end], torch.tensor([start, end])
 
 
+def trim_device(y: torch.Tensor, top_db: float = 60, frame_length: int = 2048, hop_length: int = 512) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``trim`` for a waveform that lives on the GPU (the vocoder's output): frame powers and the [start, end) search run
+    in two kernels (``m5_trim_bounds``), only the two indices come back to the host.  Same semantics as ``trim`` with
+    ref = max; y: (n,) or (channels, n) fp32 on a cuda device."""
+    from . import ops
+    mono = (torch.mean(y, dim=0) if y.dim() > 1 else y).to(torch.float32).contiguous()
+    if mono.shape[0] <= frame_length // 2:                 # shorter than the reflect padding: nothing to analyse
+        return y, torch.tensor([0, int(y.shape[-1])])
+    b = ops.trim_bounds(mono, top_db, frame_length, hop_length).cpu()
+    start, end = int(b[0]), int(b[1])
+    return y[..., start:end], torch.tensor([start, end])
+
+
 def nuke_weight_norm(module) -> None:
     """Recursively remove weight normalisation (Encodec / Vocos only)."""
     try:

@@ -793,3 +793,21 @@ def test_expand_tokens_vs_host_table(dev, tiny_bundle):
         want = [c for t in (toks - n_text).clamp(min=0).tolist() for c in table[t]]
         got = ops.expand_tokens(toks.to(dev), n_text, off.to(dev), vals.to(dev), mx)
         assert got.cpu().tolist() == want, f"n={n}"
+
+
+def test_device_trim_matches_reference_fixture(dev, gold_dir):
+    """m5_trim_bounds (the silence trim of ``tts()`` on the vocoder's device output) against what the REFERENCE's
+    ``mars5/trim.py:110-178`` returned for the same deterministic waveforms (tests/golden/trim_cases.npz): the same
+    [start, end] interval and samples for mono / stereo / all-zero / very short inputs at three thresholds."""
+    import mars5_oracle as O
+    from mars5_tts_amd.trim import trim_device
+    fx = np.load(os.path.join(gold_dir, "trim_cases.npz"))
+    waves = O.trim_test_waves()
+    for i, top_db in fx["cases"].tolist():
+        ref_idx = fx[f"idx_{i}_{top_db}"].tolist()
+        w = waves[i].clone().to(torch.float32)
+        if w.shape[-1] <= 1024:            # shorter than the reflect padding: the device path leaves it to the host trim
+            continue
+        y, idx = trim_device(w.to(dev), top_db=top_db)
+        assert idx.tolist() == ref_idx, f"wave {i} top_db {top_db}: {idx.tolist()} vs reference {ref_idx}"
+        assert torch.equal(y.cpu(), w[..., ref_idx[0]:ref_idx[1]])
