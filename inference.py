@@ -262,7 +262,30 @@ class Mars5TTS:
         ids = text_ids.tolist() if isinstance(text_ids, Tensor) else list(text_ids)
         return self._tts_core(self._prompt_from_ids(ids, prompt_codec, n_phones_gen, cfg), cfg, None, generator, None)
 
-    def _tts_core(self, pr: dict, cfg: InferenceConfig, ar_noise, generator, rng_hooks) -> Tuple[Tensor, Tensor]:
+    @torch.inference_mode()
+    def tts_stream_from_codes(self, texts: List[str], prompt_codecs: List[Tensor], ref_transcripts: List[Optional[str]],
+                              cfg: InferenceConfig = InferenceConfig(), seeds: Optional[List[int]] = None):
+        """Pipelined serving of independent requests on one GPU: a generator that yields (L0 codes, final codes) per
+        request, in order.  The two stages of consecutive requests overlap -- request i+1's AR decode (latency-bound
+        weight streaming on its own stream) runs while request i's 200 NAR steps (compute-bound) are in flight on the NAR
+        stream -- which raises throughput, not the latency of a request.  Every request draws from a private device
+        generator seeded seeds[i], so result i equals ``torch.manual_seed(seeds[i]); tts_from_codes(...)`` (same property
+        as ``tts_batch_from_codes``)."""
+        n = len(texts)
+        ar_stream, nar_stream = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+        pending = None
+        for i in range(n):
+            g = torch.Generator(device=self.device)
+            g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
+            pr = self._prompt(texts[i], prompt_codecs[i], ref_transcripts[i], cfg)
+            gen, fin = self._tts_core(pr, cfg, None, g, None, streams=(ar_stream, nar_stream), wait=False)
+            if pending is not None:
+                yield pending[0], pending[1]()
+            pending = (gen, fin)
+        if pending is not None:
+            yield pending[0], pending[1]()
+
+    def _tts_core(self, pr: dict, cfg: InferenceConfig, ar_noise, generator, rng_hooks, streams=None, wait: bool = True):
         T = self.default_T
         diff = MultinomialDiffusion(self.diffusion_n_classes, timesteps=T, device=self.device)
         if rng_hooks is not None:
@@ -274,7 +297,8 @@ class Mars5TTS:
         key = (tuple(pr["text_tokens"]), cfg.nar_guidance_w, cfg.x_0_temp, cfg.deep_clone, cfg.q0_override_steps) if h is not None else None
         nar_sess = begin_inference(self.codecnar, torch.tensor(pr["text_tokens"], dtype=torch.long, device=self.device)[None],
                                    pr["prompt_codec"].permute(0, 2, 1), diff.num_timesteps, dsh=self._dsh(cfg), diff=diff,
-                                   spk_vec=h.nar_spk if h is not None else None, cond_from=h.cond.get(key) if h is not None else None)
+                                   spk_vec=h.nar_spk if h is not None else None, cond_from=h.cond.get(key) if h is not None else None,
+                                   stream=streams[1] if streams else None)
         if h is not None and key not in h.cond:
             while len(h.cond) >= max(h.max_cond, 1):
                 h.cond.pop(next(iter(h.cond)))                 # oldest first
@@ -283,7 +307,8 @@ class Mars5TTS:
         ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
                                fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
                                n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
-                               generator=generator, spk_vec=h.ar_spk if h is not None else None, **self._ar_kwargs(cfg))
+                               generator=generator, spk_vec=h.ar_spk if h is not None else None, stream=streams[0] if streams else None,
+                               **self._ar_kwargs(cfg))
         gen_codes_decoded, batch, skip_front = self._handoff(pr, ar_codes, cfg)
         hook_kw = {}
         if rng_hooks is not None:
@@ -291,7 +316,9 @@ class Mars5TTS:
             rng_hooks.after_ar(n_gen + (1 if int(ar_codes.shape[0]) < self._ar_kwargs(cfg)["max_len"] else 0))
             hook_kw = dict(uniform=rng_hooks.uniform, randint=rng_hooks.randint, on_step=getattr(rng_hooks, "nar_on_step", None))
         final_output = perform_simple_inference(self.codecnar, batch, diff, diff.num_timesteps, torch.float16, dsh=self._dsh(cfg),
-                                                retain_quant0=True, generator=generator, session=nar_sess, **hook_kw)
+                                                retain_quant0=True, generator=generator, session=nar_sess, wait=wait, **hook_kw)
+        if not wait:               # pipelined serving: the NAR steps are in flight; the caller collects them later
+            return gen_codes_decoded, (lambda: final_output()[0, skip_front:].to(self.device))
         final_output = final_output[0, skip_front:].to(self.device)
         return gen_codes_decoded, final_output
 

@@ -18,7 +18,7 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
                 typical_p=1.0, eos_penalty_factor=1.0, eos_penalty_decay=0, n_phones_gen=None, vocode=True,
                 beam_width: int = 1, beam_length_penalty=2, use_kv_cache: bool = True,
                 noise: Optional[Tensor] = None, use_graph: bool = True, div_mode: int = 0,
-                generator: Optional[torch.Generator] = None, spk_vec: Optional[Tensor] = None) -> Tensor:
+                generator: Optional[torch.Generator] = None, spk_vec: Optional[Tensor] = None, stream=None) -> Tensor:
     """Autoregressively complete `xx` (seq_len,) with the `codeclm` language model; `ss_gen`
     (ref_len, 8) is the speaker reference.  Returns the full sequence (prompt + generated),
     EOS not appended.  `fp16`, `beam_length_penalty` and `use_kv_cache` are accepted for
@@ -46,7 +46,7 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
         logging.warning(f"[ar_generate] prompt of {P} tokens leaves no room under max_len = {max_len}: nothing generated")
         return xx.to(dev)
 
-    sess = ARSession(eng, max_len)
+    sess = ARSession(eng, max_len, stream=stream)
     n_steps = max_len - P
     gen = None
     fill = None

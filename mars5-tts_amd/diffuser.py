@@ -112,7 +112,7 @@ def _same_tables(a, b) -> bool:
 
 
 def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode: int = 0, diff=None,
-                    spk_vec: Optional[Tensor] = None, cond_from: Optional[NARSession] = None) -> NARSession:
+                    spk_vec: Optional[Tensor] = None, cond_from: Optional[NARSession] = None, stream=None) -> NARSession:
     """Start the part of ``perform_simple_inference`` that depends only on the conditioning (text ids (1,Lt),
     reference codes (1,Lc,8)) and the schedule -- speaker vector, text encoder for every step and guidance branch,
     cross-attention K / V -- on the session's own stream and return without waiting.  ``tts()`` calls this BEFORE the
@@ -120,7 +120,7 @@ def begin_inference(model, c_text: Tensor, c_codes: Tensor, T, dsh=DSH, div_mode
     cfg = _nar_config(T, dsh, div_mode)
     eng = model.engine()
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
-    sess = NARSession(eng, cfg, diff_tables=_tables(diff))
+    sess = NARSession(eng, cfg, stream=stream, diff_tables=_tables(diff))
     if cond_from is not None and cond_from.cfg == cfg and cond_from.times == list(times) and _same_tables(cond_from.diff_tables, sess.diff_tables):
         sess.adopt_cond(cond_from)          # same text, reference, schedule: nothing to recompute (Mars5TTS.prepare_reference)
     else:
@@ -134,14 +134,15 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
                              uniform: Optional[Callable[[tuple], Tensor]] = None, randint: Optional[Callable] = None,
                              use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None,
                              generator: Optional[torch.Generator] = None, session: Optional[NARSession] = None,
-                             on_step: Optional[Callable[[dict], None]] = None) -> Tensor:
+                             on_step: Optional[Callable[[dict], None]] = None, wait: bool = True):
     """batch = (c_text (1,Lt), c_codes (1,Lc,8), c_text_lengths, c_codes_lengths, x (1,Lx,8),
     x_padding_mask); returns (1, S - offset, 8) int64.  RNG draws follow the reference order:
     randint(0,K,(1,Lx,8)) then per step rand (1,S,8,K) x2 (x1 at t = 0).
     `uniform(shape)` / `randint(shape)` override the device generator (parity tests);
     `generator` draws from a private device generator instead of the global one; `session`: the result of
     ``begin_inference`` for the same conditioning, T and dsh (its conditioning work is then not repeated);
-    `on_step`: per-step observer for parity tests (``NARSession.run``)."""
+    `on_step`: per-step observer for parity tests (``NARSession.run``); `wait=False` (pipelined serving): all steps are
+    enqueued and a zero-argument callable is returned that waits for them and yields the result."""
     c_text, c_codes = batch[0], batch[1]
     assert retain_quant0, "retain_quant0=False is not a shipped configuration (inference.py:298)"
     cfg = _nar_config(T, dsh, div_mode)
@@ -165,7 +166,9 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
             _tables(diff), _tables(MultinomialDiffusion(diff.num_classes, timesteps=200)))), "session was begun with another diffusion"
         sess.prepare_state(xr, x_known, m, offset)
         sess.prepare_loop()
-    out = sess.run(uniform, use_graph=use_graph, n_steps=n_steps, on_step=on_step)
+    out = sess.run(uniform, use_graph=use_graph, n_steps=n_steps, on_step=on_step, wait=wait)
+    if not wait:
+        return lambda: sess.finish()[None, offset:].clone()
     return out[None, offset:].clone()
 
 

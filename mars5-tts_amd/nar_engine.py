@@ -376,9 +376,10 @@ class NARSession:
         self.step_i += 1
 
     def run(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True, n_steps: Optional[int] = None,
-            on_step: Optional[Callable[[dict], None]] = None) -> torch.Tensor:
+            on_step: Optional[Callable[[dict], None]] = None, wait: bool = True) -> torch.Tensor:
         """`on_step` (parity tests only; synchronises every step): called after each reverse step with
-        {i, t, x_t, x_tm1, u1, u2} so a checker can replay the step."""
+        {i, t, x_t, x_tm1, u1, u2} so a checker can replay the step.  `wait=False`: enqueue all steps and return without
+        synchronising (pipelined serving: the host goes on to the next request's AR decode); call ``finish()`` for x."""
         n = len(self.times) if n_steps is None else n_steps
         st = self.stream.cuda_stream
         ev0, ev1 = ops.Event(), ops.Event()
@@ -400,6 +401,12 @@ class NARSession:
             self.stream.synchronize()
             on_step(dict(i=i, t=t, x_t=x_t, x_tm1=self.x.clone(), u1=drawn[0][0], u2=drawn[1][0] if len(drawn) > 1 else None))
         ev1.record(st)
+        self._pending = (ev0, ev1, n)
+        return self.finish() if wait else self.x
+
+    def finish(self) -> torch.Tensor:
+        """Wait for the steps ``run`` enqueued; returns x (S, 8)."""
+        ev0, ev1, n = self._pending
         self.stream.synchronize()
         if self.ws.ln_scratch is not None and int(self.ws.ln_scratch[:4].view(torch.int32)[0]) != 0:
             raise RuntimeError("fused residual+LayerNorm GEMM: a row-tile wait timed out (grid not co-resident?)")

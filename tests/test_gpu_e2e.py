@@ -429,6 +429,28 @@ def test_tts_batch_equals_sequential_seeded_calls(dev, tiny_bundle):
     print("generated frames per request:", [int(a.shape[0]) for a, _ in seq])
 
 
+def test_tts_stream_equals_sequential_seeded_calls(dev, tiny_bundle):
+    """``tts_stream_from_codes`` (request i+1's AR decode overlapped with request i's NAR steps on two streams) must
+    return, per request, exactly what ``torch.manual_seed(s_i); tts_from_codes(...)`` returns."""
+    from inference import InferenceConfig
+    from mars5_tts_amd import synth
+    m = _tiny_tts(tiny_bundle, dev, torch.bfloat16)
+    texts = ["The quick brown rat.", "Hi.", "A somewhat longer sentence, to vary the lengths.", "Rats!", "One more."]
+    trs = ["We meet.", "Demand is high, we hear.", "Ok.", "Yes yes.", "Fine."]
+    refs = [synth.make_ref_codes(n, seed=17 + i) for i, n in enumerate([60, 25, 90, 40, 33])]
+    seeds = [2000 + i for i in range(5)]
+    cfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100, generate_max_len_override=220)
+    seq = []
+    for i in range(5):
+        torch.manual_seed(seeds[i])
+        seq.append(m.tts_from_codes(texts[i], refs[i], trs[i], cfg))
+    outs = list(m.tts_stream_from_codes(texts, refs, trs, cfg, seeds=seeds))
+    assert len(outs) == 5
+    for i in range(5):
+        assert torch.equal(outs[i][0].cpu(), seq[i][0].cpu()), f"request {i}: AR frames differ"
+        assert torch.equal(outs[i][1].cpu(), seq[i][1].cpu()), f"request {i}: final codes differ"
+
+
 def test_reference_handle_gives_identical_codes(dev, tiny_bundle):
     """``prepare_reference`` caches what depends on the reference only (speech tokens, AR / NAR speaker
     vectors) and, per text, the NAR conditioning state.  Exact by construction: seeded calls with the handle -- first use,
