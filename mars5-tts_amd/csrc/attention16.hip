@@ -18,6 +18,7 @@
 // the DMA source address and on the fragment reads (conflict-free for ds_read_b128's lane groups).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
@@ -168,14 +169,15 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         }
     };
     // softmax of tile kt (scores in `s`, overwritten by the probabilities) and O^T += V^T . P^T
-    auto softmax_pv = [&](const unsigned char* sb, int kt, f16_t (&s)[2]) {
+    auto softmax_pv = [&](auto mask_tag, const unsigned char* sb, int kt, f16_t (&s)[2]) {
         const int kbase = kt * KT;
         // mask (only tiles that touch the key limit or the causal diagonal); online softmax in the
         // exp2 domain with the score scale folded into the exponent's fma:
         //   p = exp2(s * sc2 - m),  m = running max of s * sc2   (sc2 > 0, so max commutes)
         // VALU per lane and tile: 16 v_max3 + 16 v_pk_fma + 32 v_exp + 16 v_pk_add + 16 cvt_pk.
-        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);
-        if (need_mask) {
+        // (the masked form is a separate instantiation behind a scalar branch: written as a runtime `if` inside one body,
+        // hipcc if-converts it and every tile pays the 64 compares + selects -- half of the loop's VALU instructions)
+        if constexpr (decltype(mask_tag)::value) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -270,7 +272,10 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         if (VARIANT != 2) __syncthreads();                       // ... for every wave; tile kt-1 fully consumed
         if (VARIANT != 1 && kt + 2 < ntiles) stage_load(slot == 0 ? 2 : slot - 1, kt + 2);
         if (kt + 1 < ntiles) qk_tile(lds + s1 * STAGE_B, nxt);
-        softmax_pv(lds + slot * STAGE_B, kt, cur);
+        const int kbase = kt * KT;
+        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);      // wave-uniform
+        if (__builtin_amdgcn_readfirstlane((int)need_mask)) softmax_pv(std::true_type{}, lds + slot * STAGE_B, kt, cur);
+        else softmax_pv(std::false_type{}, lds + slot * STAGE_B, kt, cur);
         slot = s1;
     };
     for (int kt = 0; kt < ntiles; kt += 2) {
