@@ -55,7 +55,7 @@ constexpr int NST = 3;
 // VARIANT: 0 = product kernel; 1..3 = timing ablations (WRONG results; M5_ATTN_VARIANT, tools only):
 // 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.
 template <typename T, int NWAVE, int VARIANT>
-__global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p) {
+__global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p, int always_mask) {
     using st = typename T::storage;
     constexpr int QB = 32 * NWAVE;
     constexpr int NJ = 16 / NWAVE;                  // DMA instructions per wave per tile
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         if (VARIANT != 1 && kt + 2 < ntiles) stage_load(slot == 0 ? 2 : slot - 1, kt + 2);
         if (kt + 1 < ntiles) qk_tile(lds + s1 * STAGE_B, nxt);
         const int kbase = kt * KT;
-        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);      // wave-uniform
+        const bool need_mask = always_mask || (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);      // wave-uniform
         if (__builtin_amdgcn_readfirstlane((int)need_mask)) softmax_pv(std::true_type{}, lds + slot * STAGE_B, kt, cur);
         else softmax_pv(std::false_type{}, lds + slot * STAGE_B, kt, cur);
         slot = s1;
@@ -309,7 +309,9 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     // M5_ATTN_NW / M5_ATTN_VARIANT: tuning + ablation hooks (tools/attn_bench.py); product = 4 waves, variant 0
     static const int nw = [] { const char* e = m5_tool_env("M5_ATTN_NW"); return e ? atoi(e) : 4; }();
     static const int var = [] { const char* e = m5_tool_env("M5_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-#define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a)
+    // tools build, M5_ATTN_ALWAYS_MASK=1: every tile takes the masked instantiation (what the if-converted single body cost)
+    static const int amask = [] { const char* e = m5_tool_env("M5_ATTN_ALWAYS_MASK"); return e ? atoi(e) : 0; }();
+#define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a, amask)
     if (dtype == M5_F16) {
         M5_A16(F16T, 4, 0);
 #ifdef M5_TOOLS
