@@ -18,7 +18,6 @@
 // the DMA source address and on the fragment reads (conflict-free for ds_read_b128's lane groups).
 #include "common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
@@ -55,7 +54,7 @@ constexpr int NST = 3;
 // VARIANT: 0 = product kernel; 1..3 = timing ablations (WRONG results; M5_ATTN_VARIANT, tools only):
 // 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.
 template <typename T, int NWAVE, int VARIANT>
-__global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p, int mask_mode) {
+__global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p) {
     using st = typename T::storage;
     constexpr int QB = 32 * NWAVE;
     constexpr int NJ = 16 / NWAVE;                  // DMA instructions per wave per tile
@@ -169,18 +168,14 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         }
     };
     // softmax of tile kt (scores in `s`, overwritten by the probabilities) and O^T += V^T . P^T
-    auto softmax_pv = [&](auto mask_tag, const unsigned char* sb, int kt, f16_t (&s)[2]) {
+    auto softmax_pv = [&](const unsigned char* sb, int kt, f16_t (&s)[2]) {
         const int kbase = kt * KT;
         // mask (only tiles that touch the key limit or the causal diagonal); online softmax in the
         // exp2 domain with the score scale folded into the exponent's fma:
         //   p = exp2(s * sc2 - m),  m = running max of s * sc2   (sc2 > 0, so max commutes)
         // VALU per lane and tile: 16 v_max3 + 16 v_pk_fma + 32 v_exp + 16 v_pk_add + 16 cvt_pk.
-        // (the masked form is a separate instantiation behind a scalar branch: written as a runtime `if` inside one body,
-        // hipcc if-converts it and every tile pays the 64 compares + selects -- half of the loop's VALU instructions)
-        bool do_mask = decltype(mask_tag)::value == 1;
-        if constexpr (decltype(mask_tag)::value == 2)        // tools A/B only: the round-1 form, a runtime condition inside one body
-            do_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);
-        if (decltype(mask_tag)::value != 0 && do_mask) {
+        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);
+        if (need_mask) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -275,14 +270,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         if (VARIANT != 2) __syncthreads();                       // ... for every wave; tile kt-1 fully consumed
         if (VARIANT != 1 && kt + 2 < ntiles) stage_load(slot == 0 ? 2 : slot - 1, kt + 2);
         if (kt + 1 < ntiles) qk_tile(lds + s1 * STAGE_B, nxt);
-        const int kbase = kt * KT;
-        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);      // wave-uniform
-#ifdef M5_TOOLS
-        if (mask_mode == 1) softmax_pv(std::integral_constant<int, 2>{}, lds + slot * STAGE_B, kt, cur);
-        else
-#endif
-        if (__builtin_amdgcn_readfirstlane((int)need_mask)) softmax_pv(std::integral_constant<int, 1>{}, lds + slot * STAGE_B, kt, cur);
-        else softmax_pv(std::integral_constant<int, 0>{}, lds + slot * STAGE_B, kt, cur);
+        softmax_pv(lds + slot * STAGE_B, kt, cur);
         slot = s1;
     };
     for (int kt = 0; kt < ntiles; kt += 2) {
@@ -316,10 +304,7 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     // M5_ATTN_NW / M5_ATTN_VARIANT: tuning + ablation hooks (tools/attn_bench.py); product = 4 waves, variant 0
     static const int nw = [] { const char* e = m5_tool_env("M5_ATTN_NW"); return e ? atoi(e) : 4; }();
     static const int var = [] { const char* e = m5_tool_env("M5_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
-    // tools build, M5_ATTN_MASKIF=1 (read per call): the round-1 form of the mask (runtime condition inside one body) for A/B runs
-    const char* me = m5_tool_env("M5_ATTN_MASKIF");
-    const int amask = me ? atoi(me) : 0;
-#define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a, amask)
+#define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a)
     if (dtype == M5_F16) {
         M5_A16(F16T, 4, 0);
 #ifdef M5_TOOLS
