@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # tuning knobs, A/B kernels and probes live only there (csrc/common.h, m5_tool_env)
 TOOLS = os.environ.get("M5_HIP_TOOLS") == "1"
 LIB_PATH = os.path.join(_HERE, "libmars5_hip_tools.so" if TOOLS else "libmars5_hip.so")
+if TOOLS and os.environ.get("M5_HIP_TOOLS_LIB"):          # same-box A/B of two tools builds (tools/*.py only)
+    LIB_PATH = os.environ["M5_HIP_TOOLS_LIB"]
 
 M5_OK, M5_ERR_ARG, M5_ERR_LAUNCH, M5_ERR_UNSUPPORTED = 0, -1, -2, -3
 F32, F16, BF16 = 0, 1, 2
