@@ -244,18 +244,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
         }
     }
     float pm = 0.f, pl = 0.f;
-    float4 ov[PRO == M5_PRO_ATTN ? 8 : 1][2];      // PRO_ATTN: this thread's 8 outputs of all 8 splits, requested now (L2 hits that the
-    if constexpr (PRO == M5_PRO_ATTN) {            // combine below would otherwise only ask for after its first barrier)
+    if constexpr (PRO == M5_PRO_ATTN) {
         if (tid < a.n_heads * 8) {                 // thread = (head, split)
             pm = a.part[(int64_t)tid * M5_ATTN_PART + 64];
             pl = a.part[(int64_t)tid * M5_ATTN_PART + 65];
         }
-        const int i0 = tid * 8;
-        const float* pp = a.part + (int64_t)(i0 >> 6) * 8 * M5_ATTN_PART + (i0 & 63);
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) ov[s][e] = *reinterpret_cast<const float4*>(pp + s * M5_ATTN_PART + 4 * e);
     }
 
     // ---- epilogue operands that depend only on the row / position: issued now, consumed after the
@@ -332,7 +325,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
             if ((tid & 7) == 0) wsm[H * 8 + (tid >> 3)] = l;
         }
         __syncthreads();
-        const int i0 = tid * PER, h = i0 >> 6;
+        const int i0 = tid * PER, h = i0 >> 6, d = i0 & 63;
+        const float* pp = a.part + (int64_t)h * 8 * M5_ATTN_PART + d;
+        float4 ov[8][PER / 4];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int e = 0; e < PER / 4; ++e) ov[s][e] = *reinterpret_cast<const float4*>(pp + s * M5_ATTN_PART + 4 * e);
         float o[PER];
 #pragma unroll
         for (int e = 0; e < PER; ++e) o[e] = 0.f;
@@ -482,14 +481,11 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
     const int done = a.state[M5_ST_DONE];          // consumed before the only global write (a finished sequence just idles)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = blockIdx.x, split = blockIdx.y;
-    const int pos = a.state[M5_ST_POS];            // needed only once the first K / V loads are in flight (see below)
-    // Key ranges are cut over the ALLOCATED slots (known at launch), not over the valid ones: the loads of a range can then
-    // be issued without waiting for the position word (one dependent round trip less per layer and token); slots >= n_valid
-    // hold zeros or stale rows, are fetched for nothing and masked once the position is known.
-    const int n_cap = min(a.w_alloc, a.window);
-    int chunk = (n_cap + a.nsplit - 1) / a.nsplit;
+    const int pos = a.state[M5_ST_POS];
+    const int n_valid = min(pos + 1, a.window);
+    int chunk = (n_valid + a.nsplit - 1) / a.nsplit;
     chunk = (chunk + PPW * 4 - 1) / (PPW * 4) * (PPW * 4);
-    const int start = split * chunk, end = min(n_cap, start + chunk);
+    const int start = split * chunk, end = min(n_valid, start + chunk);
     const int sub = lane % LPP, grp = lane / LPP;
 
     float qv[EPL];
@@ -517,7 +513,8 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int p = base0 + u * 4 * PPW + grp;
-            if (p < end) {
+            okv[u] = p < end;
+            if (okv[u]) {
                 kv[u].load(Kh + (int64_t)p * 64 + sub * EPL);
                 vv[u].load(Vh + (int64_t)p * 64 + sub * EPL);
             } else {
@@ -525,9 +522,6 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(M5AttnDecodeArgs a) {
                 vv[u].zero();
             }
         }
-        const int n_valid = min(pos + 1, a.window);
-#pragma unroll
-        for (int u = 0; u < UN; ++u) okv[u] = base0 + u * 4 * PPW + grp < min(end, n_valid);
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             float kf[EPL], vf[EPL];
