@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-batch-leg", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="also time the same utterances through tts_stream_from_codes (AR of request i+1 "
                     "enqueued beside the NAR steps of request i); measured in round 2: no overlap on this stack (5.90 vs 5.86 audio-s/s)")
     ap.add_argument("--no-graph", action="store_true")
@@ -698,6 +699,22 @@ def main():
         out["nar_loop"] = nar
         out["kernels"] = kernels
         out["time_split_ms"] = {"ar_decode": round(ar_engine.LAST_STATS["decode_ms"], 1), "nar_loop": round(nar["ms_per_step"] * 200, 1)}
+    if world == 1 and args.workload == "c2" and not args.no_batch_leg:
+        # throughput mode beside the headline (BASELINE configs[2] in small): 8 mixed-length requests through the batched
+        # AR decode + batched NAR refinement, one untimed-warmup-free pass (~7 s); `--workload c3` is the full 32-request form
+        from inference import InferenceConfig
+        texts, trs, refs, max_lens = c3_requests(m, 8, args.n_gen, seed=11)
+        bcfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
+                               eos_estimated_gen_length_factor=100.0, eos_penalty_factor=50.0, eos_penalty_decay=0.5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = m.tts_batch_from_codes(texts, [r.to(dev) for r in refs], trs, bcfg, seeds=[1000 + j for j in range(8)], nar_batch=8, ar_batch=8,
+                                     max_lens=max_lens)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - t0
+        out["batch8_mixed_lengths"] = {"value": round(sum(int(f.shape[0]) for _, f in res) / 75.0 / dtb, 4), "unit": "audio_s/s", "requests": 8,
+                                       "s_per_batch": round(dtb, 3), "reference_frames": [int(r.shape[-1]) for r in refs],
+                                       "note": "tts_batch_from_codes(ar_batch=8, nar_batch=8), single pass incl. graph captures"}
     if world == 1 and args.workload == "c2" and args.pipeline:
         # serving mode, reported beside (never as) the headline: the same utterances as a pipelined stream -- request i+1's AR
         # decode overlaps request i's NAR steps (Mars5TTS.tts_stream_from_codes); throughput up, per-request latency not
