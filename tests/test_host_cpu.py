@@ -1,0 +1,72 @@
+"""Host-side logic that needs no GPU: schedule constants taken from the caller's diffusion object, the cross-attention
+path plan of a batch, request wire format, reference-handle LRU bookkeeping."""
+import math
+
+import numpy as np
+import torch
+
+
+def test_step_consts_follow_the_callers_diffusion():
+    """The eight per-step scalars m5_nar_sample consumes must come from the MultinomialDiffusion the caller passed
+    (reference q_pred / q_posterior read diff.log_*, diffuser.py:118-206): a 100-step schedule gives other constants than
+    the default 200-step one, equal to the oracle's tables for that schedule, and out-of-range steps fail loudly."""
+    import mars5_oracle as O
+    from mars5_tts_amd.diffuser import MultinomialDiffusion, _tables
+    from mars5_tts_amd.tables import nar_step_consts
+    K = 1025
+    for T in (200, 100, 37):
+        diff = MultinomialDiffusion(K, timesteps=T)
+        tb = O.diffusion_tables(K, T)
+        times = [T - 1, T // 2, 1, 0]
+        c = nar_step_consts(times, K, tables=_tables(diff))
+        lnK = np.log(K)
+        for i, t in enumerate(times):
+            tm1 = max(t - 1, 0)
+            want = torch.stack([tb.log_cumprod_alpha[tm1], tb.log_1_min_cumprod_alpha[tm1] - lnK, tb.log_alpha[t], tb.log_1_min_alpha[t] - lnK,
+                                tb.log_cumprod_alpha[t], tb.log_1_min_cumprod_alpha[t] - lnK]).float()
+            assert torch.equal(c[i, :6], want), (T, t)
+            assert float(c[i, 6]) == float(t)
+    assert not torch.equal(nar_step_consts([50], K, tables=_tables(MultinomialDiffusion(K, timesteps=100))),
+                           nar_step_consts([50], K))
+    try:
+        nar_step_consts([150], K, tables=_tables(MultinomialDiffusion(K, timesteps=100)))
+        raise SystemExit("a step outside the diffusion's range must not be accepted")
+    except AssertionError:
+        pass
+
+
+def test_cross_plan_groups_utterances_by_path():
+    """``make_cross_plan``: consecutive utterances that take the same cross-attention path form one run; the padded memory
+    length is a function of the utterance's own memory length (so alone == inside any batch); fp32 engines and memories of
+    more than 64 rows keep the reference's operation order; models whose H * Lp is not a whole number of 64-deep K-steps
+    fall back to the next padded length."""
+    from mars5_tts_amd.blocks import AbsorbedCross, CrossMemory, EncLayerW, make_cross_plan
+    assert [AbsorbedCross.lp_of(le, 16) for le in (1, 39, 48, 49, 64, 65, 300)] == [48, 48, 48, 64, 64, 0, 0]
+    assert AbsorbedCross.lp_of(39, 2) == 64 and AbsorbedCross.lp_of(39, 3) == 0          # 2 * 48 = 96 is not a multiple of 64; odd head counts
+    D, H, T, Bm = 128, 2, 3, 2
+
+    def mem(le):
+        k = torch.zeros(T * Bm, H, le, 64, dtype=torch.bfloat16)
+        return CrossMemory(k, None, le, 64, Bm, v_rows=torch.zeros_like(k))
+
+    lw = EncLayerW(in_w=None, in_b=None, out_w=None, out_b=None, act_w=None, l2_w=None, l2_b=None, n1_w=None, n1_b=None, n2_w=None, n2_b=None)
+    lw.ca_q_wT, lw.ca_out_w, lw.ca_q_b = torch.zeros(H, D, 64, dtype=torch.bfloat16), torch.zeros(D, D, dtype=torch.bfloat16), torch.zeros(D)
+    les = [20, 64, 70, 90, 33]
+    plan = make_cross_plan([lw, lw], [[mem(le) for le in les]] * 2, D, torch.bfloat16, "cpu")
+    kinds = [(seg[0], seg[1].s0, seg[1].n_seq, seg[1].Lp) if seg[0] == "absorbed" else (seg[0], seg[1], seg[2]) for seg in plan]
+    assert kinds == [("absorbed", 0, 4, 64), ("plain", 4, 8), ("absorbed", 8, 2, 64)], kinds
+    assert plan[0][1].tab_seq.shape == (2 * 4, 8) and plan[0][1].A.shape == (2, 4, H * 64, D)
+    plan32 = make_cross_plan([lw, lw], [[mem(le) for le in les]] * 2, D, torch.float32, "cpu")
+    assert [seg[0] for seg in plan32] == ["plain"] and plan32[0][1:3] == (0, 10)
+
+
+def test_request_wire_format_roundtrip():
+    from mars5_tts_amd import sharding as sh
+    g = torch.Generator().manual_seed(1)
+    reqs = [sh.Request(i, torch.randint(0, 3000, (5 + i,), generator=g), torch.randint(0, 1024, (7 * (i + 1), 8), generator=g), seed=10 + i,
+                       n_gen_est=100 + i, n_phones_gen=40 + i, max_len=900 + i) for i in range(4)]
+    back = sh._unpack(sh._pack(reqs))
+    for a, b in zip(reqs, back):
+        assert (a.idx, a.seed, a.n_gen_est, a.n_phones_gen, a.max_len) == (b.idx, b.seed, b.n_gen_est, b.n_phones_gen, b.max_len)
+        assert torch.equal(a.text_ids, b.text_ids) and torch.equal(a.ref_codes, b.ref_codes)
+    assert sh._unpack(sh._pack([])) == []
