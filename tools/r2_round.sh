@@ -12,6 +12,9 @@ for s in "$@"; do
     narab) timeout 600 python tools/nar_step_bench.py ${NARAB:-"M5_NAR_ABSORB=0" "M5_NAR_ABSORB=1" "M5_NAR_ABSORB=1,M5_XATTN_CFG=1" "M5_NAR_ABSORB=1,M5_XATTN_CFG=2"} > $OUT/narab.log 2>&1; echo "narab rc=$?"; grep round $OUT/narab.log ;;
     attn) bash tools/attn_ablate.sh > $OUT/attn_ablate.log 2>&1; echo "attn rc=$?"; grep -E "^==|nar self|nar cross" $OUT/attn_ablate.log ;;
     c3) timeout 900 python bench.py --workload c3 --batch 32 --steps 1 --warmup 1 > $OUT/c3.json 2> $OUT/c3.err; echo "c3 rc=$?"; cat $OUT/c3.json; tail -2 $OUT/c3.err ;;
+    c5) timeout 900 python bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-batch-leg > $OUT/c5.json 2> $OUT/c5.err; echo "c5 rc=$?"; cat $OUT/c5.json | cut -c1-1500; tail -2 $OUT/c5.err ;;
+    f16) timeout 600 python bench.py --dtype f16 --steps 3 --warmup 1 --no-cpu-baseline --no-batch-leg > $OUT/bench_f16.json 2> $OUT/bench_f16.err; echo "f16 rc=$?"; cat $OUT/bench_f16.json | cut -c1-700 ;;
+    traffic) ONLY="nar swiglu" bash tools/pmc_traffic.sh $TAG/traffic > $OUT/traffic.log 2>&1; echo "traffic rc=$?"; cat gpurun_out/$TAG/traffic/summary.txt | grep -A3 -E "gemm16" | head -40 ;;
     c4) timeout 600 python bench.py --workload c4 --batch ${C4B:-4} --steps 1 --warmup 1 > $OUT/c4.json 2> $OUT/c4.err; echo "c4 rc=$?"; cat $OUT/c4.json; tail -2 $OUT/c4.err ;;
     bench) timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -2 $OUT/bench.err ;;
     benchq) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "bench rc=$?"; cat $OUT/benchq.json; tail -2 $OUT/benchq.err ;;
