@@ -18,7 +18,7 @@ for s in "$@"; do
     c4) timeout 600 python bench.py --workload c4 --batch ${C4B:-4} --steps 1 --warmup 1 > $OUT/c4.json 2> $OUT/c4.err; echo "c4 rc=$?"; cat $OUT/c4.json; tail -2 $OUT/c4.err ;;
     bench) timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -2 $OUT/bench.err ;;
     benchq) timeout 600 python bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "bench rc=$?"; cat $OUT/benchq.json; tail -2 $OUT/benchq.err ;;
-    prof) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
+    prof) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity --no-batch-leg > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
           find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -30 {} | cut -c1-200'
           find $OUT/prof -name "*kernel_trace.csv" -size +30M -delete ;;
     smoke) timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
