@@ -103,6 +103,21 @@ __device__ inline uint2 pack4(const float v[4]) {
     return *reinterpret_cast<const uint2*>(t);
 }
 
+// s_waitcnt vmcnt(y * n) for the wave-uniform y in [0, Y] (y younger stages of n DMA instructions each may stay in flight)
+template <int Y, int JN>
+__device__ inline void wait_younger(int y, bool full_share) {
+    if constexpr (Y > 0) {
+        if (y == Y) {
+            if (full_share) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Y * JN) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Y * (JN - 1)) : "memory");
+            return;
+        }
+        wait_younger<Y - 1, JN>(y, full_share);
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // Workgroup tile = (WM x WN) waves, each wave (TM x TN) MFMA tiles of 16x16 (fp32 accumulators
 // 4 TM TN per lane); BKB = K-step in BYTES per row (128: 64 halves, 64: 32 halves); NSTAGE LDS
 // stages (NSTAGE-1 K-steps of DMA in flight ahead of the MFMAs); OCC = workgroups per CU the
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     constexpr int JN = (NQ + NW - 1) / NW;
     constexpr int KS = BKB / 64;                       // MFMA k-steps (32 halves) per stage
     static_assert(BM % RPI == 0 && BN % RPI == 0, "stage tiling");
-    static_assert(NSTAGE * STAGE <= 160 * 1024 && NSTAGE >= 2 && NSTAGE <= 4, "LDS budget");
+    static_assert(NSTAGE * STAGE <= 160 * 1024 && NSTAGE >= 2 && NSTAGE <= 10, "LDS budget");
     static_assert((NSTAGE - 2) * JN < 64, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
 
@@ -170,6 +185,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     // (conflict-free for ds_read_b128's four 16-lane groups in both layouts: SQ_LDS_BANK_CONFLICT = 0).
     const int srow = (BKB == 128) ? (lane >> 3) : (lane >> 2);
     const int schunk = (BKB == 128) ? ((lane & 7) ^ srow) : ((lane & 3) ^ ((-(srow >> 2)) & 3));
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const unsigned char* gp[JN];
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
@@ -178,7 +194,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         if (r < BM) gp[j] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda * 2 + schunk * 16;
         else gp[j] = W + (int64_t)min(n0 + r - BM, p.N - 1) * p.ldw * 2 + schunk * 16;
     }
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     auto stage_load = [&](int stage, int kt) {
         const uint32_t sbase = lds_base + stage * STAGE + wave * 1024;
         const int64_t koff = (int64_t)kt * BKB;
@@ -287,15 +302,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         // K-step kt has landed once at most min(NSTAGE-2, nk-1-kt) younger stages remain in flight
         // (vmcnt is per wave: a wave that issues JN - 1 instructions per stage counts with JN - 1)
         const int younger = min(NSTAGE - 2, nk - 1 - kt);
-        if (NSTAGE >= 4 && younger == 2) {
-            if (full_share) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * JN) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (JN - 1)) : "memory");
-        } else if (NSTAGE >= 3 && younger == 1) {
-            if (full_share) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(JN) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(JN - 1) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        wait_younger<NSTAGE - 2, JN>(younger, full_share);
         __syncthreads();
         // the slot read during K-step kt-1 is free now: refill it with K-step kt+NSTAGE-1
         if (kt + NSTAGE - 1 < nk) stage_load(slot == 0 ? NSTAGE - 1 : slot - 1, kt + NSTAGE - 1);
@@ -906,13 +913,16 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
 }
 
 // Tile configurations.  M5_GEMM_CFG=<n> forces one (tuning sweeps); otherwise pick_config().
-struct CfgInfo { int bm, bn, tn, occ; float t_fix_us, t_iter_us; };   // t_iter: per 64-deep K-step, measured (profiles/)
+struct CfgInfo { int bm, bn, tn, occ; float t_fix_us, t_iter_us; int only_epi; };   // t_iter: per 64-deep K-step, measured (profiles/)
 static const CfgInfo kCfg[] = {
-    {128, 128, 4, 2, 8.f, 0.72f},     // 0: 128x128 tile, 4 waves, 2 stages, 2 WG/CU
-    {192, 384, 6, 1, 8.f, 2.37f},     // 1: region 192x384, 8 waves (2x4 of 96x96), 2 stages
-    {192, 192, 4, 1, 7.f, 1.40f},     // 2: region 192x192, 6 waves (2x3 of 96x64), 3 stages
-    { 96, 128, 4, 1, 8.f, 0.64f},     // 3: region  96x128, 4 waves (2x2 of 48x64), 4 stages
-    { 96, 128, 2, 2, 8.f, 0.66f},     // 4: tile    96x128, 8 waves (2x4 of 48x32), 2 stages, 2 WG/CU
+    {128, 128, 4, 2, 8.f, 0.72f, -1},             // 0: 128x128 tile, 4 waves, 2 stages, 2 WG/CU
+    {192, 384, 6, 1, 8.f, 2.20f, -1},             // 1: region 192x384, 8 waves (2x4 of 96x96), 2 stages
+    {192, 192, 4, 1, 7.f, 1.20f, -1},             // 2: region 192x192, 12 waves (4x3 of 48x64), 3 stages
+    { 96, 128, 4, 1, 8.f, 0.64f, -1},             // 3: region  96x128, 4 waves (2x2 of 48x64), 4 stages
+    { 96, 128, 2, 2, 8.f, 0.66f, -1},             // 4: tile    96x128, 8 waves (2x4 of 48x32), 2 stages, 2 WG/CU
+    {192, 384, 6, 1, 8.f, 2.10f, M5_EPI_SWIGLU},  // 5: region 192x384, 16 waves (4x4 of 48x96), 2 stages (the QKV / residual
+                                                  //    epilogues spill at 128 VGPRs: SwiGLU only)
+    {192, 192, 4, 1, 7.f, 1.40f, -2},             // 6: region 192x192, 6 waves (2x3 of 96x64), 3 stages (sweeps: superseded by 2)
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -921,9 +931,11 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s) {
     switch (cfg) {
         case 0: return launch16<T, 2, 2, 4, 4, 128, 2, 2>(epi, p, batch, s);
         case 1: return launch16<T, 2, 4, 6, 6, 128, 2, 1>(epi, p, batch, s);
-        case 2: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s);
+        case 2: return launch16<T, 4, 3, 3, 4, 128, 3, 1>(epi, p, batch, s);
         case 3: return launch16<T, 2, 2, 3, 4, 128, 4, 1>(epi, p, batch, s);
         case 4: return launch16<T, 2, 4, 3, 2, 128, 2, 2>(epi, p, batch, s);
+        case 5: return launch16<T, 4, 4, 3, 6, 128, 2, 1>(epi, p, batch, s);
+        case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s);
         default: return M5_ERR_ARG;
     }
 }
@@ -936,12 +948,16 @@ int pick_config(int M, int N, int K, int batch, int span_div, int epi) {
     float best_t = 1e30f;
     for (int c = 0; c < kNumCfg; ++c) {
         const CfgInfo& f = kCfg[c];
+        if (f.only_epi == -2 || (f.only_epi >= 0 && f.only_epi != epi)) continue;
         if (span_div && (span_div % (f.tn * 16))) continue;
         const int64_t wg = (int64_t)((M + f.bm - 1) / f.bm) * ((N + f.bn - 1) / f.bn) * batch;
         const int64_t slots = 256 * f.occ;
         const int64_t rounds = (wg + slots - 1) / slots;
         // a partially filled last round of an occ-2 configuration runs its workgroups alone on their CUs
         float t = (float)rounds * (f.t_fix_us + (float)(K / 64) * f.t_iter_us);
+        // many rounds (batched NAR groups, M >= 10k rows): the tail round no longer matters and most of a workgroup's
+        // fixed cost hides under its successor / co-resident workgroup (measured at M = 35840, profiles/r2t_gemm_configs.txt)
+        if (wg >= 4 * slots) t = (float)wg / (float)slots * ((f.occ == 1 ? 0.2f : 0.7f) * f.t_fix_us + (float)(K / 64) * f.t_iter_us);
         if (epi == M5_EPI_QKV && c == 3) t += 2.5f * (float)rounds;     // measured: its 4-wave scatter epilogue is the slowest
         if (t < best_t) { best_t = t; best = c; }
     }
@@ -1121,7 +1137,13 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
         p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     }
     const char* fe = m5_tool_env("M5_GEMM_CFG");             // tuning sweeps (tools build only); read per call on purpose
-    const int forced = (fe && fe[0]) ? atoi(fe) : -1;
+    int forced = (fe && fe[0]) ? atoi(fe) : -1;
+    if (forced < 0) {                                        // per-epilogue override: M5_GEMM_CFG_E<epi>=<n>
+        char nm[24];
+        snprintf(nm, sizeof nm, "M5_GEMM_CFG_E%d", epi);
+        const char* fe2 = m5_tool_env(nm);
+        if (fe2 && fe2[0]) forced = atoi(fe2);
+    }
     const int span_div = (sc && sc->vt) ? sc->n_heads * sc->head_dim : 0;
     int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div, epi);
     if (cfg < 0 || cfg >= kNumCfg || (span_div && (span_div % (kCfg[cfg].tn * 16)))) cfg = 0;

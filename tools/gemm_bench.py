@@ -115,6 +115,11 @@ CASES = [
     ("ar prefill w13", 489, 7168, 1536, L.EPI_SWIGLU, False, None),
     ("ar prefill w2", 489, 1536, 3584, L.EPI_RESIDUAL, False, None),
     ("spk enc qkv", 451, 3072, 1024, L.EPI_QKV, True, 451),
+    # batched NAR group (c3: 8 utterances x 2 branches x 2240 rows)
+    ("big out_proj", 35840, 1024, 1024, L.EPI_RESIDUAL, True, None),
+    ("big linear2", 35840, 1024, 3072, L.EPI_RESIDUAL, True, None),
+    ("big swiglu", 35840, 6144, 1024, L.EPI_SWIGLU, False, None),
+    ("big qkv", 35840, 3072, 1024, L.EPI_QKV, True, 2240),
 ]
 
 if __name__ == "__main__":
