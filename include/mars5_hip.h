@@ -242,6 +242,29 @@ int m5_ar_qkv_rope_batch(int dtype, const void* xn, int64_t lda, const void* wqk
 int m5_ar_attn_combine_batch(int dtype, const float* part, int64_t part_bs, int B, int n_heads, int nsplit,
                              const int32_t* state, int32_t state_bs, void* out, int64_t out_bs, void* stream);
 
+/* The n_layers Mistral layers of one decode step as ONE persistent launch (csrc/ar_mega.hip): 256 co-resident workgroups,
+ * the five launches of a layer become phases with the same row / lane / k mapping (bit-identical results), dependent
+ * vectors cross between workgroups as tagged 8-byte granules, later phases' weight rows stream in underneath the edges.
+ * 16-bit operands, CodecLM geometry only (dim 1536, hidden 3584, 24 heads, 8 key splits); needs >= 256 CUs; the stacked
+ * per-layer weights are contiguous: wqkv [L][3D][D], wo [L][D][D], w13 [L][2F][D] (rows interleaved W1_i, W3_i), w2 [L][D][F],
+ * norms [L][D] fp32, caches [L][H][w_alloc][64].  gran: M5_AR_MEGA_GRANULES 8-byte words, zeroed by the host at every
+ * prefill (tags are unique within an utterance only).  err[0] != 0 after a launch: a workgroup gave up waiting (the grid was
+ * not co-resident); sticky -- later launches return at once -- the caller re-runs the step with the per-launch entry points.
+ * M5_ERR_UNSUPPORTED (nothing launched) for other geometries / fewer CUs.  nn_future.py:235-274,326-333. */
+#define M5_AR_MEGA_GRANULES 21760
+typedef struct {
+    const void* wqkv; const void* wo; const void* w13; const void* w2;
+    const float* attn_norm; const float* ffn_norm; float eps;
+    int32_t dim, hidden, n_heads, layer0, layer1;          /* layers [layer0, layer1)                */
+    float* xres;                                           /* [dim] residual stream in / out         */
+    const float* rope; const int32_t* state;
+    void* kcache; void* vcache; int32_t w_alloc, window;
+    float scale;
+    uint64_t* gran; uint32_t* err;
+    unsigned long long* dbg;                               /* diagnostics (tools build): phase stamps of workgroup 0, or NULL */
+} M5ArMegaArgs;
+int m5_ar_layers_persistent(int dtype, const M5ArMegaArgs* a, void* stream);
+
 /* Sampler chain of ar_generate.py:74-115 + samplers.py:20-93 on device, then the
  * multinomial draw argmax(p / q) with caller-supplied Exp(1) noise, EOS / max_len
  * handling (ar_generate.py:62,121) and the next token's embedding load (model.py:106). */
@@ -339,6 +362,11 @@ int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int iters, int row
 /* Diagnostics: workgroup b streams chunk (b + shift) % blocks of buf (chunk_bytes each; nt = non-temporal loads): pairs of
  * launches with equal / different shifts measure whether an XCD's L2 keeps lines across a kernel boundary.  tools/l2_retention.py. */
 int m5_debug_l2_touch(const void* buf, int64_t chunk_bytes, int blocks, int threads, int shift, int nt, float* sink, void* stream);
+/* All-gather edge probe (tools/edge_probe.py): `blocks` co-resident workgroups each publish `per` values of an n-vector
+ * as 8-byte {fp32, tag} granules and sweep the whole vector, `iters` times in one launch, optionally under a weight
+ * stream of stream_kb KiB per workgroup and edge: the price of one dependency edge of a persistent decode step. */
+int m5_debug_edge_probe(uint64_t* gran, int n, int per, int blocks, int threads, int iters, uint32_t base_tag,
+                        const void* wbuf, int stream_kb, uint32_t* err, float* sums, void* stream);
 #endif /* M5_TOOLS */
 
 #ifdef __cplusplus

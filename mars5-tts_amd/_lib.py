@@ -74,6 +74,18 @@ class GemvArgs(C.Structure):
                 ("w_alloc", i32), ("window", i32), ("dim", i32), ("dbg", vp), ("pf", Prefetch)]
 
 
+class ArMegaArgs(C.Structure):
+    _fields_ = [("wqkv", vp), ("wo", vp), ("w13", vp), ("w2", vp),
+                ("attn_norm", vp), ("ffn_norm", vp), ("eps", f32),
+                ("dim", i32), ("hidden", i32), ("n_heads", i32), ("layer0", i32), ("layer1", i32),
+                ("xres", vp), ("rope", vp), ("state", vp),
+                ("kcache", vp), ("vcache", vp), ("w_alloc", i32), ("window", i32), ("scale", f32),
+                ("gran", vp), ("err", vp), ("dbg", vp)]
+
+
+AR_MEGA_GRANULES = 21760
+
+
 class AttnDecodeArgs(C.Structure):
     _fields_ = [("qbuf", vp), ("kcache", vp), ("vcache", vp), ("part", vp), ("state", vp),
                 ("n_heads", i32), ("w_alloc", i32), ("window", i32), ("nsplit", i32), ("scale", f32),
@@ -124,6 +136,7 @@ PROTOTYPES = {
     "m5_rope_cache": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, i64, C.c_int, vp, i64, i64, vp]),
     "m5_ar_gemv": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(GemvArgs), vp]),
     "m5_ar_attn_decode": (C.c_int, [C.c_int, C.POINTER(AttnDecodeArgs), vp]),
+    "m5_ar_layers_persistent": (C.c_int, [C.c_int, C.POINTER(ArMegaArgs), vp]),
     "m5_ar_sample": (C.c_int, [C.POINTER(SampleArgs), vp]),
     "m5_ar_rope_cache_batch": (C.c_int, [C.c_int, vp, C.c_int, C.c_int, vp, vp, i32, vp, i64, vp, vp, i64, i64, C.c_int, vp]),
     "m5_ar_qkv_rope_batch": (C.c_int, [C.c_int, vp, i64, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, i32, vp, i64, vp, vp, i64, i64,
@@ -150,6 +163,7 @@ TOOLS_PROTOTYPES = {
     "m5_debug_launch_chain": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "m5_debug_grid_barrier": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "m5_debug_l2_touch": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "m5_debug_edge_probe": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, vp, C.c_int, vp, vp, vp]),
 }
 
 

@@ -47,6 +47,11 @@ class ARSamplingConfig:
     div_mode: int = 0            # 0: logits / T (reference CPU kernel), 1: logits * (1/T) (reference GPU kernel)
 
 
+def _mega_default() -> bool:
+    """Persistent-layers decode step on / off (M5_AR_MEGA=0|1)."""
+    return os.environ.get("M5_AR_MEGA", "0") == "1"
+
+
 class ARModel:
     """Packed CodecLM weights on one GPU.  dtype: GEMM operand type ('f32' | 'f16' | 'bf16')."""
 
@@ -112,6 +117,11 @@ class ARSession:
             self.logits = bf["logits"] if "logits" in bf else torch.zeros(V, dtype=torch.float32, device=dev)
             self.state = bf["state"] if "state" in bf else torch.zeros(L.ST_WORDS, dtype=torch.int32, device=dev)
             self.tokens = bf["tokens"] if "tokens" in bf else torch.zeros(max_len + 1, dtype=torch.int64, device=dev)
+            # persistent-layers form of the decode step (csrc/ar_mega.hip): granule buffer + sticky error word
+            self.gran = torch.zeros(L.AR_MEGA_GRANULES, dtype=torch.int64, device=dev)
+            self.mega_err = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.mega_dbg: Optional[torch.Tensor] = None           # tools/ar_mega_clock.py: (32, 16, 8) int64 phase stamps
+        self.mega = _mega_default() and model.dt != torch.float32 and (D, F, H) == (1536, 3584, 24) and not buffers
         self.graph: Optional[ops.Graph] = None
         self._sample_args: Optional[L.SampleArgs] = None
         self._keep: List[torch.Tensor] = []
@@ -163,6 +173,8 @@ class ARSession:
             self.xdec.copy_(x[M - 1])
             self.tokens[:P].copy_(prompt)
             self.state.copy_(torch.tensor([P, 0, 0, P, -1, 0, 0, 0], dtype=torch.int32), non_blocking=False)
+            self.gran.zero_()                                  # granule tags are unique within one utterance only
+            self.mega_err.zero_()
             self._keep = [table, x]
         self.P = P
 
@@ -194,6 +206,16 @@ class ARSession:
     def enqueue_layers(self, st: int) -> None:
         m, s = self.m, self.m.shape
         D, F, H = s.dim, s.hidden_dim, s.nhead
+        if self.mega:
+            a = L.ArMegaArgs(wqkv=m.wqkv.data_ptr(), wo=m.wo.data_ptr(), w13=m.w13.data_ptr(), w2=m.w2.data_ptr(),
+                             attn_norm=m.attn_norm.data_ptr(), ffn_norm=m.ffn_norm.data_ptr(), eps=s.norm_eps,
+                             dim=D, hidden=F, n_heads=H, layer0=0, layer1=s.n_layers, xres=self.xdec.data_ptr(),
+                             rope=m.rope.data_ptr(), state=self.state.data_ptr(), kcache=self.kc.data_ptr(), vcache=self.vc.data_ptr(),
+                             w_alloc=self.w_alloc, window=self.window, scale=64 ** -0.5, gran=self.gran.data_ptr(),
+                             err=self.mega_err.data_ptr(), dbg=self.mega_dbg.data_ptr() if self.mega_dbg is not None else None)
+            if ops.ar_layers_persistent(m.dt, a, stream=st) == L.M5_OK:
+                return
+            self.mega = False                                  # geometry / device not eligible: per-launch form from here on
         # same-stream prefetch plan (M5Prefetch): 0 off; 1 every launch pulls the NEXT launch's weights; 2 only the two
         # bandwidth-idle launches (cache scan, Wo) pull the two halves of W1|W3.  16-bit streaming geometry only.
         plan = int(os.environ.get("M5_AR_PREFETCH", "0")) if (m.dt != torch.float32 and D == 1536 and F == 3584) else 0
@@ -289,6 +311,9 @@ class ARSession:
         ev1.record(st)
         self.stream.synchronize()
         final = self.state.cpu()
+        if self.mega and int(self.mega_err.cpu()[0]):
+            raise RuntimeError("persistent AR decode step: a workgroup gave up waiting for its peers (grid not co-resident?); "
+                               "set M5_AR_MEGA=0 to use the per-launch form")
         n_tok = int(final[L.ST_NTOK])
         self.ended_on_eos = bool(int(final[L.ST_DONE])) and int(final[L.ST_LAST]) == int(self._sample_args.eos_idx)
         LAST_STATS.update(decode_ms=ev0.elapsed_ms(ev1), decode_steps_launched=done, n_generated=n_tok - self.P,

@@ -229,4 +229,72 @@ extern "C" int m5_debug_l2_touch(const void* buf, int64_t chunk_bytes, int block
     M5_CHECK_LAUNCH();
     return M5_OK;
 }
+
+// ---- all-gather edge probe (diagnostics; tools/edge_probe.py): what does one dependency edge of a persistent decode
+// step cost on this part?  Every workgroup produces `per` fp32 values of an n-vector as 8-byte {value, tag} granules (one
+// agent-scope relaxed 8-byte store each: value and tag can never be seen torn), then every workgroup sweeps the whole
+// vector until all n tags carry the edge's tag, and consumes it (a sum, checked on the host).  `stream_kb` > 0 adds a
+// non-temporal read of that many KiB per workgroup and edge from `wbuf` (the weight stream a decode phase runs under).
+// Two granule buffers alternate, so a fast workgroup never overwrites values a slow one still waits for.
+// Spins are bounded: err[0] counts workgroups that gave up (the kernel never hangs).
+namespace {
+__global__ void edge_probe_kernel(unsigned long long* gran, int n, int per, int iters, unsigned base_tag,
+                                  const unsigned char* wbuf, int stream_kb, unsigned* err, float* sums) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    __shared__ float red[16];
+    __shared__ int bad;
+    float total = 0.f;
+    unsigned sink = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned tag = base_tag + (unsigned)it + 1u;
+        unsigned long long* g = gran + (size_t)(it & 1) * n;
+        // the phase's weight stream (issued first, consumed after the edge)
+        u32x4 w[8];
+        const int nld = stream_kb * 1024 / (nt * 16);            // 16-byte loads per thread
+        const unsigned char* wp = wbuf + ((size_t)b * iters + it) % 4096 * ((size_t)stream_kb * 1024);
+        for (int i = 0; i < 8; ++i) w[i] = (i < nld) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + ((size_t)i * nt + tid) * 16)) : u32x4{0, 0, 0, 0};
+        // produce
+        if (tid < per && b * per + tid < n) {
+            const float v = (float)((it + b * per + tid) & 1023);
+            const unsigned long long word = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+            __hip_atomic_store(&g[b * per + tid], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // consume: thread t owns granules t, t + nt, ...
+        float s = 0.f;
+        if (tid == 0) bad = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += nt) {
+            unsigned long long word;
+            int spins = 0;
+            while (true) {
+                word = __hip_atomic_load(&g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(word >> 32) == tag) break;
+                if (++spins > (1 << 18)) { bad = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s += __uint_as_float((unsigned)word);
+        }
+        for (int i = 0; i < 8; ++i) sink ^= w[i].x ^ w[i].y ^ w[i].z ^ w[i].w;
+        // block sum (the consumer's use of the vector)
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if ((tid & 63) == 0) red[tid >> 6] = s;
+        __syncthreads();
+        if (tid == 0) { float t = 0.f; for (int k = 0; k < nt / 64; ++k) t += red[k]; total += t; if (bad) atomicAdd(err, 1u); }
+        __syncthreads();
+        if (bad) break;
+    }
+    if (tid == 0) sums[b] = total + (sink == 0x12345u ? 1.f : 0.f);
+}
+}  // namespace
+extern "C" int m5_debug_edge_probe(uint64_t* gran, int n, int per, int blocks, int threads, int iters, uint32_t base_tag,
+                                   const void* wbuf, int stream_kb, uint32_t* err, float* sums, void* stream) {
+    // gran: 2 n words (zeroed by the caller once; tags only grow); wbuf: >= 4096 * stream_kb KiB when stream_kb > 0
+    if (!gran || !err || !sums || n <= 0 || per <= 0 || blocks <= 0 || blocks > 1024 || threads < 64 || threads > 1024 || (threads % 64) || iters <= 0) return M5_ERR_ARG;
+    if (per > threads || (int64_t)blocks * per < n || stream_kb < 0 || stream_kb * 1024 > threads * 16 * 8 || (stream_kb && !wbuf)) return M5_ERR_ARG;
+    hipLaunchKernelGGL(edge_probe_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (unsigned long long*)gran, n, per, iters, base_tag,
+                       (const unsigned char*)wbuf, stream_kb, err, sums);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
 #endif  // M5_TOOLS

@@ -154,6 +154,15 @@ def ar_gemv(dtype: torch.dtype, pro: int, epi: int, args: L.GemvArgs, stream: Op
     check(lib.m5_ar_gemv(DT_CODE[dtype], pro, epi, C.byref(args), _s(stream)), "m5_ar_gemv")
 
 
+def ar_layers_persistent(dtype: torch.dtype, args: L.ArMegaArgs, stream: Optional[int] = None) -> int:
+    """All Mistral layers of one decode step as one persistent launch (csrc/ar_mega.hip).  Returns the C status: M5_OK, or
+    M5_ERR_UNSUPPORTED when the geometry / device does not allow it (the caller then enqueues the per-launch form)."""
+    rc = lib.m5_ar_layers_persistent(DT_CODE[dtype], C.byref(args), _s(stream))
+    if rc not in (L.M5_OK, L.M5_ERR_UNSUPPORTED):
+        check(rc, "m5_ar_layers_persistent")
+    return rc
+
+
 def ar_rope_cache_batch(qkv: torch.Tensor, n_heads: int, rope: torch.Tensor, state: torch.Tensor, qbuf: torch.Tensor,
                         kcache: torch.Tensor, vcache: torch.Tensor, cache_bs: int, cache_hs: int, window: int,
                         stream: Optional[int] = None) -> None:

@@ -35,7 +35,7 @@ def main():
             out = sess.decode(use_graph=True)
             from mars5_tts_amd import ar_engine
             s = ar_engine.LAST_STATS
-            print(f"round {rnd} {v:40s} {1e3 * s['decode_ms'] / max(s['n_generated'] - 1, 1):8.1f} us/token  ({s['n_generated']} tokens, checksum {int(out.sum())})", flush=True)
+            print(f"round {rnd} {v:40s} {1e3 * s['decode_ms'] / max(s['n_generated'] - 1, 1):8.1f} us/token  ({s['n_generated']} tokens, checksum {int(out.sum())}, persistent {int(sess.mega)}, err {int(sess.mega_err[0])})", flush=True)
             for k in kv:
                 os.environ.pop(k, None)
             del sess
