@@ -426,7 +426,10 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     bytes_tok = ae.weight_bytes_per_token() + kv_per_pos * (avg_len + 1)
     tok_ms = ars["decode_ms"] / max(ars["n_generated"] - 1, 1)
     gbs = bytes_tok / tok_ms / 1e6
-    ar = dict(bound="hbm", kernel="AR decode step (132 launches: 26 x {gemv qkv+rope, attn_decode, gemv wo, gemv w13+swiglu, gemv w2} + head + sampler, hipGraph)", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+    form = ("3 launches: ar_mega_kernel (26 layers, 256 persistent workgroups, tagged-granule edges, LDS-DMA weight prefetch) + head + sampler, hipGraph"
+            if ars.get("persistent") else
+            "132 launches: 26 x {gemv qkv+rope, attn_decode, gemv wo, gemv w13+swiglu, gemv w2} + head + sampler, hipGraph")
+    ar = dict(bound="hbm", kernel=f"AR decode step ({form})", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
               frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_token=int(bytes_tok), us_per_token=round(1e3 * tok_ms, 1))
     return roof, ar, nar, kernels
 

@@ -48,8 +48,10 @@ class ARSamplingConfig:
 
 
 def _mega_default() -> bool:
-    """Persistent-layers decode step on / off (M5_AR_MEGA=0|1)."""
-    return os.environ.get("M5_AR_MEGA", "0") == "1"
+    """Persistent-layers form of the batch-1 decode step (csrc/ar_mega.hip): on unless M5_AR_MEGA=0.  It computes the same
+    bits as the per-launch form (tests/test_gpu_parity16.py) and applies to the 16-bit CodecLM geometry on a device with
+    at least 256 CUs; anything else runs the per-launch form."""
+    return os.environ.get("M5_AR_MEGA", "1") != "0"
 
 
 class ARModel:
@@ -317,7 +319,7 @@ class ARSession:
         n_tok = int(final[L.ST_NTOK])
         self.ended_on_eos = bool(int(final[L.ST_DONE])) and int(final[L.ST_LAST]) == int(self._sample_args.eos_idx)
         LAST_STATS.update(decode_ms=ev0.elapsed_ms(ev1), decode_steps_launched=done, n_generated=n_tok - self.P,
-                          prefill_len=self.P + 1, final_len=n_tok)
+                          prefill_len=self.P + 1, final_len=n_tok, persistent=bool(self.mega))
         return self.tokens[:n_tok].clone()
 
 

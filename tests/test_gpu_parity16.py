@@ -144,6 +144,68 @@ def test_ar_full_size_16bit_450_tokens_vs_oracle(dev, full_bundle, dt):
     _ar_compare(dev, b, dt, prompt, ref_codes[0].T.contiguous(), 450, 64, dev, len(TEXT), AR_TOL_EMU[dt], AR_TOL_F32[dt], 400)
 
 
+def _session(eng, b, st, P, N, noise, persistent):
+    from mars5_tts_amd.ar_engine import ARSamplingConfig, ARSession
+    s = ARSession(eng, P + N)
+    s.mega = bool(persistent) and s.mega
+    cfg = ARSamplingConfig(temperature=0.7, topk=1, top_p=0.2, alpha_frequency=3.0, alpha_presence=0.4, penalty_window=100,
+                           eos_penalty_factor=50.0, eos_penalty_decay=0.5, n_phones_gen=100 * len(TEXT))
+    s.configure_sampler(cfg, b.n_text, b.n_text + st.special_tokens["<|endofspeech|>"], noise)
+    return s
+
+
+@pytest.mark.parametrize("window", [3000, 96])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_ar_persistent_step_is_bit_identical_to_the_per_launch_step(dev, full_bundle, dt, window):
+    """The one-launch form of the decode step (csrc/ar_mega.hip: 256 co-resident workgroups, tagged-granule edges, LDS-DMA
+    weight prefetch) against the five-launches-per-layer form it replaces: every step's logits bit for bit (eager), the
+    same tokens from the hipGraph replays, no workgroup ever gave up waiting.  window = 96: a 60-token prompt and 200
+    decoded positions wrap the rotating KV buffer twice (BASELINE configs[4]'s mechanism at the real width)."""
+    from mars5_tts_amd import _lib as L, model, synth
+    b = full_bundle
+    tt, st = _toks(b)
+    a = b.ar_shape
+    lm = model.CodecLM(a.n_vocab, dim=a.dim, nhead=a.nhead, n_layers=a.n_layers, n_spk_layers=a.n_spk_layers,
+                       dim_ff_scale=a.hidden_dim / a.dim + 1e-9, sliding_window=window)
+    lm.load_state_dict(b.ar_ckpt["model"])
+    eng = lm.to(dev).set_engine_dtype(dt).engine()
+    ref_codes = synth.make_ref_codes(450, seed=7)
+    ref = ref_codes[0].T.contiguous()
+    prompt, _ = _bench_prompt(b, tt, st, ref_codes)
+    if window < 3000:
+        prompt = prompt[-60:]
+    P, N = int(prompt.shape[0]), 200
+    noise = torch.ones(N, a.n_vocab, device=dev)
+    runs = {}
+    for persistent in (False, True):
+        s = _session(eng, b, st, P, N, noise, persistent)
+        assert s.mega == persistent, "the persistent form should apply to this geometry on an MI355X"
+        s.prefill(prompt, ref)
+        sv = s.stream.cuda_stream
+        lg = []
+        for i in range(N):
+            if i:
+                s.enqueue_layers(sv)
+            s.enqueue_head_and_sample(sv)
+            s.stream.synchronize()
+            lg.append(s.logits.clone())
+        n_tok = int(s.state.cpu()[L.ST_NTOK])
+        assert int(s.mega_err.cpu()[0]) == 0
+        runs[persistent] = (torch.stack(lg), s.tokens[:n_tok].cpu())
+        del s
+    assert runs[True][1].tolist() == runs[False][1].tolist()
+    n_gen = runs[True][1].shape[0] - P
+    assert n_gen >= 150, n_gen
+    diff = (runs[True][0][:n_gen] != runs[False][0][:n_gen]).any(dim=1)
+    assert not bool(diff.any()), f"first differing step {int(diff.nonzero()[0])}"
+    # the timed path: hipGraph replays
+    s = _session(eng, b, st, P, N, noise, True)
+    s.prefill(prompt, ref)
+    tok = s.decode(use_graph=True).cpu()
+    assert s.mega and tok.tolist() == runs[False][1].tolist()
+    print(f"AR persistent step {str(dt).split('.')[-1]} window {window}: {n_gen} steps bit-identical to the per-launch form")
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_ar_tiny_16bit_vs_cpu_oracle(dev, tiny_bundle, dt):
     """The same comparison at test scale against the oracle on the CPU (the pinned instrument itself, CPU libm): the
