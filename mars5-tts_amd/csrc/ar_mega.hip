@@ -2,29 +2,40 @@
 // 235-274, 326-333 -- TransformerBlock.forward / Attention.forward decode branch / FeedForward.forward).
 //
 // The 5-launches-per-layer form (ar_decode.hip) spends ~3.8 us per launch outside its weight stream (boundary, first
-// byte, drain) and streams a layer's 52 MB in ~8 us.  Here 256 co-resident workgroups (one per CU, 8 waves) walk the
-// layers themselves.  The five launches become phases of the same arithmetic, row for row and lane for lane (a workgroup
-// owns exactly the rows workgroup blockIdx.x of the corresponding launch owned, with the same wave / lane / k mapping, so
-// every dot product, RMSNorm sum and softmax merge is bit-identical to ar_decode.hip):
+// byte, drain) and streams a layer's 52 MB in ~8 us: 27.4 us per layer.  Here 256 co-resident workgroups (one per CU, 8
+// waves) walk the layers themselves: 19.8 us per layer, 571 vs 733 us per token (profiles/r3_ar_persistent_step_log.txt).
+// The five launches become phases of the same arithmetic, row for row and lane for lane (a workgroup owns exactly the rows
+// workgroup blockIdx.x of the corresponding launch owned, with the same lane / k mapping and the same reduction trees, so
+// every dot product, RMSNorm sum and softmax merge is bit-identical to ar_decode.hip; tests/test_gpu_parity16.py):
 //   P1 RMSNorm -> Wqkv rows -> RoPE -> KV-cache slot + {q, k, v} of this token          (waves 0-2: 6 rows each)
 //   P2 workgroups 0..191: (head, key split) cache scan;  192..215: merge the 8 splits of one head
 //   P3 Wo rows -> x += .                                                                  (waves 0-2: 2 rows each)
 //   P4 RMSNorm -> interleaved (W1, W3) rows -> silu(a) * b                                (waves 0-6: 4 rows each)
 //   P5 W2 rows -> x += .                                                                  (waves 0-5: 1 row each)
-// What a phase needs from OTHER workgroups crosses as 8-byte granules {fp32 value, tag} written by one agent-scope store
-// each (value and tag cannot be seen torn; no fence, no flag): tag = (pos + 1) * 256 + layer * 8 + edge is unique within an
-// utterance, and the host zeroes the granule buffer at prefill.  Waves 4-7 of every workgroup are the gatherers: each sweeps
-// a quarter of the vector the next phase consumes (all granules of a sweep in flight, repeated until every tag matches)
-// into LDS while the others are parked at a workgroup barrier.  A poll queues behind whatever its wave already has in
-// flight (the VM counter retires in order), so weight rows are requested where that does not matter: Wqkv / Wo rows (waves
-// 0-2, which never poll) as soon as their registers are free, two phases ahead; W1|W3 and W2 rows right after the
-// gather of the phase before theirs.  They stream in underneath the edges: that overlap is what the launch boundaries
-// of the 5-launch form cannot give.
-// A buffer is reused by every layer: safe, because a workgroup publishes edge e of layer l + 1 only after it has gathered
-// everything up to edge e - 1 of that layer, which every workgroup published after consuming edge e of layer l.
-// Spins are bounded: a gatherer that waits ~2^16 sweeps raises err[0] and its workgroup leaves; the others then run into
-// their own bound.  err is sticky (later launches return at once), so a broken co-residency assumption costs milliseconds,
-// never a hang; the host then falls back to the 5-launch form.
+//
+// Edges.  What a phase needs from OTHER workgroups crosses as 8-byte granules {32-bit payload, tag} written by one
+// agent-scope store each (payload and tag cannot be seen torn; no fence, no flag): tag = (pos + 1) * 256 + layer * 8 + edge
+// is unique within an utterance, and the host zeroes the granule buffer at prefill.  fp32 values (residual stream, split-KV
+// partials) travel one per granule, 16-bit values (q | k | v, merged attention output, SwiGLU output) two per granule.  The
+// consumers sweep the vector (every granule of a wave's share in flight, repeated until all tags match) into LDS.
+//   * ONE store instruction publishes a workgroup's outputs of a phase (collected through LDS).  An edge costs ~0.3 us per
+//     store instruction of a different wave / CU that lands in the same 128-byte line: the SwiGLU edge took 4.7 us while
+//     each of 7 waves x 256 workgroups stored its own granule, 1.7 us with one instruction per workgroup (-17 % per token).
+//   * A CU's polls queue behind its own DMA returns (~25 GB/s per CU), and a wave's polls behind everything that wave has
+//     in flight (the VM counter retires in order).  So no wave that polls ever has a weight load in flight.
+// A granule buffer is reused by every layer: safe, because a workgroup publishes edge e of layer l + 1 only after it has
+// gathered everything up to edge e - 1 of that layer, which every workgroup published after consuming edge e of layer l.
+//
+// Weights.  Wave 7 is the loader: it alone requests weight rows, by LDS-DMA (no data registers: hipcc spilled every
+// register-held prefetch of this kernel), as flat copies of the workgroup's contiguous rows into two LDS regions
+// (A: Wqkv rows, then W1|W3 rows; B: Wo rows, then W2 rows), one to three phases ahead and -- as far as the regions
+// allow -- at points where the workgroup is about to compute rather than about to wait for an edge.  It makes sure a set
+// has landed (counted vmcnt: the sets retire in issue order) before it joins the barrier in front of the products that
+// read it.  Waves 0-6 only ever touch LDS and granules.
+//
+// Workgroup barriers order LDS only (lgkmcnt(0) + s_barrier, never the VM counter).  Spins are bounded: a gatherer that
+// waits ~2^16 sweeps raises err[0] and its workgroup leaves; the others then run into their own bound.  err is sticky
+// (later launches return at once), so a broken co-residency assumption costs milliseconds, never a hang; the host raises.
 #include "common.h"
 
 namespace {
@@ -173,7 +184,7 @@ __device__ inline void dot_rows(float (&acc)[R], const unsigned char* slice, con
 
 // RMSNorm of the gathered vector (graw, MD values) into xs with the thread mapping of a gemv_stream launch of NWP waves
 // (chunk c = tid + j * NWP * 64 of MD / 4 float4 chunks; block sum = wave trees, then the waves in order).  All 512
-// threads call it (two workgroup barriers inside).
+// threads call it (one workgroup barrier inside).
 template <typename T, int NWP>
 __device__ inline void rms_to_xs(const float* graw, const float* nws, float eps, float* xs, float* red, int tid, int lane, int wave) {
     constexpr int NT = NWP * 64, NCH = MD / 4, JN = (NCH + NT - 1) / NT;
@@ -191,8 +202,7 @@ __device__ inline void rms_to_xs(const float* graw, const float* nws, float eps,
             if (tid + j * NT < NCH) ss += xin[j].x * xin[j].x + xin[j].y * xin[j].y + xin[j].z * xin[j].z + xin[j].w * xin[j].w;
         ss = wave_sum(ss);
     }
-    bar();
-    if (wave < NWP && lane == 0) red[wave] = ss;
+    if (wave < NWP && lane == 0) red[wave] = ss;             // (the caller alternates two `red` arrays: no barrier needed before)
     bar();
     float tot = 0.f;
 #pragma unroll
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
     float* xs = reinterpret_cast<float*>(lds) + MF;             // the phase's activation vector as the dot products read it
     float* nws = graw + 2048;                                   // RMSNorm weights of the phase (P1 / P4 gather 1536 values only)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    __shared__ float red[8];
+    __shared__ float red[2][8];
     __shared__ float sm[4][8][10];                              // attention: per-wave partial (o[8], m, l) of 8 d-groups
     __shared__ float xloc[8];                                   // this workgroup's 6 rows of the residual stream
     __shared__ unsigned pub[16];                                // a phase's outputs of this workgroup, published by ONE store instruction
@@ -263,7 +273,11 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
     // the fabric allows); wave 7 is the loader: it alone issues the weight DMAs, one phase or more ahead, and makes sure a
     // set has landed (counted vmcnt) before it joins the barrier in front of the products that read it.
     const bool loader = wave == 7;
-    if (loader) dma_flat(lds_base + OFF_A, Wq + ((int64_t)a.layer0 * 3 * MD + (int64_t)b * 18) * MD * 2, 54, lane);
+    const unsigned char* Wo = (const unsigned char*)a.wo;
+    if (loader) {
+        dma_flat(lds_base + OFF_A, Wq + ((int64_t)a.layer0 * 3 * MD + (int64_t)b * 18) * MD * 2, 54, lane);
+        dma_flat(lds_base + OFF_B, Wo + ((int64_t)a.layer0 * MD + (int64_t)b * 6) * MD * 2, 18, lane);
+    }
 
     for (int l = a.layer0; l < a.layer1; ++l) {
         const unsigned tl = tag0 + (unsigned)l * 8u;
@@ -283,9 +297,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 1);
-        // loader: this layer's Wo rows -> region B (the W2 rows of the layer before were consumed before this barrier)
-        if (loader) dma_flat(lds_base + OFF_B, (const unsigned char*)a.wo + ((int64_t)l * MD + (int64_t)b * 6) * MD * 2, 18, lane);
-        rms_to_xs<T, 3>(graw, nws, a.eps, xs, red, tid, lane, wave);
+        rms_to_xs<T, 3>(graw, nws, a.eps, xs, red[0], tid, lane, wave);
         if (loader) wait_dma<18>();                           // the Wqkv rows have landed (the 18 Wo pieces are younger)
         bar();
         if (wave < 3) {
@@ -423,23 +435,22 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
             }
             bar();
             if (loader) dma_flat(lds_base + OFF_A + 42 * 1024, W13 + 42 * 1024, 42, lane);      // drains before the O edge completes
-            if (tid < 8) {
+            if (wave == 0) {
+                // merge of the 4 waves (attn_decode_kernel's 8-thread tail, one (d-group, element) per lane: the same sums in
+                // the same order), then two store instructions publish the 66 words
+                const int ms = lane >> 3, me = lane & 7;
                 float mm = -INFINITY;
-                for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm[w][tid][8]);
-                float ll = 0.f, oo[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) oo[e] = 0.f;
+                for (int w = 0; w < 4; ++w) mm = fmaxf(mm, sm[w][ms][8]);
+                float ll = 0.f, oo = 0.f;
                 for (int w = 0; w < 4; ++w) {
-                    const float mw = sm[w][tid][8];
+                    const float mw = sm[w][ms][8];
                     const float wt = (mw == -INFINITY) ? 0.f : expf(mw - mm);
-                    ll += wt * sm[w][tid][9];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) oo[e] += wt * sm[w][tid][e];
+                    ll += wt * sm[w][ms][9];
+                    oo += wt * sm[w][ms][me];
                 }
                 u64* dst = g + G_PART + ah * PART_H + asplit * M5_ATTN_PART;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) publish(dst, tid * 8 + e, oo[e], tl + E_PART);
-                if (tid == 0) { publish(dst, 64, mm, tl + E_PART); publish(dst, 65, ll, tl + E_PART); }
+                publish(dst, lane, oo, tl + E_PART);
+                if (lane < 2) publish(dst, 64 + lane, lane == 0 ? mm : ll, tl + E_PART);
             }
         } else if (b < MH * MNS + MH) {
             const int hh = b - MH * MNS;
@@ -472,8 +483,11 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 5);
+        // loader: the W2 rows that do not overlap the Wo rows (region B bytes [18 K, 42 K)); the rest behind the P4 gather
+        const unsigned char* W2 = (const unsigned char*)a.w2 + ((int64_t)l * MD + (int64_t)b * 6) * MF * 2;
+        if (loader) dma_flat(lds_base + OFF_B + 18 * 1024, W2 + 18 * 1024, 24, lane);
         for (int i = tid; i < MD / 4; i += 512) *reinterpret_cast<float4*>(xs + i * 4) = *reinterpret_cast<const float4*>(graw + i * 4);
-        if (loader) wait_dma<63>();                           // 18 Wo + 84 W1|W3 pieces issued since: <= 63 outstanding => the Wo rows landed
+        if (loader) wait_dma<63>();                           // 18 Wo + 84 W1|W3 + 24 W2 pieces issued since: <= 63 outstanding => the Wo rows landed
         bar();
         if (wave < 3) {
             float acc[2];
@@ -502,8 +516,8 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         mstamp(a.dbg, l, 7);
         // loader: W2 rows -> region B (the Wo rows were consumed in P3, before this barrier).  Issued here rather than behind
         // the products: they then stream under P4's arithmetic instead of under the h edge (measured 4.6 vs 5.4 us for it)
-        if (loader) dma_flat(lds_base + OFF_B, (const unsigned char*)a.w2 + ((int64_t)l * MD + (int64_t)b * 6) * MF * 2, 42, lane);
-        rms_to_xs<T, 7>(graw, nws, a.eps, xs, red, tid, lane, wave);
+        if (loader) dma_flat(lds_base + OFF_B, W2, 18, lane);
+        rms_to_xs<T, 7>(graw, nws, a.eps, xs, red[1], tid, lane, wave);
         if (loader) wait_dma<42>();                           // the W1 | W3 rows have landed (the 42 W2 pieces are younger)
         bar();
         if (wave < 7) {
@@ -535,10 +549,13 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 9);
         // loader: next layer's Wqkv rows -> region A (the W1 | W3 rows were consumed in P4, before this barrier)
-        if (loader && l + 1 < a.layer1) dma_flat(lds_base + OFF_A, Wq + ((int64_t)(l + 1) * 3 * MD + (int64_t)b * 18) * MD * 2, 54, lane);
+        const bool more = l + 1 < a.layer1;
+        const unsigned char* Wqn = Wq + ((int64_t)(l + 1) * 3 * MD + (int64_t)b * 18) * MD * 2;
+        if (loader && more) dma_flat(lds_base + OFF_A, Wqn, 27, lane);
         for (int i = tid; i < MF / 4; i += 512) *reinterpret_cast<float4*>(xs + i * 4) = *reinterpret_cast<const float4*>(graw + i * 4);
-        if (loader) { if (l + 1 < a.layer1) wait_dma<54>(); else wait_dma<0>(); }      // the W2 rows have landed
+        if (loader) { if (more) wait_dma<27>(); else wait_dma<0>(); }      // the W2 rows have landed
         bar();
+        if (loader && more) dma_flat(lds_base + OFF_A + 27 * 1024, Wqn + 27 * 1024, 27, lane);   // (about a microsecond of stream: gone before the x edge polls matter)
         if (wave < 6) {
             float acc[1];
             dot_rows<T, 1, 7>(acc, lds + OFF_B + wave * 7 * 1024, xs, lane);
@@ -549,9 +566,11 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         }
         bar();
         if (wave == 0 && lane < 6) {
-            if (l + 1 < a.layer1) publish(g + G_X2, b * 6 + lane, xloc[lane], tl + E_X2);
+            if (more) publish(g + G_X2, b * 6 + lane, xloc[lane], tl + E_X2);
             else a.xres[b * 6 + lane] = xloc[lane];
         }
+        // loader: next layer's Wo rows -> region B (the W2 rows were consumed before this barrier)
+        if (loader && more) dma_flat(lds_base + OFF_B, Wo + ((int64_t)(l + 1) * MD + (int64_t)b * 6) * MD * 2, 18, lane);
         mstamp(a.dbg, l, 10);
     }
 }
