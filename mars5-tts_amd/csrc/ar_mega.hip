@@ -135,15 +135,6 @@ __device__ inline void glds16_nt(const unsigned char* gsrc, uint32_t lds_addr) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_addr) : "memory");
 }
-template <int R, int NIT>
-__device__ inline void dma_rows(uint32_t slice, const unsigned char* W, int64_t ld_bytes, int row0, int lane) {
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const unsigned char* wr = W + (int64_t)(row0 + r) * ld_bytes + lane * 16;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) glds16_nt(wr + it * 1024, slice + (r * NIT + it) * 1024);
-    }
-}
 // The loader wave: `pieces` KiB of a workgroup's contiguous weight rows -> a contiguous LDS region (a workgroup's rows of a
 // phase are consecutive rows of the matrix, and the waves' slices are laid out in the same order)
 __device__ inline void dma_flat(uint32_t dst, const unsigned char* src, int pieces, int lane) {
