@@ -98,9 +98,12 @@ __device__ inline float half_to_f32(unsigned bits) {
 // fp32 to dst[2 (j nl + lane)], [.. + 1]; else one fp32 value to dst[j nl + lane].  false: gave up.
 // Addresses: wave-uniform base (SGPRs) + one shared 32-bit lane offset; the buffer is readable up to (PER - 1) sj + 64 words.
 template <typename T, int PER, bool PACK>
-__device__ inline bool gather(const u64* g, int sj, int nl, unsigned tag, float* dst, int lane) {
+__device__ inline bool gather(const u64* g, int sj, int nl, unsigned tag, float* dst, int lane, int n_total = PER * 64) {
     const unsigned lane8 = (unsigned)lane * 8u;
-    unsigned pend = (lane < nl) ? ((1u << PER) - 1u) : 0u;
+    unsigned pend = 0;                                          // granule (j, lane) is wanted iff lane < nl and j nl + lane < n_total
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+        if (lane < nl && j * nl + lane < n_total) pend |= 1u << j;
     for (int spins = 0; spins < SPIN_LIMIT; ++spins) {
         u64 w[PER];
 #pragma unroll
@@ -445,8 +448,8 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
             }
         } else if (b < MH * MNS + MH) {
             const int hh = b - MH * MNS;
-            if (wave == 4 && (!gather<T, 8, false>(g + G_PART + hh * PART_H, 64, 64, tl + E_PART, graw, lane) ||
-                              !gather<T, 1, false>(g + G_PART + hh * PART_H + 512, 64, 16, tl + E_PART, graw + 512, lane))) fail = 1;
+            // one sweep over the head's 8 x 66 words (the region is padded to 9 x 64 granules)
+            if (wave == 4 && !gather<T, 9, false>(g + G_PART + hh * PART_H, 64, 64, tl + E_PART, graw, lane, MNS * M5_ATTN_PART)) fail = 1;
             bar();
             if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
             if (wave == 0) {                                  // lane = d; the merge of gemv_stream_kernel's PRO_ATTN prologue
@@ -542,11 +545,11 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         // loader: next layer's Wqkv rows -> region A (the W1 | W3 rows were consumed in P4, before this barrier)
         const bool more = l + 1 < a.layer1;
         const unsigned char* Wqn = Wq + ((int64_t)(l + 1) * 3 * MD + (int64_t)b * 18) * MD * 2;
-        if (loader && more) dma_flat(lds_base + OFF_A, Wqn, 27, lane);
+        if (loader && more) dma_flat(lds_base + OFF_A, Wqn, 54, lane);     // (half of them behind the barrier below measured
+                                                                           // worse: x edge 1.9 + P5 1.65 us against 1.4 + 2.0)
         for (int i = tid; i < MF / 4; i += 512) *reinterpret_cast<float4*>(xs + i * 4) = *reinterpret_cast<const float4*>(graw + i * 4);
-        if (loader) { if (more) wait_dma<27>(); else wait_dma<0>(); }      // the W2 rows have landed
+        if (loader) { if (more) wait_dma<54>(); else wait_dma<0>(); }      // the W2 rows have landed
         bar();
-        if (loader && more) dma_flat(lds_base + OFF_A + 27 * 1024, Wqn + 27 * 1024, 27, lane);   // (about a microsecond of stream: gone before the x edge polls matter)
         if (wave < 6) {
             float acc[1];
             dot_rows<T, 1, 7>(acc, lds + OFF_B + wave * 7 * 1024, xs, lane);
