@@ -3,7 +3,7 @@
 //
 // The 5-launches-per-layer form (ar_decode.hip) spends ~3.8 us per launch outside its weight stream (boundary, first
 // byte, drain) and streams a layer's 52 MB in ~8 us: 27.4 us per layer.  Here 256 co-resident workgroups (one per CU, 8
-// waves) walk the layers themselves: 19.8 us per layer, 571 vs 733 us per token (profiles/r3_ar_persistent_step_log.txt).
+// waves) walk the layers themselves: 19.2 us per layer, 557 vs 733 us per token (profiles/r3_ar_persistent_step_log.txt).
 // The five launches become phases of the same arithmetic, row for row and lane for lane (a workgroup owns exactly the rows
 // workgroup blockIdx.x of the corresponding launch owned, with the same lane / k mapping and the same reduction trees, so
 // every dot product, RMSNorm sum and softmax merge is bit-identical to ar_decode.hip; tests/test_gpu_parity16.py):
@@ -475,16 +475,16 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
 
         mstamp(a.dbg, l, 4);
         // ------------------------------------------------------------------ P3: Wo rows -> x += .
-        if (wave < 6 && !gather<T, 2, true>(g + G_O + wave * 128, 64, 64, tl + E_O, graw + wave * 256, lane)) fail = 1;
+        // The gathered values ARE the products' operand (already rounded): they go straight to xs (its last readers, P1's
+        // products, are behind the post-P1 barrier), and the loader's wait sits in front of the one barrier of this phase.
+        if (wave < 6 && !gather<T, 2, true>(g + G_O + wave * 128, 64, 64, tl + E_O, xs + wave * 256, lane)) fail = 1;
+        if (loader) wait_dma<63>();                           // 18 Wo + 84 W1|W3 pieces issued since: <= 63 outstanding => the Wo rows landed
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 5);
-        // loader: the W2 rows that do not overlap the Wo rows (region B bytes [18 K, 42 K)); the rest behind the P4 gather
+        // loader: the W2 rows that do not overlap the Wo rows (region B bytes [18 K, 42 K)), while the others run their products
         const unsigned char* W2 = (const unsigned char*)a.w2 + ((int64_t)l * MD + (int64_t)b * 6) * MF * 2;
         if (loader) dma_flat(lds_base + OFF_B + 18 * 1024, W2 + 18 * 1024, 24, lane);
-        for (int i = tid; i < MD / 4; i += 512) *reinterpret_cast<float4*>(xs + i * 4) = *reinterpret_cast<const float4*>(graw + i * 4);
-        if (loader) wait_dma<63>();                           // 18 Wo + 84 W1|W3 + 24 W2 pieces issued since: <= 63 outstanding => the Wo rows landed
-        bar();
         if (wave < 3) {
             float acc[2];
             dot_rows<T, 2, 3>(acc, lds + OFF_B + wave * 6 * 1024, xs, lane);
@@ -510,12 +510,11 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 7);
-        // loader: W2 rows -> region B (the Wo rows were consumed in P3, before this barrier).  Issued here rather than behind
-        // the products: they then stream under P4's arithmetic instead of under the h edge (measured 4.6 vs 5.4 us for it)
-        if (loader) dma_flat(lds_base + OFF_B, W2, 18, lane);
         rms_to_xs<T, 7>(graw, nws, a.eps, xs, red[1], tid, lane, wave);
-        if (loader) wait_dma<42>();                           // the W1 | W3 rows have landed (the 42 W2 pieces are younger)
+        if (loader) wait_dma<24>();                           // the W1 | W3 rows have landed (the 24 W2 pieces of P3 are younger)
         bar();
+        // loader: the remaining W2 rows -> region B bytes [0, 18 K) (the Wo rows were consumed in P3)
+        if (loader) dma_flat(lds_base + OFF_B, W2, 18, lane);
         if (wave < 7) {
             float acc[4];
             dot_rows<T, 4, 3>(acc, lds + OFF_A + wave * 12 * 1024, xs, lane);
@@ -540,18 +539,14 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
 
         mstamp(a.dbg, l, 8);
         // ------------------------------------------------------------------ P5: W2 rows -> x += .
-        if (wave < 7 && !gather<T, 4, true>(g + G_H + wave * 256, 64, 64, tl + E_H, graw + wave * 512, lane)) fail = 1;
+        if (wave < 7 && !gather<T, 4, true>(g + G_H + wave * 256, 64, 64, tl + E_H, xs + wave * 512, lane)) fail = 1;   // (straight to xs, as in P3)
+        if (loader) wait_dma<0>();                            // the W2 rows have landed
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 9);
-        // loader: next layer's Wqkv rows -> region A (the W1 | W3 rows were consumed in P4, before this barrier)
+        // loader: next layer's Wqkv rows -> region A (the W1 | W3 rows were consumed in P4), while the others run their products
         const bool more = l + 1 < a.layer1;
-        const unsigned char* Wqn = Wq + ((int64_t)(l + 1) * 3 * MD + (int64_t)b * 18) * MD * 2;
-        if (loader && more) dma_flat(lds_base + OFF_A, Wqn, 54, lane);     // (half of them behind the barrier below measured
-                                                                           // worse: x edge 1.9 + P5 1.65 us against 1.4 + 2.0)
-        for (int i = tid; i < MF / 4; i += 512) *reinterpret_cast<float4*>(xs + i * 4) = *reinterpret_cast<const float4*>(graw + i * 4);
-        if (loader) { if (more) wait_dma<54>(); else wait_dma<0>(); }      // the W2 rows have landed
-        bar();
+        if (loader && more) dma_flat(lds_base + OFF_A, Wq + ((int64_t)(l + 1) * 3 * MD + (int64_t)b * 18) * MD * 2, 54, lane);
         if (wave < 6) {
             float acc[1];
             dot_rows<T, 1, 7>(acc, lds + OFF_B + wave * 7 * 1024, xs, lane);
