@@ -15,7 +15,9 @@ What is different from the reference by design (all exact):
 """
 from __future__ import annotations
 
+import contextlib
 import os
+import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
@@ -45,6 +47,29 @@ class ARSamplingConfig:
     eos_penalty_decay: float = 0.0
     n_phones_gen: Optional[int] = None
     div_mode: int = 0            # 0: logits / T (reference CPU kernel), 1: logits * (1/T) (reference GPU kernel)
+
+
+# Two persistent decode steps must never share the GPU: each needs all 256 CUs for its co-resident workgroups, and two of
+# them dispatched at the same time from two streams could each hold half of the CUs and spin for the other half (the spins
+# are bounded, so the result would be an error, not a hang).  Sessions therefore enqueue their persistent launches under
+# one per-device lock, each batch of launches behind the event that closed the previous session's batch.
+_MEGA_LOCK = threading.Lock()
+_MEGA_LAST: Dict[int, "torch.cuda.Event"] = {}
+
+
+@contextlib.contextmanager
+def _mega_exclusive(stream: "torch.cuda.Stream", dev: torch.device):
+    with _MEGA_LOCK:
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        last = _MEGA_LAST.get(key)
+        if last is not None:
+            stream.wait_event(last)
+        try:
+            yield
+        finally:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            _MEGA_LAST[key] = ev
 
 
 def _mega_default() -> bool:
@@ -299,12 +324,13 @@ class ARSession:
         while done < budget:
             n = min(poll, budget - done)
             need(done + n + 1)                                 # the n steps below read rows done+1 .. done+n
-            for _ in range(n):
-                if use_graph:
-                    self.graph.launch(st)
-                else:
-                    self.enqueue_layers(st)
-                    self.enqueue_head_and_sample(st)
+            with (_mega_exclusive(self.stream, self.m.dev) if self.mega else contextlib.nullcontext()):
+                for _ in range(n):
+                    if use_graph:
+                        self.graph.launch(st)
+                    else:
+                        self.enqueue_layers(st)
+                        self.enqueue_head_and_sample(st)
             done += n
             with torch.cuda.stream(self.stream):
                 flag = self.state.cpu()                        # syncs this stream only
@@ -454,12 +480,13 @@ class ARBatchSession:
         while done < budget:
             n = min(poll, budget - done)
             need(done + n + 1)
-            for _ in range(n):
-                if use_graph:
-                    self.graph.launch(st)
-                else:
-                    self.enqueue_layers(st)
-                    self.enqueue_head_and_sample(st)
+            with (_mega_exclusive(self.stream, self.m.dev) if self.mega else contextlib.nullcontext()):
+                for _ in range(n):
+                    if use_graph:
+                        self.graph.launch(st)
+                    else:
+                        self.enqueue_layers(st)
+                        self.enqueue_head_and_sample(st)
             done += n
             with torch.cuda.stream(self.stream):
                 flags = self.state.cpu()                       # syncs this stream only

@@ -206,6 +206,51 @@ def test_ar_persistent_step_is_bit_identical_to_the_per_launch_step(dev, full_bu
     print(f"AR persistent step {str(dt).split('.')[-1]} window {window}: {n_gen} steps bit-identical to the per-launch form")
 
 
+def test_two_persistent_sessions_decode_concurrently_from_two_threads(dev, full_bundle):
+    """Two batch-1 decodes on two streams from two host threads (a server with two workers): each persistent step needs every
+    CU, so their launches are serialised on the device (ar_engine._mega_exclusive); both must finish without a workgroup
+    ever giving up and give the tokens a lone run gives."""
+    import threading
+    from mars5_tts_amd import model, synth
+    b = full_bundle
+    tt, st = _toks(b)
+    a = b.ar_shape
+    lm = model.CodecLM(a.n_vocab, dim=a.dim, nhead=a.nhead, n_layers=a.n_layers, n_spk_layers=a.n_spk_layers,
+                       dim_ff_scale=a.hidden_dim / a.dim + 1e-9, sliding_window=a.sliding_window)
+    lm.load_state_dict(b.ar_ckpt["model"])
+    eng = lm.to(dev).set_engine_dtype(torch.bfloat16).engine()
+    ref_codes = synth.make_ref_codes(450, seed=7)
+    ref = ref_codes[0].T.contiguous()
+    prompt, _ = _bench_prompt(b, tt, st, ref_codes)
+    prompts = [prompt, prompt[:-7]]
+    N = 96
+    noise = torch.ones(N, a.n_vocab, device=dev)
+
+    def run(p):
+        s = _session(eng, b, st, int(p.shape[0]), N, noise, True)
+        assert s.mega
+        s.prefill(p, ref)
+        return s.decode(use_graph=True).cpu().tolist()
+
+    alone = [run(p) for p in prompts]
+    out, errs = [None, None], []
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(dev)
+            out[i] = run(prompts[i])
+        except Exception as e:                      # noqa: BLE001 - reported below
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs, errs
+    assert out == alone
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_ar_tiny_16bit_vs_cpu_oracle(dev, tiny_bundle, dt):
     """The same comparison at test scale against the oracle on the CPU (the pinned instrument itself, CPU libm): the
