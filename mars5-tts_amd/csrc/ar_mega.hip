@@ -3,13 +3,13 @@
 //
 // The 5-launches-per-layer form (ar_decode.hip) spends ~3.8 us per launch outside its weight stream (boundary, first
 // byte, drain) and streams a layer's 52 MB in ~8 us: 27.4 us per layer.  Here 256 co-resident workgroups (one per CU, 8
-// waves) walk the layers themselves: 19.2 us per layer, 557 vs 733 us per token (profiles/r3_ar_persistent_step_log.txt).
+// waves) walk the layers themselves: 19.0 us per layer, 550 vs 737 us per token (profiles/r3_ar_persistent_step_log.txt).
 // The five launches become phases of the same arithmetic, row for row and lane for lane (a workgroup owns exactly the rows
 // workgroup blockIdx.x of the corresponding launch owned, with the same lane / k mapping and the same reduction trees, so
 // every dot product, RMSNorm sum and softmax merge is bit-identical to ar_decode.hip; tests/test_gpu_parity16.py):
-//   P1 RMSNorm -> Wqkv rows -> RoPE -> KV-cache slot + {q, k, v} of this token          (waves 0-2: 6 rows each)
+//   P1 RMSNorm -> Wqkv rows -> RoPE -> KV-cache slot + {q, k, v} of this token          (18 rows: 9 pairs over waves 0-6)
 //   P2 workgroups 0..191: (head, key split) cache scan;  192..215: merge the 8 splits of one head
-//   P3 Wo rows -> x += .                                                                  (waves 0-2: 2 rows each)
+//   P3 Wo rows -> x += .                                                                  (waves 0-5: 1 row each)
 //   P4 RMSNorm -> interleaved (W1, W3) rows -> silu(a) * b                                (waves 0-6: 4 rows each)
 //   P5 W2 rows -> x += .                                                                  (waves 0-5: 1 row each)
 //
@@ -245,10 +245,12 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
     if (tid < 6) xloc[tid] = a.xres[b * 6 + tid];
 
     // RoPE factors of this lane's (q | k) row pair: the same in every layer
-    const int qrow0 = (b * 3 + wave) * 6;                       // P1 rows of this wave (waves 0-2)
+    // P1: the workgroup's 18 Wqkv rows = 9 (even, odd) pairs.  A row's product and reduction are the same whichever wave
+    // runs them, so the pairs are spread over all 7 compute waves (2, 2, 1, 1, 1, 1, 1) instead of the 3 x 3 of the launch.
+    const int qpair0 = wave < 2 ? 2 * wave : wave + 2, qnp = wave < 2 ? 2 : 1;      // first pair, pairs of this wave
     float rcs = 1.f, rsn = 0.f;
-    if (wave < 3 && lane < 3) {
-        const int n = qrow0 + 2 * lane;
+    if (wave < 7 && lane < qnp) {
+        const int n = b * 18 + 2 * (qpair0 + lane);
         if (n < 2 * MD) {
             const int d = (n % MD) & 63;
             rcs = a.rope[((int64_t)pos * 32 + (d >> 1)) * 2];
@@ -294,16 +296,23 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 1);
         rms_to_xs<T, 3>(graw, nws, a.eps, xs, red[0], tid, lane, wave);
+        mstamp(a.dbg, l, 11);
         if (loader) wait_dma<18>();                           // the Wqkv rows have landed (the 18 Wo pieces are younger)
         bar();
-        if (wave < 3) {
-            float acc[6];
-            dot_rows<T, 6, 3>(acc, lds + OFF_A + wave * 18 * 1024, xs, lane);
-            if (lane < 3) {
-                float va = 0.f, vb = 0.f;
-#pragma unroll
-                for (int r = 0; r + 1 < 6; r += 2) if (lane == r / 2) { va = acc[r]; vb = acc[r + 1]; }
-                const int n = qrow0 + 2 * lane;
+        mstamp(a.dbg, l, 12);
+        if (wave < 7) {
+            float acc[4];
+            const unsigned char* rows = lds + OFF_A + qpair0 * 2 * 3 * 1024;
+            if (wave < 2) {
+                dot_rows<T, 4, 3>(acc, rows, xs, lane);
+            } else {
+                float a2[2];
+                dot_rows<T, 2, 3>(a2, rows, xs, lane);
+                acc[0] = a2[0]; acc[1] = a2[1]; acc[2] = 0.f; acc[3] = 0.f;
+            }
+            if (lane < qnp) {
+                const float va = lane == 0 ? acc[0] : acc[2], vb = lane == 0 ? acc[1] : acc[3];
+                const int n = b * 18 + 2 * (qpair0 + lane);
                 const int sec = n / MD, c = n - sec * MD, h = c >> 6, d = c & 63;
                 const float x0 = round_dt<T>(va), x1 = round_dt<T>(vb);
                 float o0 = x0, o1 = x1;
@@ -321,9 +330,10 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
                 unsigned short u0, u1;
                 __builtin_memcpy(&u0, &s0, 2);
                 __builtin_memcpy(&u1, &s1, 2);
-                pub[wave * 3 + lane] = pack16(u0, u1);        // granule (n >> 1) = b * 9 + wave * 3 + lane
+                pub[qpair0 + lane] = pack16(u0, u1);          // granule (n >> 1) = b * 9 + pair
             }
         }
+        mstamp(a.dbg, l, 13);
         bar();                                                // every wave is done with the Wqkv rows: region A is free
         // One store instruction publishes the workgroup's outputs of a phase.  Measured: an edge costs ~0.3 us per store
         // instruction (of different waves / CUs) that hits the same 128-byte line -- 1.3 us for the merged attention output
@@ -485,16 +495,10 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         // loader: the W2 rows that do not overlap the Wo rows (region B bytes [18 K, 42 K)), while the others run their products
         const unsigned char* W2 = (const unsigned char*)a.w2 + ((int64_t)l * MD + (int64_t)b * 6) * MF * 2;
         if (loader) dma_flat(lds_base + OFF_B + 18 * 1024, W2 + 18 * 1024, 24, lane);
-        if (wave < 3) {
-            float acc[2];
-            dot_rows<T, 2, 3>(acc, lds + OFF_B + wave * 6 * 1024, xs, lane);
-            if (lane < 2) {
-                float v = 0.f;
-#pragma unroll
-                for (int r = 0; r < 2; ++r) if (lane == r) v = acc[r];
-                const float x1 = xloc[wave * 2 + lane] + v;
-                xloc[wave * 2 + lane] = x1;
-            }
+        if (wave < 6) {                                       // one row per wave (the launch ran 3 waves x 2 rows: same sums)
+            float acc[1];
+            dot_rows<T, 1, 3>(acc, lds + OFF_B + wave * 3 * 1024, xs, lane);
+            if (lane == 0) xloc[wave] = xloc[wave] + acc[0];
         }
         bar();
         if (wave == 0 && lane < 6) publish(g + G_X1, b * 6 + lane, xloc[lane], tl + E_X1);
@@ -511,8 +515,10 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 7);
         rms_to_xs<T, 7>(graw, nws, a.eps, xs, red[1], tid, lane, wave);
+        mstamp(a.dbg, l, 14);
         if (loader) wait_dma<24>();                           // the W1 | W3 rows have landed (the 24 W2 pieces of P3 are younger)
         bar();
+        mstamp(a.dbg, l, 15);
         // loader: the remaining W2 rows -> region B bytes [0, 18 K) (the Wo rows were consumed in P3)
         if (loader) dma_flat(lds_base + OFF_B, W2, 18, lane);
         if (wave < 7) {

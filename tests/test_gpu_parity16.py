@@ -154,13 +154,14 @@ def _session(eng, b, st, P, N, noise, persistent):
     return s
 
 
-@pytest.mark.parametrize("window", [3000, 96])
+@pytest.mark.parametrize("window,plen", [(3000, 0), (96, 60), (3000, 1400)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_ar_persistent_step_is_bit_identical_to_the_per_launch_step(dev, full_bundle, dt, window):
+def test_ar_persistent_step_is_bit_identical_to_the_per_launch_step(dev, full_bundle, dt, window, plen):
     """The one-launch form of the decode step (csrc/ar_mega.hip: 256 co-resident workgroups, tagged-granule edges, LDS-DMA
     weight prefetch) against the five-launches-per-layer form it replaces: every step's logits bit for bit (eager), the
     same tokens from the hipGraph replays, no workgroup ever gave up waiting.  window = 96: a 60-token prompt and 200
-    decoded positions wrap the rotating KV buffer twice (BASELINE configs[4]'s mechanism at the real width)."""
+    decoded positions wrap the rotating KV buffer twice (BASELINE configs[4]'s mechanism at the real width); a 1400-token
+    prompt makes every key split longer than one 128-position pass of the cache scan (its multi-pass loop)."""
     from mars5_tts_amd import _lib as L, model, synth
     b = full_bundle
     tt, st = _toks(b)
@@ -172,8 +173,10 @@ def test_ar_persistent_step_is_bit_identical_to_the_per_launch_step(dev, full_bu
     ref_codes = synth.make_ref_codes(450, seed=7)
     ref = ref_codes[0].T.contiguous()
     prompt, _ = _bench_prompt(b, tt, st, ref_codes)
-    if window < 3000:
-        prompt = prompt[-60:]
+    if plen and plen < prompt.shape[0]:
+        prompt = prompt[-plen:]
+    elif plen:
+        prompt = torch.cat([prompt] + [prompt[-450:]] * ((plen - int(prompt.shape[0]) + 449) // 450))[:plen]
     P, N = int(prompt.shape[0]), 200
     noise = torch.ones(N, a.n_vocab, device=dev)
     runs = {}
@@ -203,7 +206,7 @@ def test_ar_persistent_step_is_bit_identical_to_the_per_launch_step(dev, full_bu
     s.prefill(prompt, ref)
     tok = s.decode(use_graph=True).cpu()
     assert s.mega and tok.tolist() == runs[False][1].tolist()
-    print(f"AR persistent step {str(dt).split('.')[-1]} window {window}: {n_gen} steps bit-identical to the per-launch form")
+    print(f"AR persistent step {str(dt).split('.')[-1]} window {window} prompt {P}: {n_gen} steps bit-identical to the per-launch form")
 
 
 def test_two_persistent_sessions_decode_concurrently_from_two_threads(dev, full_bundle):

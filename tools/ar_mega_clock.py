@@ -32,14 +32,15 @@ st = sess.stream.cuda_stream
 sess.enqueue_head_and_sample(st)
 acc = None
 names = ["layer start", "P1 gathered", "P1 done", "P2 gathered (q k v)", "P2 done", "P3 gathered (O)", "P3 done",
-         "P4 gathered (x)", "P4 done", "P5 gathered (h)", "P5 done"]
+         "P4 gathered (x)", "P4 done", "P5 gathered (h)", "P5 done", "  P1 normed", "  P1 weights landed", "  P1 products done",
+         "  P4 normed", "  P4 weights landed"]
 n = 0
 for step in range(12):
     sess.enqueue_layers(st)
     sess.enqueue_head_and_sample(st)
     sess.stream.synchronize()
     if step >= 2:
-        d = sess.mega_dbg.cpu().double()[:, 2:26, :11, :]       # (workgroup, layers, stamps, waves)
+        d = sess.mega_dbg.cpu().double()[:, 2:26, :16, :]       # (workgroup, layers, stamps, waves)
         rel = (d - d[0:1, :, 0:1, 0:1]) / 100.0                  # us since workgroup 0 / wave 0's layer start
         acc = rel.mean(1) if acc is None else acc + rel.mean(1)
         n += 1
