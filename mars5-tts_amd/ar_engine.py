@@ -480,13 +480,12 @@ class ARBatchSession:
         while done < budget:
             n = min(poll, budget - done)
             need(done + n + 1)
-            with (_mega_exclusive(self.stream, self.m.dev) if self.mega else contextlib.nullcontext()):
-                for _ in range(n):
-                    if use_graph:
-                        self.graph.launch(st)
-                    else:
-                        self.enqueue_layers(st)
-                        self.enqueue_head_and_sample(st)
+            for _ in range(n):
+                if use_graph:
+                    self.graph.launch(st)
+                else:
+                    self.enqueue_layers(st)
+                    self.enqueue_head_and_sample(st)
             done += n
             with torch.cuda.stream(self.stream):
                 flags = self.state.cpu()                       # syncs this stream only
