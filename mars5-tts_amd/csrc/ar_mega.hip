@@ -52,35 +52,6 @@ constexpr int G_X2 = 0, G_QKV = G_X2 + MD, G_PART = G_QKV + 3 * MD / 2, G_O = G_
 static_assert(G_WORDS == M5_AR_MEGA_GRANULES, "granule buffer size in the header");
 constexpr int SPIN_LIMIT = 1 << 16;
 
-// Cross-lane exchanges without the LDS crossbar.  `__shfl_xor` compiles to ds_bpermute_b32 (address arithmetic + an LDS-pipe
-// round trip + a wait, ~100 cycles per step, and a phase ends in a chain of 6 dependent steps per row); the same partners
-// are reachable with DPP modifiers on the add (xor 1, 2: quad_perm; xor 4: quad reverse then row_half_mirror; xor 8:
-// row_ror:8) and gfx950's v_permlane16_swap / v_permlane32_swap (xor 16, 32).  Same partners, same order, commutative
-// adds: bit-identical to common.h's wave_sum (checked lane by lane on the hardware before use).
-template <int CTRL>
-__device__ inline float dppf(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true)); }
-__device__ inline float lane_xor1(float v) { return dppf<0xB1>(v); }
-__device__ inline float lane_xor2(float v) { return dppf<0x4E>(v); }
-__device__ inline float lane_xor4(float v) { return dppf<0x141>(dppf<0x1B>(v)); }
-__device__ inline float lane_xor8(float v) { return dppf<0x128>(v); }
-__device__ inline float lane_xor16(float v, int lane) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float((lane & 16) ? r[0] : r[1]);
-}
-__device__ inline float lane_xor32(float v, int lane) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float((lane & 32) ? r[0] : r[1]);
-}
-__device__ inline float wsum(float v) {                     // = wave_sum: v += partner for xor 32, 16, 8, 4, 2, 1
-    { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-    { const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }
-    v += lane_xor8(v);
-    v += lane_xor4(v);
-    v += lane_xor2(v);
-    v += lane_xor1(v);
-    return v;
-}
-
 // Workgroup barrier that orders LDS only (every LDS operation of the wave retired, then s_barrier).  __syncthreads() would
 // also wait for the VM counter, i.e. for the weight rows a compute wave has in flight for LATER phases and for its granule
 // stores -- exactly the overlap this kernel exists for.  Cross-workgroup data only travels in granules (single atomic
@@ -204,7 +175,7 @@ __device__ inline void dot_rows(float (&acc)[R], const unsigned char* slice, con
         }
     }
 #pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = wsum(acc[r]);
+    for (int r = 0; r < R; ++r) acc[r] = wave_sum(acc[r]);
 }
 
 // RMSNorm of the gathered vector (graw, MD values) into xs with the thread mapping of a gemv_stream launch of NWP waves
@@ -225,7 +196,7 @@ __device__ inline void rms_to_xs(const float* graw, const float* nws, float eps,
 #pragma unroll
         for (int j = 0; j < JN; ++j)
             if (tid + j * NT < NCH) ss += xin[j].x * xin[j].x + xin[j].y * xin[j].y + xin[j].z * xin[j].z + xin[j].w * xin[j].w;
-        ss = wsum(ss);
+        ss = wave_sum(ss);
     }
     if (wave < NWP && lane == 0) red[wave] = ss;             // (the caller alternates two `red` arrays: no barrier needed before)
     bar();
@@ -463,8 +434,8 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
                     m = mn;
                 };
                 merge_with([&](float v) { return lane_xor8(v); });
-                merge_with([&](float v) { return lane_xor16(v, lane); });
-                merge_with([&](float v) { return lane_xor32(v, lane); });
+                merge_with([&](float v) { return lane_xor16(v); });
+                merge_with([&](float v) { return lane_xor32(v); });
                 if (grp == 0) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sm[wave][sub][e] = o[e];

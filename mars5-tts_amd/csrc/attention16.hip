@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);      // -> v_max3_f32
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * sc2;
+        mx = fmaxf(mx, lane_xor32(mx)) * sc2;
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);      // m_run = -inf -> 0
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
     }
 
     // ---- normalise and store: oacc[db][r] = O[query l31][d = 32 db + (r&3) + 8 (r>>2) + 4 hh]
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = l_run + lane_xor32(l_run);
     if (qpos < p.Sq) {
         const float inv = 1.0f / l_tot;
         st* Og = reinterpret_cast<st*>(p.o) + b * p.o_bs + (int64_t)qpos * p.o_rs + h * 64;

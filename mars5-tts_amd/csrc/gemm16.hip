@@ -392,15 +392,15 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     mx = fmaxf(mx, vs);
                 }
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = fmaxf(mx, lane_xor16(mx));
+            mx = fmaxf(mx, lane_xor32(mx));
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < XA_MAX_KT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(sc[t][r] - mx); sc[t][r] = e; sum += e; }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum += lane_xor16(sum);
+            sum += lane_xor32(sum);
             const float inv = __builtin_amdgcn_rcpf(sum);
             f4_t o[4];
 #pragma unroll
@@ -463,16 +463,16 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j) sm += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
-            sm += __shfl_xor(sm, 16);
-            sm += __shfl_xor(sm, 32);
+            sm += lane_xor16(sm);
+            sm += lane_xor32(sm);
             mean_w[i] = sm * (1.0f / (TN * 16));
             float q = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float d = v[i][j][r] - mean_w[i]; q += d * d; }
-            q += __shfl_xor(q, 16);
-            q += __shfl_xor(q, 32);
+            q += lane_xor16(q);
+            q += lane_xor32(q);
             m2_w[i] = q;
         }
         __syncthreads();                                      // the stage buffers are free
@@ -690,15 +690,15 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[j][r] = (acc[i][j][r] + bvs[j][r]) * 1.4426950408889634f; mx = fmaxf(mx, v[j][r]); }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = fmaxf(mx, lane_xor16(mx));
+            mx = fmaxf(mx, lane_xor32(mx));
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { v[j][r] = __builtin_amdgcn_exp2f(v[j][r] - mx); sum += v[j][r]; }
-            sum += __shfl_xor(sum, 16);
-            sum += __shfl_xor(sum, 32);
+            sum += lane_xor16(sum);
+            sum += lane_xor32(sum);
             const float inv = 1.0f / sum;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
