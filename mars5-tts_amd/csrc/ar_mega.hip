@@ -3,7 +3,7 @@
 //
 // The 5-launches-per-layer form (ar_decode.hip) spends ~3.8 us per launch outside its weight stream (boundary, first
 // byte, drain) and streams a layer's 52 MB in ~8 us: 27.4 us per layer.  Here 256 co-resident workgroups (one per CU, 8
-// waves) walk the layers themselves: 19.0 us per layer, 550 vs 737 us per token (profiles/r3_ar_persistent_step_log.txt).
+// waves) walk the layers themselves: 17.8 us per layer, 520 vs 740 us per token (profiles/r3_ar_persistent_step_log.txt).
 // The five launches become phases of the same arithmetic, row for row and lane for lane (a workgroup owns exactly the rows
 // workgroup blockIdx.x of the corresponding launch owned, with the same lane / k mapping and the same reduction trees, so
 // every dot product, RMSNorm sum and softmax merge is bit-identical to ar_decode.hip; tests/test_gpu_parity16.py):
