@@ -56,6 +56,27 @@ def test_argument_validation_returns_status_codes():
         _lib.check(_lib.M5_ERR_UNSUPPORTED, "unit test")
 
 
+def test_persistent_decode_step_refuses_what_it_cannot_run():
+    """m5_ar_layers_persistent validates before it touches the device: missing pointers are an argument error, any geometry
+    but the CodecLM one (dim 1536, hidden 3584, 24 heads), fp32 operands or more than 31 layers are 'unsupported' -- the
+    status on which ARSession falls back to the per-launch step -- and nothing is launched in either case."""
+    from mars5_tts_amd import _lib as L
+    a = L.ArMegaArgs()
+    assert L.lib.m5_ar_layers_persistent(L.BF16, C.byref(a), None) == L.M5_ERR_ARG
+    buf = (C.c_uint64 * 4)()
+    ptr = C.addressof(buf)
+    for f, _ in L.ArMegaArgs._fields_:
+        if f not in ("eps", "dim", "hidden", "n_heads", "layer0", "layer1", "w_alloc", "window", "scale", "dbg"):
+            setattr(a, f, ptr)
+    a.dim, a.hidden, a.n_heads, a.layer0, a.layer1, a.w_alloc, a.window = 1024, 3584, 24, 0, 26, 64, 64
+    assert L.lib.m5_ar_layers_persistent(L.BF16, C.byref(a), None) == L.M5_ERR_UNSUPPORTED      # wrong width
+    a.dim = 1536
+    assert L.lib.m5_ar_layers_persistent(L.F32, C.byref(a), None) == L.M5_ERR_UNSUPPORTED       # parity mode: per-launch form
+    a.layer1 = 40
+    assert L.lib.m5_ar_layers_persistent(L.BF16, C.byref(a), None) == L.M5_ERR_UNSUPPORTED      # the tag has 5 layer bits
+    assert L.AR_MEGA_GRANULES == int(re.search(r"#define M5_AR_MEGA_GRANULES (\d+)", open(os.path.join(ROOT, "include", "mars5_hip.h")).read()).group(1))
+
+
 def test_inference_config_surface_matches_reference():
     """21 fields, names and defaults of reference inference.py:24-77."""
     from inference import InferenceConfig
