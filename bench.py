@@ -429,7 +429,13 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     form = ("3 launches: ar_mega_kernel (26 layers, 256 persistent workgroups, tagged-granule edges, LDS-DMA weight prefetch) + head + sampler, hipGraph"
             if ars.get("persistent") else
             "132 launches: 26 x {gemv qkv+rope, attn_decode, gemv wo, gemv w13+swiglu, gemv w2} + head + sampler, hipGraph")
-    ar = dict(bound="hbm", kernel=f"AR decode step ({form})", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+    ar_traffic = None
+    try:        # HBM-side bytes of one persistent step from the committed PMC passes (profiles/traffic.json; bf16, prompt ~490)
+        if ars.get("persistent") and dtype_name == "bf16":
+            ar_traffic = next(v["bytes_per_launch"] for v in tj.values() if isinstance(v, dict) and v.get("label") == "ar_mega_kernel")
+    except Exception:
+        ar_traffic = None
+    ar = dict(bound="hbm", kernel=f"AR decode step ({form})", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", traffic=ar_traffic,
               frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_token=int(bytes_tok), us_per_token=round(1e3 * tok_ms, 1))
     return roof, ar, nar, kernels
 

@@ -10,7 +10,7 @@ for f in sorted(glob.glob(root + "/**/*counter_collection.csv", recursive=True))
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("==", f)
     for k, d in acc.items():
-        if not any(t in k[0] for t in ("gemm16", "attn", "skinny", "gemv", "sample_kernel")):
+        if not any(t in k[0] for t in ("gemm16", "attn", "skinny", "gemv", "sample_kernel", "ar_mega")):
             continue
         print(k[0], "grid", k[1], "n", len(next(iter(d.values()))))
         for c, v in d.items():
