@@ -56,7 +56,51 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ar-batch", type=int, default=32)
     ap.add_argument("--nar-batch", type=int, default=8)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous + rank census only, then exit (no model, no GPU work): with --backend gloo this is how the "
+                         "CPU tests check that `--gpus N` really starts N ranks")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on the GPU box)")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves, one process per GPU,
+    through torch.distributed.run on 127.0.0.1 (what the driver's command line does), and return its exit code.  Fails
+    loudly when fewer than N devices are visible (a silent N = 1 run would be recorded as an N-GPU number)."""
+    import socket
+    import subprocess
+    if args.backend == "nccl":
+        n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if n_dev < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible on this node; refusing to run", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # RCCL needs dmabuf IPC on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, world: int, rank: int) -> None:
+    """--launch-check: init the process group, one all-gather census, rank 0 prints what the collective saw."""
+    import torch.distributed as dist
+    from mars5_tts_amd import sharding as sh
+    if args.backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    if world > 1:
+        dist.init_process_group(backend=args.backend)
+        census = sh.rank_census()
+        seen = sh.LAST_STATS["ranks_seen"]
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        census, seen = [dict(rank=0)], 1
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": seen, "requested": args.gpus, "world_size_env": world,
+                          "collective": {"backend": args.backend if world > 1 else None, "ranks_seen": seen, "census": census}}), flush=True)
 
 
 WORDS = ("the quick brown rat jumped over lazy dogs twice while seven silver foxes watched from behind a quiet river bank and "
@@ -138,15 +182,18 @@ def main_c3(args, m, dev, world, rank, barrier):
         frames += nf
     barrier()
     elapsed = time.perf_counter() - t0
+    ranks_seen = world
     if world > 1:
-        from mars5_tts_amd.sharding import reduce_timing
-        elapsed, frames = reduce_timing(elapsed, float(frames))
+        from mars5_tts_amd import sharding as sh
+        elapsed, frames = sh.reduce_timing(elapsed, float(frames))
+        sh.rank_census()
+        ranks_seen = sh.LAST_STATS["ranks_seen"]
     if rank != 0:
         return
     ref_frames = [int(r.shape[-1]) for r in refs]
     out = {
         "metric": "generated audio seconds/sec (RTF), deep-clone", "value": round(frames / 75.0 / elapsed, 4), "unit": "audio_s/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "n_gpus": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "p50_batch_latency_s": round(statistics.median(lat), 3),
         "config": {"workload": f"BASELINE configs[2]: batch of {args.batch} mixed-length requests per GPU, deep-clone, temperature=0.7 "
@@ -245,7 +292,7 @@ def main_c4(args, m, dev, world, rank, barrier):
     ref_frames = [int(r.ref_codes.shape[0]) for r in reqs]
     out = {
         "metric": "generated audio seconds/sec (RTF), deep-clone", "value": round(frames / 75.0 / elapsed, 4), "unit": "audio_s/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "n_gpus": (collective["ranks_seen"] if collective else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[3]: {n_total} mixed-length deep-clone requests ({args.batch} per GPU) built on rank 0, "
                                f"scattered over {world} rank(s) by estimated cost, batch-1 hot path per request, results gathered on rank 0; "
@@ -296,10 +343,10 @@ def run_utterance(m, ref_codes, cfg, seed):
 
 # ------------------------------------------------------------------------------------ roofline
 def roofline_leg(m, ref_codes, cfg, dtype_name):
-    """Per-kernel durations of the NAR reverse step at the bench shapes: the forward of a fresh session is replayed eagerly
-    with a HIP event pair around every launch of every kernel class (GEMMs by epilogue and shape, attention, LayerNorm, the
-    absorbed cross-attention operand build, embedding) on the engine's own stream; the dominant class by total time is
-    reported against its roofline (profiles/ holds the rocprofv3 summary of the same command for cross-checking).  Plus the
+    """Per-kernel durations of the NAR reverse step at the bench shapes, measured INSIDE a replayed hipGraph of the step's
+    forward (clock-stamp launches between the launches: see below); launches are grouped the way rocprofv3 --stats groups
+    them (by kernel name: every shape of one GEMM epilogue is one kernel) and the kernel with the largest total is reported
+    against its roofline, per shape under `shapes` (profiles/ holds the rocprofv3 summary of the same command).  Plus the
     event-timed AR decode graph replays of the last utterance."""
     from mars5_tts_amd import ar_engine, nar_engine, ops
     from mars5_tts_amd import _lib as L
@@ -317,21 +364,20 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     mm = torch.zeros(S, 8, dtype=torch.uint8)
     mm[:, 0] = 1
     mm[:off] = 1
-    sess.prepare(c_text, ref_codes[0].T.contiguous(), x, z, mm, off, [199, 150, 100, 50])
+    sess.prepare(c_text, ref_codes[0].T.contiguous(), x, z, mm, off, list(range(199, 199 - 24, -1)))
     st = sess.stream.cuda_stream
     es = 2 if dtype_name != "f32" else 4
-    rec = []
     names_epi = {L.EPI_F32: "F32", L.EPI_RESIDUAL: "RESIDUAL", L.EPI_SWIGLU: "SWIGLU", L.EPI_QKV: "QKV", L.EPI_DT: "DT", L.EPI_SILU_DT: "SILU"}
     orig = {k: getattr(ops, k) for k in ("gemm", "attention", "layernorm", "xattn_scores", "xattn_absorb", "chunked_embed")}
 
+    slots = torch.zeros(2048, dtype=torch.int64, device=m.device)
+    labels = []
+
     def timed(fn, label, flops, hbm_bytes):
         def w(*a, **kw):
-            e0, e1 = ops.Event(), ops.Event()
-            e0.record(st)
+            ops.clock_stamp(slots, len(labels), stream=st)
+            labels.append((label(*a, **kw), flops(*a, **kw), hbm_bytes(*a, **kw)))
             fn(*a, **kw)
-            e1.record(st)
-            lab, fl, by = label(*a, **kw), flops(*a, **kw), hbm_bytes(*a, **kw)
-            rec.append((lab, fl, by, e0, e1))
         return w
 
     def gemm_label(a, w_, out, epi, **kw):
@@ -347,6 +393,7 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
         c = Mv * N * (8 if epi == L.EPI_RESIDUAL else (4 if epi == L.EPI_F32 else es)) // (2 if epi == L.EPI_SWIGLU else 1)
         return float(Mv * K * es + N * K * es * kw.get("batch", 1) + c)
 
+    orig["mark"] = ops.mark
     ops.gemm = timed(orig["gemm"], gemm_label, gemm_flops, gemm_bytes)
     ops.attention = timed(orig["attention"], lambda dt, a_, **kw: f"attn16_kernel Sq={a_.Sq} Sk={a_.Sk}",
                           lambda dt, a_, **kw: 4.0 * a_.B * a_.H * a_.Sq * a_.Sk * 64,
@@ -362,46 +409,78 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
                              lambda dt, ts, tl, nl, nsq, H, D, Lp, step, scale, **kw: float(nl * (2 * D * D * es + nsq * 2 * H * Lp * D * es)))
     ops.chunked_embed = timed(orig["chunked_embed"], lambda out, *a, **kw: "chunked_embed_kernel", lambda *a, **kw: 0.0,
                               lambda out, *a, **kw: float(out.numel() * 4 * 2))
-    # Eager replay of three steps, an event pair around every launch.  (Event nodes INSIDE the captured step graph would give
-    # replay-context timings, but this HIP build cannot query events recorded during capture: hipEventSynchronize fails with
-    # invalid handle, measured in round 2.)  A pair brackets the launch plus the two packet hand-overs around it; that
-    # overhead is measured with pairs around nothing and subtracted.
+
+    def mark(label, stream=None):
+        ops.clock_stamp(slots, len(labels), stream=st)
+        labels.append((label, 0.0, 0.0))
+    ops.mark = mark
+    # In-graph timing.  The forward of one reverse step is captured with a one-lane clock-stamp launch (100 MHz wall clock ->
+    # device memory, m5_clock_stamp) in front of every launch: in the replay, stamp i+1 runs when launch i has drained, so
+    # t[i+1] - t[i] - (the same difference with nothing in between) is what launch i occupies in the replay, boundary
+    # included.  (HIP events cannot be read back when recorded during a capture on this stack, and an eager event pair times
+    # the launch on an otherwise idle GPU at higher clocks: 12 % rosier than rocprofv3 of the graph, round 2.)
+    n_rep = 8
     try:
-        cal = []
-        for _ in range(64):
-            e0, e1 = ops.Event(), ops.Event()
-            e0.record(st)
-            e1.record(st)
-            cal.append((e0, e1))
-        sess.stream.synchronize()
-        pair_overhead_ms = sorted(e0.elapsed_ms(e1) for e0, e1 in cal)[len(cal) // 2]
-        for _ in range(3):
-            sess.enqueue_forward(st)
-            ops.add_int(sess.step_ptr, 1, stream=st)
-        sess.stream.synchronize()
-        per = [(lab, fl, by, max(e0.elapsed_ms(e1) - pair_overhead_ms, 1e-4)) for lab, fl, by, e0, e1 in rec]
+        ops.Graph.begin(st)
+        sess.enqueue_forward(st)
+        ops.clock_stamp(slots, len(labels), stream=st)
+        g_fwd = ops.Graph().end(st)
     finally:
         for k, v in orig.items():
             setattr(ops, k, v)
-    timing = f"eager replay, HIP-event pair per launch minus the empty-pair overhead ({1e3 * pair_overhead_ms:.2f} us)"
-    n_rep = 3
-    agg = {}
+    n_l = len(labels)
+    cal_slots = torch.zeros(64, dtype=torch.int64, device=m.device)
+    ops.Graph.begin(st)
+    for i in range(64):
+        ops.clock_stamp(cal_slots, i, stream=st)
+    g_cal = ops.Graph().end(st)
+    ops.Graph.begin(st)                      # the same forward without stamps: what the stamps add, and the whole-step time
+    sess.enqueue_forward(st)
+    g_plain = ops.Graph().end(st)
+    g_cal.launch(st)
+    g_cal.launch(st)
+    sess.stream.synchronize()
+    cd = (cal_slots[1:] - cal_slots[:-1]).cpu().tolist()
+    stamp_us = sorted(cd)[len(cd) // 2] * 0.01
+    acc_us = [0.0] * n_l
+    for r in range(n_rep + 2):
+        g_fwd.launch(st)
+        ops.add_int(sess.step_ptr, 1, stream=st)
+        sess.stream.synchronize()
+        if r >= 2:
+            t = slots[: n_l + 1].cpu().tolist()
+            for i in range(n_l):
+                acc_us[i] += max((t[i + 1] - t[i]) * 0.01 - stamp_us, 0.01)
+    e0, e1 = ops.Event(), ops.Event()
+    g_plain.launch(st)
+    e0.record(st)
+    for r in range(n_rep):
+        g_plain.launch(st)
+    e1.record(st)
+    sess.stream.synchronize()
+    fwd_plain_us = 1e3 * e0.elapsed_ms(e1) / n_rep
+    per = [(lab, fl, by, 1e-3 * acc_us[i] / n_rep) for i, (lab, fl, by) in enumerate(labels)]
+    timing = (f"in-graph: clock-stamp launches between the launches of the captured step, {n_rep} replays; stamp-to-stamp overhead "
+              f"{stamp_us:.2f} us subtracted per interval")
+    agg, cls = {}, {}
     for lab, fl, by, ms in per:
-        a = agg.setdefault(lab, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
-        a["ms"] += ms
-        a["flops"] += fl
-        a["bytes"] += by
-        a["n"] += 1
-    kernels = {k: dict(launches_per_step=v["n"] // n_rep, avg_us=round(1e3 * v["ms"] / v["n"], 2), tflops=round(v["flops"] / v["ms"] / 1e9, 1),
-                       alg_gbs=round(v["bytes"] / v["ms"] / 1e6, 1), step_share_us=round(1e3 * v["ms"] / n_rep, 1)) for k, v in agg.items()}
+        for d, key in ((agg, lab), (cls, lab.split(" M=")[0].split(" Sq=")[0].split(" D=")[0].split(" layers=")[0])):
+            a = d.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+            a["ms"] += ms
+            a["flops"] += fl
+            a["bytes"] += by
+            a["n"] += 1
+    kernels = {k: dict(launches_per_step=v["n"], avg_us=round(1e3 * v["ms"] / v["n"], 2), tflops=round(v["flops"] / v["ms"] / 1e9, 1),
+                       alg_gbs=round(v["bytes"] / v["ms"] / 1e6, 1), step_share_us=round(1e3 * v["ms"], 1)) for k, v in agg.items()}
     peak = PEAK_MFMA_TFLOPS[dtype_name]
-    dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
+    # the dominant kernel = the kernel NAME with the largest total, as rocprofv3 --stats groups them (all shapes of one epilogue)
+    dom = max(cls.items(), key=lambda kv: kv[1]["ms"])
     mfma_bound = dom[1]["flops"] > 0
     traffic = None
     try:        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json), same shapes
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         for k, v in tj.items():
-            if isinstance(v, dict) and v.get("label") == dom[0] and dtype_name == "bf16":
+            if isinstance(v, dict) and v.get("class") == dom[0] and dtype_name == "bf16":
                 traffic = v["bytes_per_launch"]
     except Exception:
         traffic = None
@@ -411,8 +490,13 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     else:
         achieved = dom[1]["bytes"] / dom[1]["ms"] / 1e6
         roof = dict(bound="hbm", kernel=dom[0], achieved=round(achieved, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(achieved / PEAK_HBM_GBS, 4))
-    roof.update(traffic=traffic, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_per_step=dom[1]["n"] // n_rep, timing=timing,
-                alg_per_launch=(dom[1]["flops"] if mfma_bound else dom[1]["bytes"]) / dom[1]["n"])
+    sum_us = 1e3 * sum(ms for _, _, _, ms in per)
+    fwd_flops = sum(fl for _, fl, _, _ in per)
+    roof.update(traffic=traffic, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_per_step=dom[1]["n"], timing=timing,
+                alg_per_launch=(dom[1]["flops"] if mfma_bound else dom[1]["bytes"]) / dom[1]["n"],
+                shapes={k: v["avg_us"] for k, v in kernels.items() if k.startswith(dom[0])},
+                forward_sum_of_intervals_us=round(sum_us, 1), forward_graph_replay_us=round(fwd_plain_us, 1),
+                whole_step_frac=round(fwd_flops / fwd_plain_us / 1e6 / peak, 4))
     # NAR loop as a whole (graph replay + RNG + sample kernel), from the last timed utterance
     step_ms = ns["loop_ms"] / ns["steps"]
     nar = dict(ms_per_step=round(step_ms, 3), tflops=round(eng.flops_per_step(S, Le, s_out) / step_ms / 1e9, 1), S=S, Le=Le,
@@ -594,15 +678,23 @@ def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=40.0):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))          # N ranks, one per GPU; this process only waits for them
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if args.launch_check:
+        launch_check(args, world, rank)
+        return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        dist.init_process_group(backend=args.backend, device_id=dev)
     from mars5_tts_amd import synth
     global TEXT
     workload_name = ("BASELINE configs[1]: single utterance deep-clone, temperature=0.7 top_k=100, 6 s / 450-frame synthetic "
@@ -690,7 +782,7 @@ def main():
         return
     out = {
         "metric": "generated audio seconds/sec (RTF), deep-clone", "value": round(audio_s / elapsed, 4), "unit": "audio_s/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
+        "n_gpus": (collective["ranks_seen"] if collective else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "p50_latency_s": round(statistics.median(lat), 4),
         "config": {"workload": workload_name,
@@ -701,8 +793,11 @@ def main():
         "collective": collective,
     }
     if not args.no_roofline:
+        from mars5_tts_amd import ar_engine, nar_engine
+        ar_stats, nar_stats = dict(ar_engine.LAST_STATS), dict(nar_engine.LAST_STATS)
         roof, ar_roof, nar, kernels = roofline_leg(m, ref_codes, cfg, args.dtype)
-        from mars5_tts_amd import ar_engine
+        ar_engine.LAST_STATS.update(ar_stats)
+        nar_engine.LAST_STATS.update(nar_stats)
         out["roofline"] = roof
         out["roofline_ar_decode"] = ar_roof
         out["nar_loop"] = nar

@@ -332,6 +332,9 @@ int m5_event_create(void** ev);
 int m5_event_record(void* ev, void* stream);
 int m5_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
 int m5_event_destroy(void* ev);
+/* In-graph timing (bench roofline leg): a one-lane launch that stores the 100 MHz wall clock into *slot (device memory).
+ * Captured between two launches of a hipGraph, consecutive stamps bracket the launch between them as the replay runs it. */
+int m5_clock_stamp(uint64_t* slot, void* stream);
 
 #ifdef M5_TOOLS
 /* ---- tools library only (libmars5_hip_tools.so, built with -DM5_TOOLS; the scripts under tools/ load it with M5_HIP_TOOLS=1).  The

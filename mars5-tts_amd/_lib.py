@@ -154,6 +154,7 @@ PROTOTYPES = {
     "m5_event_record": (C.c_int, [vp, vp]),
     "m5_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(f32)]),
     "m5_event_destroy": (C.c_int, [vp]),
+    "m5_clock_stamp": (C.c_int, [vp, vp]),
 }
 # exported by libmars5_hip_tools.so only (header: #ifdef M5_TOOLS)
 TOOLS_PROTOTYPES = {

@@ -39,6 +39,8 @@ struct Gemm16Params {
     int M, N, K;
     int tilesM, tilesN, nblk, group_m;
     unsigned long long* dbg;         // diagnostics: workgroup 0 records {shader clock, 100 MHz wall clock} at entry / exit
+    int abl;                         // tools build only (M5_GEMM_ABL): timing ablations with WRONG results -- 1: no fragment reads / MFMAs,
+                                     // 2: no operand DMA after the prologue stages, 3: neither (barriers + epilogue only)
     int qkv_stage;                   // QKV scatter: alignment / shape allow the LDS-staged 16-byte-chunk epilogue
     int vec16;                       // 16-bit outputs: rows / batch stride / base / width allow 16-byte row chunks (LDS-staged epilogue)
     int vec_c;                       // C rows / batch stride / base allow 16-byte (fp32) or 8-byte (16-bit) vectors
@@ -305,9 +307,16 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         wait_younger<NSTAGE - 2, JN>(younger, full_share);
         __syncthreads();
         // the slot read during K-step kt-1 is free now: refill it with K-step kt+NSTAGE-1
+#ifdef M5_TOOLS
+        if (kt + NSTAGE - 1 < nk && !(p.abl & 2)) stage_load(slot == 0 ? NSTAGE - 1 : slot - 1, kt + NSTAGE - 1);
+#else
         if (kt + NSTAGE - 1 < nk) stage_load(slot == 0 ? NSTAGE - 1 : slot - 1, kt + NSTAGE - 1);
+#endif
         const unsigned char* sb = lds + slot * STAGE;
         slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+#ifdef M5_TOOLS
+        if (p.abl & 1) continue;
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             uint4 af[TM], bf[TN];
@@ -1141,6 +1150,7 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     } else {
         p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     }
+    if (const char* ab = m5_tool_env("M5_GEMM_ABL")) p.abl = atoi(ab);
     const char* fe = m5_tool_env("M5_GEMM_CFG");             // tuning sweeps (tools build only); read per call on purpose
     int forced = (fe && fe[0]) ? atoi(fe) : -1;
     if (forced < 0) {                                        // per-epilogue override: M5_GEMM_CFG_E<epi>=<n>

@@ -51,6 +51,19 @@ extern "C" int m5_event_destroy(void* ev) {
     if (!ev) return M5_ERR_ARG;
     return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? M5_OK : M5_ERR_LAUNCH;
 }
+// In-graph timing: a one-lane kernel that stores the 100 MHz wall clock (s_memrealtime).  Captured between the launches of a
+// hipGraph it runs after its predecessor has drained and before its successor starts, so slot[i + 1] - slot[i] is the time the
+// launch between them occupies in the replay (its launch boundary included) -- what HIP events cannot give inside a capture.
+namespace {
+__global__ void clock_stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+extern "C" int m5_clock_stamp(uint64_t* slot, void* stream) {
+    if (!slot) return M5_ERR_ARG;
+    hipLaunchKernelGGL(clock_stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)slot);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
 #ifdef M5_TOOLS   // probes behind tools/*.py (dispatch census, launch floor, operand-feed probe, grid barrier): tools library only
 
 // ---- placement census (diagnostics; tools/census.py): where does the dispatcher put the

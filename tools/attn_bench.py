@@ -59,6 +59,11 @@ def case(name, B, H, Sq, Sk, causal=False, key_len=None):
     print(f"{name:28s} B={B} H={H} Sq={Sq} Sk={Sk}  {us:8.2f} us  {fl / us / 1e6:7.1f} TF  maxerr={err:.4g}", flush=True)
 
 if __name__ == "__main__":
+    if os.environ.get("CASES"):            # CASES="B,H,Sq,Sk;B,H,Sq,Sk;..." : grid-shape experiments
+        for c in os.environ["CASES"].split(";"):
+            B, H, Sq, Sk = (int(v) for v in c.split(","))
+            case(f"case {c}", B, H, Sq, Sk)
+        sys.exit(0)
     case("nar self", 2, 16, 1349, 1349)
     case("nar self keylen", 2, 16, 1349, 1349, key_len=[1349, 1000])
     case("nar cross", 2, 16, 1349, 39)

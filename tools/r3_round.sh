@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-3 GPU-box runner.  usage: tools/r3_round.sh <tag> <step>...   (outputs under gpurun_out/<tag>/)
+TAG=${1:-r3}; shift
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for s in "$@"; do
+  case $s in
+    test) timeout 1700 python -m pytest tests -m gpu -x -q -s --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" $OUT/pytest.log | tail -3 ;;
+    parity) timeout 1200 python -m pytest tests/test_gpu_parity16.py -m gpu -q -s --durations=10 > $OUT/parity.log 2>&1; echo "parity rc=$?"; grep -E "^AR |^NAR |^nar_sample|passed|failed|Error|assert" $OUT/parity.log | tail -40 ;;
+    yard) timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/yard -o y -- python tools/blas_yardstick.py > $OUT/yard.log 2>&1; echo "yard rc=$?"; cat $OUT/yard.log | grep '^{'
+          find $OUT/yard -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -40 {} | cut -c1-260' > $OUT/yard_kernel_stats_head.txt
+          find $OUT/yard -name "*kernel_trace.csv" -size +20M -delete ;;
+    abl) for a in 0 1 2 3; do echo "== M5_GEMM_ABL=$a"; M5_GEMM_ABL=$a ONLY="nar self qkv,nar out_proj,nar swiglu,nar linear2" timeout 300 python tools/gemm_bench.py 2>&1 | grep "nar "; done > $OUT/gemm_abl.log 2>&1; echo "abl rc=$?"; cat $OUT/gemm_abl.log ;;
+    attnq) CASES="${ATTN_CASES:-1,16,1349,1349;2,16,1024,1349;2,16,1349,1349;2,16,1536,1349;2,16,2048,1349;2,16,3072,1349;4,16,1349,1349}" timeout 300 python tools/attn_bench.py > $OUT/attn_grid.log 2>&1; echo "attnq rc=$?"; cat $OUT/attn_grid.log ;;
+    narab) timeout 900 python tools/nar_step_bench.py ${NARAB} > $OUT/narab.log 2>&1; echo "narab rc=$?"; grep round $OUT/narab.log ;;
+    arab) timeout 900 python tools/ar_step_bench.py ${ARAB} > $OUT/arab.log 2>&1; echo "arab rc=$?"; grep round $OUT/arab.log ;;
+    c3) timeout 900 python bench.py --workload c3 --batch 32 --steps 1 --warmup 1 > $OUT/c3.json 2> $OUT/c3.err; echo "c3 rc=$?"; cat $OUT/c3.json; tail -2 $OUT/c3.err ;;
+    c5) timeout 900 python bench.py --workload c5 --steps 1 --warmup 1 --no-cpu-baseline --no-parity --no-batch-leg > $OUT/c5.json 2> $OUT/c5.err; echo "c5 rc=$?"; cat $OUT/c5.json | cut -c1-1500; tail -2 $OUT/c5.err ;;
+    bench) timeout 900 python bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -2 $OUT/bench.err ;;
+    benchq) timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-batch-leg > $OUT/benchq.json 2> $OUT/benchq.err; echo "benchq rc=$?"; cat $OUT/benchq.json; tail -3 $OUT/benchq.err ;;
+    prof) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity --no-batch-leg > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
+          find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -30 {} | cut -c1-200'
+          find $OUT/prof -name "*kernel_trace.csv" -size +30M -delete ;;
+    smoke) timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
