@@ -23,6 +23,7 @@
 //     operand order back (block-uniform) so the four consecutive elements run along s.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) _Float16 h8_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 b8_t;
@@ -45,6 +46,9 @@ struct Gemm16Params {
     int vec16;                       // 16-bit outputs: rows / batch stride / base / width allow 16-byte row chunks (LDS-staged epilogue)
     int vec_c;                       // C rows / batch stride / base allow 16-byte (fp32) or 8-byte (16-bit) vectors
     int vt_vec;                      // V^T scatter may store 4 consecutive s as one 8-byte vector
+    int fast_c;                      // fp32 C: vectors allowed AND N a multiple of 4 AND bias 16-byte aligned: the epilogue's loads / stores
+                                     // are whole float4s with ONE row predicate (the general path spends ~1000 issue slots per wave on
+                                     // per-element bounds branches: ~2 us per launch at one wave per SIMD)
     M5QkvScatter sc;
     int sec_kind[3];
     // EPI_RESIDUAL_LN: LayerNorm of the updated rows fused behind the residual add (see the epilogue)
@@ -131,7 +135,14 @@ __device__ inline void wait_younger(int y, bool full_share) {
 // the 128x128 configuration (2 workgroups per CU) there are "region" configurations that cut the
 // output into ~240-256 large rectangles, ONE per CU (192x384, 192x192, 96x128): the bytes staged
 // per flop drop 1.5-2x and every CU gets the same amount, instead of 128x128 tiles in 2.06 rounds.
-template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC>
+// PF ("prefetched fragments", round 3): the K loop keeps TWO fragment register sets and places its one barrier per K-step
+// between the two 32-deep MFMA blocks: block 0 of K-step kt runs on fragments read during block 1 of K-step kt-1, block 1
+// on fragments read during block 0 -- no MFMA ever waits for an LDS read or sits right behind the barrier.  Measured on
+// the 4-wave (one wave per SIMD) 96x128 region kernel: without it a K-step costs ~800 cycles with the DMAs removed against
+// 408 cycles of MFMA issue (profiles/r3a_gemm_ablation.txt); hipBLASLt's 128x96 kernel runs these shapes 1.5-1.8x faster
+// (profiles/r3a_blas_yardstick.txt).  The K-step's fragments are all in registers at the barrier, so the slot just read
+// is refilled one K-step earlier than in the plain loop (NSTAGE K-steps of DMA in flight instead of NSTAGE-1).
+template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false>
 __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_kernel(Gemm16Params p) {
     using st = typename T::storage;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
@@ -222,35 +233,51 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     // per-wave column span (16 TN) divides the section width Dm.
     bool vblock = false;
     const int Dm = p.sc.n_heads * p.sc.head_dim;
-    if constexpr (EPI == M5_EPI_QKV) vblock = p.sec_kind[min((n0 + wn * TN * 16) / Dm, 2)] == 2;
+    // (readfirstlane: the tile index comes out of vector-ALU divisions, so hipcc would treat the branch as divergent and run
+    // BOTH operand orders under EXEC masks -- which MFMA ignores)
+    if constexpr (EPI == M5_EPI_QKV) vblock = __builtin_amdgcn_readfirstlane(p.sec_kind[min((n0 + wn * TN * 16) / Dm, 2)]) == 2;
 
     // in-place residual: the old C values of this wave's tile are requested BEFORE the K loop (they come
     // from HBM: 11.5 MB of fp32 per 2816 x 1024 launch) and consumed after it -- the epilogue then only writes
     constexpr bool PRELOAD_C = (EPI == M5_EPI_RESIDUAL || EPI == EPI_RESIDUAL_LN) && (TM * TN <= 16);
     float4 oldpre[PRELOAD_C ? TM : 1][PRELOAD_C ? TN : 1];
-    if constexpr (PRELOAD_C) {
-        const float* Cr = reinterpret_cast<const float*>(p.C) + (int64_t)bz * p.sC;
+    auto preload_c = [&]() {
+        if constexpr (PRELOAD_C) {
+            const float* Cr = reinterpret_cast<const float*>(p.C) + (int64_t)bz * p.sC;
+            if (p.fast_c) {                                  // rows clamped (a row past M is never stored), columns by whole float4s
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = m0 + wm * TM * 16 + i * 16 + l15;
+                for (int i = 0; i < TM; ++i) {
+                    const float* rp = Cr + (int64_t)min(m0 + wm * TM * 16 + i * 16 + l15, p.M - 1) * p.ldc;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
-                oldpre[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < p.M && col < p.N) {
-                    const float* cp = Cr + (int64_t)row * p.ldc + col;
-                    if (p.vec_c && col + 3 < p.N) {
-                        oldpre[i][j] = *reinterpret_cast<const float4*>(cp);
-                    } else {
-                        oldpre[i][j].x = cp[0];
-                        if (col + 1 < p.N) oldpre[i][j].y = cp[1];
-                        if (col + 2 < p.N) oldpre[i][j].z = cp[2];
-                        if (col + 3 < p.N) oldpre[i][j].w = cp[3];
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = min(n0 + wn * TN * 16 + j * 16 + lg * 4, p.N - 4);
+                        oldpre[i][j] = *reinterpret_cast<const float4*>(rp + col);
+                    }
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = m0 + wm * TM * 16 + i * 16 + l15;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
+                    oldpre[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row < p.M && col < p.N) {
+                        const float* cp = Cr + (int64_t)row * p.ldc + col;
+                        if (p.vec_c && col + 3 < p.N) {
+                            oldpre[i][j] = *reinterpret_cast<const float4*>(cp);
+                        } else {
+                            oldpre[i][j].x = cp[0];
+                            if (col + 1 < p.N) oldpre[i][j].y = cp[1];
+                            if (col + 2 < p.N) oldpre[i][j].z = cp[2];
+                            if (col + 3 < p.N) oldpre[i][j].w = cp[3];
+                        }
                     }
                 }
             }
         }
-    }
+    };
 
     // EPI_Q_CROSS: this wave's 64 columns are ONE head; the memory of a sequence is short (<= 64 keys) and already
     // projected, so its K / V^T fragments for this head are requested now (L2 hits, they land during the K loop).
@@ -294,8 +321,160 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     };
     if constexpr (EPI == EPI_Q_CROSS) xa_load(min(m0 + wm * TM * 16, p.M - 1) / p.xa_rows_per_seq);
 
+    // bias of this lane's columns (swapped layout: 4 consecutive columns of each of the TN tiles), requested BEFORE the K
+    // loop: loaded behind it, the epilogue opened with 16 dependent scalar loads and a vmcnt(0) (~1 us per launch)
+    const float* bias = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
+    float bvh[TN][4];
+    auto load_bias = [&]() {
+        if (bias && ((reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (p.N & 3) == 0 && p.N >= 4) {    // whole float4s, column clamped
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float4 t4 = *reinterpret_cast<const float4*>(bias + min(n0 + wn * TN * 16 + j * 16 + lg * 4, p.N - 4));
+                bvh[j][0] = t4.x; bvh[j][1] = t4.y; bvh[j][2] = t4.z; bvh[j][3] = t4.w;
+            }
+            return;
+        }
+        const bool bvec = bias && ((reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
+            if (bvec && col + 3 < p.N) {
+                const float4 t4 = *reinterpret_cast<const float4*>(bias + col);
+                bvh[j][0] = t4.x; bvh[j][1] = t4.y; bvh[j][2] = t4.z; bvh[j][3] = t4.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bvh[j][r] = bias ? bias[min(col + r, p.N - 1)] : 0.f;
+            }
+        }
+    };
+    // (hipcc cannot sink these loads below the loop: the DMA statements inside it clobber "memory")
+
     const int nk = p.K * 2 / BKB;
     const bool full_share = (NQ % NW == 0) || (wave < NQ % NW);     // this wave issues JN (else JN - 1) DMAs per stage
+    auto mfma_block = [&](const uint4 (&af)[TM], const uint4 (&bf)[TN]) {
+        if (EPI == M5_EPI_QKV && vblock) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<T>(af[i], bf[j], acc[i][j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
+        }
+    };
+    if constexpr (PF) {
+        static_assert(KS == 2, "prefetched-fragment loop: two 32-deep MFMA blocks per K-step");
+        static_assert(NQ % NW == 0, "prefetched-fragment loop: every wave issues JN DMAs per stage (constant vmcnt counts)");
+        static_assert((BM / RPI) % NW == 0, "prefetched-fragment loop: a wave's first JA pieces are A rows, the rest W rows");
+        static_assert((NSTAGE - 1) * JN < 64 && TM * TN >= JN, "vmcnt range; one DMA piece behind each of the first JN MFMAs");
+        constexpr int JA = (BM / RPI) / NW;
+        // DMA pieces in the scalar-base form: global_load_lds_dwordx4 voffset, s[base:base+1] -- the K-step advances a
+        // wave-uniform base (two scalar adds per stage) instead of seven 64-bit vector pointers, and M0 is written without
+        // the save / restore dance (nothing else in this kernel uses M0): three instructions per piece, so that a piece
+        // fits behind one MFMA (16 cycles of matrix pipe) when the refill is interleaved with MFMA block 1.
+        // (the batch index comes out of an integer division, which hipcc evaluates on the vector ALU: make the bases provably uniform)
+        auto uniform_ptr = [](const unsigned char* q) {
+            const uint64_t u = (uint64_t)(uintptr_t)q;
+            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+            return (const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+        };
+        const unsigned char* Au = uniform_ptr(A);
+        const unsigned char* Wu = uniform_ptr(W);
+        uint32_t voff[JN];
+#pragma unroll
+        for (int j = 0; j < JN; ++j) {
+            const int r = (wave + NW * j) * RPI + srow;
+            if (j < JA) voff[j] = (uint32_t)((int64_t)min(m0 + r, p.M - 1) * p.lda * 2 + schunk * 16);
+            else voff[j] = (uint32_t)((int64_t)min(n0 + r - BM, p.N - 1) * p.ldw * 2 + schunk * 16);
+        }
+        auto piece = [&](int j, const unsigned char* sA, const unsigned char* sW, uint32_t sbase) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"(voff[j]), "s"(j < JA ? sA : sW), "s"(sbase + j * NW * 1024) : "memory");
+        };
+        auto read_frags = [&](const unsigned char* sb, int ks, uint4 (&af)[TM], uint4 (&bf)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_row0 + i * 16 * BKB + foff[ks]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const uint4*>(sb + w_row0 + j * 16 * BKB + foff[ks]);
+        };
+#pragma unroll
+        for (int sgi = 0; sgi < NSTAGE; ++sgi)
+            if (sgi < nk) {
+#pragma unroll
+                for (int j = 0; j < JN; ++j) piece(j, Au + (int64_t)sgi * BKB, Wu + (int64_t)sgi * BKB, lds_base + sgi * STAGE + wave * 1024);
+            }
+        // old C and bias are requested BEHIND the operand stages (the VM counter retires in order: in front of them, the first
+        // MFMA would wait for 11.5 MB of cold fp32 residual).  These loads are younger than K-step 0, so the counted wait
+        // below over-waits a little on the first K-step only -- never under-waits.
+        preload_c();
+        load_bias();
+        wait_younger<NSTAGE - 1, JN>(min(NSTAGE - 1, nk - 1), true);             // K-step 0 has landed
+        __syncthreads();
+        uint4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+        read_frags(lds, 0, af0, bf0);
+        int slot = 0;                                      // stage slot of K-step kt
+        // One K-step with a successor: block 0 under the reads of block 1; then K-step kt+1 has landed once at most Y younger
+        // stages remain in flight, and at the barrier every wave holds ALL fragments of K-step kt in registers (lgkmcnt(0)),
+        // so its slot is refilled at once (REFILL: K-step kt+NSTAGE exists), one piece behind each of the first JN MFMAs of
+        // block 1, which runs under the reads of the next block 0.  The issue order is pinned (sched_barrier): left alone,
+        // hipcc sinks the fragment reads to just in front of their first use and the MFMAs wait for LDS again.
+        // The steady-state loop is ONE basic block (constant wait, unconditional refill): with control flow between the two
+        // MFMA blocks hipcc rotates the 48 accumulator registers through copies every iteration.
+        auto kstep = [&](int kt, auto y_tag, auto refill_tag) {
+            constexpr int Y = decltype(y_tag)::value;
+            constexpr bool REFILL = decltype(refill_tag)::value;
+            read_frags(lds + slot * STAGE, 1, af1, bf1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_block(af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            const int nslot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Y * JN) : "memory");
+            __syncthreads();
+            read_frags(lds + nslot * STAGE, 0, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned char* sA = Au + (int64_t)(kt + NSTAGE) * BKB;
+            const unsigned char* sW = Wu + (int64_t)(kt + NSTAGE) * BKB;
+            const uint32_t sbase = lds_base + slot * STAGE + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (EPI == M5_EPI_QKV && vblock) acc[i][j] = mfma16<T>(af1[i], bf1[j], acc[i][j]);
+                    else acc[i][j] = mfma16<T>(bf1[j], af1[i], acc[i][j]);
+                    if constexpr (REFILL) {
+                        if (i * TN + j < JN) {
+                            piece(i * TN + j, sA, sW, sbase);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot;
+        };
+        int kt = 0;
+#ifdef M5_TOOLS
+        if (p.abl & 2) {
+            for (; kt + NSTAGE < nk; ++kt) kstep(kt, std::integral_constant<int, NSTAGE - 2>{}, std::false_type{});
+        }
+#endif
+        for (; kt + NSTAGE < nk; ++kt) kstep(kt, std::integral_constant<int, NSTAGE - 2>{}, std::true_type{});
+        // the last min(nk, NSTAGE) - 1 K-steps with a successor: r K-steps follow, min(NSTAGE-2, r-1) of them still in flight
+        auto tail = [&](auto r_tag) {
+            constexpr int R = decltype(r_tag)::value;
+            if (nk - 1 - kt == R) { kstep(kt, std::integral_constant<int, (R - 1 < NSTAGE - 2 ? R - 1 : NSTAGE - 2)>{}, std::false_type{}); ++kt; }
+        };
+        static_assert(NSTAGE <= 4, "tail unrolled for up to 3 K-steps");
+        if constexpr (NSTAGE >= 4) tail(std::integral_constant<int, 3>{});
+        if constexpr (NSTAGE >= 3) tail(std::integral_constant<int, 2>{});
+        tail(std::integral_constant<int, 1>{});
+        read_frags(lds + slot * STAGE, 1, af1, bf1);       // last K-step: nothing left to wait for or to refill
+        mfma_block(af0, bf0);
+        mfma_block(af1, bf1);
+    } else {
+    preload_c();
+    load_bias();
 #pragma unroll
     for (int sgi = 0; sgi < NSTAGE - 1; ++sgi)
         if (sgi < nk) stage_load(sgi, sgi);
@@ -324,22 +503,12 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_row0 + i * 16 * BKB + foff[ks]);
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const uint4*>(sb + w_row0 + j * 16 * BKB + foff[ks]);
-            if (EPI == M5_EPI_QKV && vblock) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<T>(af[i], bf[j], acc[i][j]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16<T>(bf[j], af[i], acc[i][j]);
-            }
+            mfma_block(af, bf);
         }
+    }
     }
     if (dbg_on) { dbg[2] = clock64(); dbg[3] = wall_clock64(); }
     // ---- epilogue.  swapped layout: acc[i][j][r] = C[mw + 16 i + l15][nw + 16 j + 4 lg + r]
-    const float* bias = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
     constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL || EPI == EPI_RESIDUAL_LN);
     unsigned char* Cb = p.C + (int64_t)bz * p.sC * (F32OUT ? 4 : 2);
     const int mw = m0 + wm * TM * 16, nw = n0 + wn * TN * 16;
@@ -358,10 +527,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         unsigned char* wsq = lds + wave * (TM * 16 * RBQ);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = nw + j * 16 + lg * 4;
             float bv4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv4[r] = bias ? bias[col + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float vq[4];
@@ -455,7 +623,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             const int col = nw + j * 16 + lg * 4;
             float bv4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bv4[r] = bias ? bias[col + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const float4 o = oldpre[i][j];
@@ -585,10 +753,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 if (!vblock) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int col = ncol0 + j * 16 + lg * 4;
                         float bv4[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) bv4[r] = biasp ? biasp[min(col + r, p.N - 1)] : 0.f;
+                        for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
                             float v[4];
@@ -685,12 +852,11 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         static_assert(NW * TM * 16 * RBS <= NSTAGE * STAGE, "the output tile is staged in the (dead) K-loop stages");
         __syncthreads();
         unsigned char* ws = lds + wave * (TM * 16 * RBS);
-        const float* biasp = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
         float bvs[TN][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bvs[j][r] = biasp ? biasp[min(nw + j * 16 + lg * 4 + r, p.N - 1)] : 0.f;
+            for (int r = 0; r < 4; ++r) bvs[j][r] = bvh[j][r];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float v[TN][4];
@@ -742,13 +908,11 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             if (p.vec16) {
                 __syncthreads();                                          // every wave is done reading the stages
                 unsigned char* ws = lds + wave * (TM * 16 * RBS);
-                const float* biasp = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
                     float bv4[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) bv4[r] = biasp ? biasp[min(col + r, p.N - 1)] : 0.f;
+                    for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         float v[4];
@@ -796,10 +960,30 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     // per-column-group constants (this lane's 4 consecutive columns of each of the TN tiles)
     float bv[TN][4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = nw + j * 16 + lg * 4;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[j][r] = bias ? bias[min(col + r, p.N - 1)] : 0.f;
+        for (int r = 0; r < 4; ++r) bv[j][r] = bvh[j][r];
+    if constexpr (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL) {
+        if (p.fast_c && (EPI == M5_EPI_F32 || PRELOAD_C)) {
+            float* Cf = reinterpret_cast<float*>(Cb);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = mw + i * 16 + l15;
+                float* rp = Cf + (int64_t)row * p.ldc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = nw + j * 16 + lg * 4;
+                    float4 o;
+                    o.x = acc[i][j][0] + bv[j][0]; o.y = acc[i][j][1] + bv[j][1]; o.z = acc[i][j][2] + bv[j][2]; o.w = acc[i][j][3] + bv[j][3];
+                    if constexpr (EPI == M5_EPI_RESIDUAL) {
+                        o.x = oldpre[i][j].x + o.x; o.y = oldpre[i][j].y + o.y; o.z = oldpre[i][j].z + o.z; o.w = oldpre[i][j].w + o.w;
+                    }
+                    if (row < p.M && col < p.N) *reinterpret_cast<float4*>(rp + col) = o;
+                }
+            }
+            if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
+            return;
+        }
     }
     // in-place residual: row i+1's reads of C are issued BEFORE row i's writes (the compiler cannot
     // hoist a load above a possibly-aliasing store, which would serialise TM x TN round trips)
@@ -902,7 +1086,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC>
+template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false>
 int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
@@ -911,7 +1095,7 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
     p.nblk = (int)nblk;
     p.group_m = max(1, GROUP_M * 128 / BM);
     const dim3 grid(p.nblk), blk(WM * WN * 64);
-#define M5_G16(E) hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC>), grid, blk, 0, s, p)
+#define M5_G16(E) hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF>), grid, blk, 0, s, p)
     switch (epi) {
         case M5_EPI_F32: M5_G16(M5_EPI_F32); break;
         case M5_EPI_DT: M5_G16(M5_EPI_DT); break;
@@ -932,11 +1116,12 @@ static const CfgInfo kCfg[] = {
     {128, 128, 4, 2, 8.f, 0.72f, -1},             // 0: 128x128 tile, 4 waves, 2 stages, 2 WG/CU
     {192, 384, 6, 1, 8.f, 2.20f, -1},             // 1: region 192x384, 8 waves (2x4 of 96x96), 2 stages
     {192, 192, 4, 1, 7.f, 1.20f, -1},             // 2: region 192x192, 12 waves (4x3 of 48x64), 3 stages
-    { 96, 128, 4, 1, 8.f, 0.64f, -1},             // 3: region  96x128, 4 waves (2x2 of 48x64), 4 stages
+    { 96, 128, 4, 1, 8.f, 0.64f, -2},             // 3: region  96x128, 4 waves (2x2 of 48x64), 4 stages (sweeps: superseded by 7)
     { 96, 128, 2, 2, 8.f, 0.66f, -1},             // 4: tile    96x128, 8 waves (2x4 of 48x32), 2 stages, 2 WG/CU
     {192, 384, 6, 1, 8.f, 2.10f, M5_EPI_SWIGLU},  // 5: region 192x384, 16 waves (4x4 of 48x96), 2 stages (the QKV / residual
                                                   //    epilogues spill at 128 VGPRs: SwiGLU only)
     {192, 192, 4, 1, 7.f, 1.40f, -2},             // 6: region 192x192, 6 waves (2x3 of 96x64), 3 stages (sweeps: superseded by 2)
+    { 96, 128, 4, 1, 8.f, 0.40f, -1},             // 7: = 3 with the prefetched-fragment K loop (PF)
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -950,6 +1135,7 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s) {
         case 4: return launch16<T, 2, 4, 3, 2, 128, 2, 2>(epi, p, batch, s);
         case 5: return launch16<T, 4, 4, 3, 6, 128, 2, 1>(epi, p, batch, s);
         case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s);
+        case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true>(epi, p, batch, s);
         default: return M5_ERR_ARG;
     }
 }
@@ -972,7 +1158,7 @@ int pick_config(int M, int N, int K, int batch, int span_div, int epi) {
         // many rounds (batched NAR groups, M >= 10k rows): the tail round no longer matters and most of a workgroup's
         // fixed cost hides under its successor / co-resident workgroup (measured at M = 35840, profiles/r2t_gemm_configs.txt)
         if (wg >= 4 * slots) t = (float)wg / (float)slots * ((f.occ == 1 ? 0.2f : 0.7f) * f.t_fix_us + (float)(K / 64) * f.t_iter_us);
-        if (epi == M5_EPI_QKV && c == 3) t += 2.5f * (float)rounds;     // measured: its 4-wave scatter epilogue is the slowest
+        if (epi == M5_EPI_QKV && (c == 3 || c == 7)) t += 2.5f * (float)rounds;     // measured: its 4-wave scatter epilogue is the slowest
         if (t < best_t) { best_t = t; best = c; }
     }
     return best;
@@ -1046,6 +1232,8 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
     // 128 x 2Lp with 8 waves, 2 stages and two workgroups per CU
     int cfg = 0;
     if (const char* ce = m5_tool_env("M5_XATTN_CFG")) cfg = atoi(ce);
+    if (const char* pf = m5_tool_env("M5_GEMM_PF")) { if (atoi(pf) == 0 && cfg == 0) cfg = 3; }         // same-process A/B (tools build)
+    const bool off32 = ((int64_t)M * ldx * 2 < (1ll << 32)) && ((int64_t)n_heads * Lp * K * 2 < (1ll << 32));
     const int BM = cfg == 1 ? 64 : (cfg == 2 ? 128 : 96);
     p.tilesM = (M + BM - 1) / BM; p.tilesN = p.N / BN;
     const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
@@ -1053,11 +1241,11 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
     p.nblk = (int)nblk; p.group_m = max(1, GROUP_M * 128 / BM);
     const dim3 grid(p.nblk);
     hipStream_t s = (hipStream_t)stream;
-#define M5_XS(TT, WMv, TMv, TNv, NSv, OCv) hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv>), grid, dim3(WMv * 128), 0, s, p)
+#define M5_XS(TT, WMv, TMv, TNv, NSv, OCv, PFv) hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv, PFv>), grid, dim3(WMv * 128), 0, s, p)
 #ifdef M5_TOOLS
-#define M5_XS_CFG(TT, TNv) do { if (cfg == 1) M5_XS(TT, 4, 1, TNv, 2, 2); else if (cfg == 2) M5_XS(TT, 4, 2, TNv, 2, 2); else M5_XS(TT, 2, 3, TNv, 4, 1); } while (0)
+#define M5_XS_CFG(TT, TNv) do { if (cfg == 1) M5_XS(TT, 4, 1, TNv, 2, 2, false); else if (cfg == 2) M5_XS(TT, 4, 2, TNv, 2, 2, false); else if (cfg == 3 || !off32) M5_XS(TT, 2, 3, TNv, 4, 1, false); else M5_XS(TT, 2, 3, TNv, 4, 1, true); } while (0)
 #else
-#define M5_XS_CFG(TT, TNv) M5_XS(TT, 2, 3, TNv, 4, 1)
+#define M5_XS_CFG(TT, TNv) do { if (off32) M5_XS(TT, 2, 3, TNv, 4, 1, true); else M5_XS(TT, 2, 3, TNv, 4, 1, false); } while (0)
 #endif
     if (dtype == M5_F16) { if (Lp == 48) M5_XS_CFG(F16T, 3); else M5_XS_CFG(F16T, 4); }
     else { if (Lp == 48) M5_XS_CFG(BF16T, 3); else M5_XS_CFG(BF16T, 4); }
@@ -1129,6 +1317,7 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
         p.vec16 = (!f32out && C && (ldc % 8 == 0) && (sC % 8 == 0) && (((uintptr_t)C & 15) == 0) && (nout % 8 == 0)) ? 1 : 0;
     }
     p.vec_c = (C && (ldc % 4 == 0) && (sC % 4 == 0) && (((uintptr_t)C & cal) == 0)) ? 1 : 0;
+    p.fast_c = (f32out && p.vec_c && (N % 4 == 0) && N >= 4 && (!bias || ((((uintptr_t)bias & 15) == 0) && (sBias % 4 == 0)))) ? 1 : 0;
     if (sc) {
         p.sc = *sc;
         for (int i = 0; i < 3; ++i) p.sec_kind[i] = sec_kind[i];
@@ -1162,6 +1351,12 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     const int span_div = (sc && sc->vt) ? sc->n_heads * sc->head_dim : 0;
     int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div, epi);
     if (cfg < 0 || cfg >= kNumCfg || (span_div && (span_div % (kCfg[cfg].tn * 16)))) cfg = 0;
+    // the prefetched-fragment loop addresses operand rows with 32-bit byte offsets from a scalar base
+    const bool off32 = ((int64_t)M * lda * 2 < (1ll << 32)) && ((int64_t)N * ldw * 2 < (1ll << 32));
+    if (const char* pf = m5_tool_env("M5_GEMM_PF")) { if (atoi(pf) == 0 && cfg == 7) cfg = 3; }      // same-process A/B (tools build)
+    if (cfg == 7 && !off32) cfg = 3;
+    // (PF on the multi-wave configurations 2 and 0 measured SLOWER -- their co-resident waves already cover the LDS latency:
+    // QKV 26.7 -> 37.0 us, 34.8 -> 38.6 us; profiles/r3b_gemm_pf_ab.txt -- and was removed)
     if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s);
     return launch_cfg<BF16T>(cfg, epi, p, batch, s);
 }

@@ -62,6 +62,32 @@ def test_gemm_epilogues(dev, dt, M, N, K):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 384, 512, 1024, 3072])
+def test_gemm_prefetched_fragment_loop_every_pipeline_depth(dev, dt, K):
+    """The 96x128 region kernel's K loop (round 3: fragments of the next MFMA block read one block ahead, barrier between the
+    blocks, slot refilled NSTAGE K-steps ahead, tails of 3 / 2 / 1 K-steps unrolled): every K-step count from 1 up through
+    the prologue-only, tail-only and steady-state regimes, residual and plain 16-bit epilogues, against torch fp32 on the
+    same 16-bit operands.  M / N are not tile multiples (row / column clamps of the scalar-base DMA offsets)."""
+    from mars5_tts_amd import _lib as L, ops
+    M, N = 250, 300
+    a, w, b = _q(_rand((M, K), 11), dt), _q(_rand((N, K), 12, scale=K ** -0.5), dt), _rand((N,), 13)
+    ref = a @ w.T + b
+    ad, wd, bd = a.to(dev, dt), w.to(dev, dt), b.to(dev)
+    res = _rand((M, N), 14).to(dev)
+    res0 = res.clone()
+    ops.gemm(ad, wd, res, L.EPI_RESIDUAL, bias=bd)
+    out = torch.zeros(M, N, device=dev, dtype=dt)
+    ops.gemm(ad, wd, out, L.EPI_DT, bias=bd)
+    torch.cuda.synchronize()
+    assert _rel((res - res0).cpu(), ref) < TOL[dt] * 2, f"residual K={K}"
+    assert _rel(out.float().cpu(), ref) < 8e-3, f"plain K={K}"
+    # a second launch on the same buffers (graph-style back-to-back reuse of the stage slots / M0)
+    ops.gemm(ad, wd, res, L.EPI_RESIDUAL, bias=bd)
+    torch.cuda.synchronize()
+    assert _rel((res - res0).cpu(), 2 * ref) < TOL[dt] * 2
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M", [1, 5, 16, 17, 32])
 def test_gemm_skinny_decode_shapes(dev, dt, M):
     """The M <= 32 weight-streaming path of m5_gemm (batched AR decode step) at the real projection shapes:

@@ -22,6 +22,9 @@ for s in "$@"; do
     prof) timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o r -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity --no-batch-leg > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
           find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -30 {} | cut -c1-200'
           find $OUT/prof -name "*kernel_trace.csv" -size +30M -delete ;;
+    gemmtest) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "gemm or absorbed" > $OUT/gemmtest.log 2>&1; echo "gemmtest rc=$?"; tail -5 $OUT/gemmtest.log ;;
+    gemmab) for pf in 0 1; do echo "== M5_GEMM_PF=$pf"; M5_GEMM_PF=$pf ONLY="nar out_proj,nar linear2,nar head (1 of 7),big out_proj,big linear2" timeout 300 python tools/gemm_bench.py 2>&1 | grep -E "nar |big "; done > $OUT/gemm_pf_ab.log 2>&1
+            echo "gemmab rc=$?"; cat $OUT/gemm_pf_ab.log ;;
     smoke) timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
