@@ -177,7 +177,10 @@ def _load() -> C.CDLL:
     protos = dict(PROTOTYPES)
     if TOOLS:
         protos.update(TOOLS_PROTOTYPES)
+    override = TOOLS and bool(os.environ.get("M5_HIP_TOOLS_LIB"))
     for name, (res, args) in protos.items():
+        if override and not hasattr(lib, name):
+            continue                 # same-box A/B against an OLDER tools build (tools/*.py only): newer entry points are absent there
         fn = getattr(lib, name)      # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args

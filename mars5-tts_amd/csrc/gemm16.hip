@@ -199,20 +199,39 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     const int srow = (BKB == 128) ? (lane >> 3) : (lane >> 2);
     const int schunk = (BKB == 128) ? ((lane & 7) ^ srow) : ((lane & 3) ^ ((-(srow >> 2)) & 3));
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const unsigned char* gp[JN];
+    // DMA pieces in the scalar-base form: global_load_lds_dwordx4 voffset, s[base:base+1].  The base is the tile's first A / W
+    // row at the K-step (wave-uniform: two scalar adds per stage), the 32-bit per-lane offset is tile-local (row clamp folded
+    // in), so neither 64-bit per-lane pointers nor their per-K-step vector adds exist, and M0 is written without a save /
+    // restore (nothing else in this kernel uses M0): three instructions per piece.  (The batch index comes out of an integer
+    // division, which hipcc evaluates on the vector ALU: readfirstlane makes the bases provably uniform.)
+    auto uniform_ptr = [](const unsigned char* q) {
+        const uint64_t u = (uint64_t)(uintptr_t)q;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+        return (const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
+    const unsigned char* Au = uniform_ptr(A + (int64_t)min(m0, p.M - 1) * p.lda * 2);
+    const unsigned char* Wu = uniform_ptr(W + (int64_t)min(n0, p.N - 1) * p.ldw * 2);
+    uint32_t voff[JN];
+    bool piece_a[JN];                                   // wave-uniform: piece j of this wave is rows of A (else of W)
 #pragma unroll
     for (int j = 0; j < JN; ++j) {
         const int q = wave + NW * j;                   // wave-uniform
         const int r = q * RPI + srow;                  // row of the stage image
-        if (r < BM) gp[j] = A + (int64_t)min(m0 + r, p.M - 1) * p.lda * 2 + schunk * 16;
-        else gp[j] = W + (int64_t)min(n0 + r - BM, p.N - 1) * p.ldw * 2 + schunk * 16;
+        piece_a[j] = q * RPI < BM;
+        if (r < BM) voff[j] = (uint32_t)((int64_t)min(r, max(p.M - 1 - m0, 0)) * p.lda * 2 + schunk * 16);
+        else voff[j] = (uint32_t)((int64_t)min(r - BM, max(p.N - 1 - n0, 0)) * p.ldw * 2 + schunk * 16);
     }
+    auto piece = [&](int j, const unsigned char* sA, const unsigned char* sW, uint32_t sbase) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"(voff[j]), "s"(piece_a[j] ? sA : sW), "s"(sbase + j * NW * 1024) : "memory");
+    };
     auto stage_load = [&](int stage, int kt) {
         const uint32_t sbase = lds_base + stage * STAGE + wave * 1024;
-        const int64_t koff = (int64_t)kt * BKB;
+        const unsigned char* sA = Au + (int64_t)kt * BKB;
+        const unsigned char* sW = Wu + (int64_t)kt * BKB;
 #pragma unroll
         for (int j = 0; j < JN; ++j)
-            if (NQ % NW == 0 || wave + NW * j < NQ) glds16(gp[j] + koff, sbase + j * NW * 1024);
+            if (NQ % NW == 0 || wave + NW * j < NQ) piece(j, sA, sW, sbase);
     };
 
     // fragment read offsets: row (16 i + l15), k-chunk (4 ks + lg) swizzled like the source
@@ -324,6 +343,10 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     // bias of this lane's columns (swapped layout: 4 consecutive columns of each of the TN tiles), requested BEFORE the K
     // loop: loaded behind it, the epilogue opened with 16 dependent scalar loads and a vmcnt(0) (~1 us per launch)
     const float* bias = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
+    // ... where the register budget allows it (the 16-wave 192x384 SwiGLU region kernel has 128 VGPRs per wave: 24 more live
+    // values across the K loop spilled 95 registers to scratch there)
+    constexpr int WAVES_PER_SIMD = (OCC * WM * WN + 3) / 4;
+    constexpr bool HOIST_B = TM * TN * 4 * (PRELOAD_C ? 2 : 1) + (TM + TN) * 4 * (PF ? 2 : 1) + TN * 4 + 48 <= 512 / WAVES_PER_SIMD;
     float bvh[TN][4];
     auto load_bias = [&]() {
         if (bias && ((reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (p.N & 3) == 0 && p.N >= 4) {    // whole float4s, column clamped
@@ -348,6 +371,17 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         }
     };
     // (hipcc cannot sink these loads below the loop: the DMA statements inside it clobber "memory")
+    // bias of column tile j as the epilogues consume it: the hoisted registers, or -- no budget for them -- loaded on the spot
+    auto bias_j = [&](int j, float (&b4)[4]) {
+        if constexpr (HOIST_B) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = bvh[j][r];
+        } else {
+            const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = bias ? bias[min(col + r, p.N - 1)] : 0.f;
+        }
+    };
 
     const int nk = p.K * 2 / BKB;
     const bool full_share = (NQ % NW == 0) || (wave < NQ % NW);     // this wave issues JN (else JN - 1) DMAs per stage
@@ -367,32 +401,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     if constexpr (PF) {
         static_assert(KS == 2, "prefetched-fragment loop: two 32-deep MFMA blocks per K-step");
         static_assert(NQ % NW == 0, "prefetched-fragment loop: every wave issues JN DMAs per stage (constant vmcnt counts)");
-        static_assert((BM / RPI) % NW == 0, "prefetched-fragment loop: a wave's first JA pieces are A rows, the rest W rows");
         static_assert((NSTAGE - 1) * JN < 64 && TM * TN >= JN, "vmcnt range; one DMA piece behind each of the first JN MFMAs");
-        constexpr int JA = (BM / RPI) / NW;
-        // DMA pieces in the scalar-base form: global_load_lds_dwordx4 voffset, s[base:base+1] -- the K-step advances a
-        // wave-uniform base (two scalar adds per stage) instead of seven 64-bit vector pointers, and M0 is written without
-        // the save / restore dance (nothing else in this kernel uses M0): three instructions per piece, so that a piece
-        // fits behind one MFMA (16 cycles of matrix pipe) when the refill is interleaved with MFMA block 1.
-        // (the batch index comes out of an integer division, which hipcc evaluates on the vector ALU: make the bases provably uniform)
-        auto uniform_ptr = [](const unsigned char* q) {
-            const uint64_t u = (uint64_t)(uintptr_t)q;
-            const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
-            return (const unsigned char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
-        };
-        const unsigned char* Au = uniform_ptr(A);
-        const unsigned char* Wu = uniform_ptr(W);
-        uint32_t voff[JN];
-#pragma unroll
-        for (int j = 0; j < JN; ++j) {
-            const int r = (wave + NW * j) * RPI + srow;
-            if (j < JA) voff[j] = (uint32_t)((int64_t)min(m0 + r, p.M - 1) * p.lda * 2 + schunk * 16);
-            else voff[j] = (uint32_t)((int64_t)min(n0 + r - BM, p.N - 1) * p.ldw * 2 + schunk * 16);
-        }
-        auto piece = [&](int j, const unsigned char* sA, const unsigned char* sW, uint32_t sbase) {
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                         :: "v"(voff[j]), "s"(j < JA ? sA : sW), "s"(sbase + j * NW * 1024) : "memory");
-        };
         auto read_frags = [&](const unsigned char* sb, int ks, uint4 (&af)[TM], uint4 (&bf)[TN]) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sb + a_row0 + i * 16 * BKB + foff[ks]);
@@ -409,7 +418,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         // MFMA would wait for 11.5 MB of cold fp32 residual).  These loads are younger than K-step 0, so the counted wait
         // below over-waits a little on the first K-step only -- never under-waits.
         preload_c();
-        load_bias();
+        if constexpr (HOIST_B) load_bias();
         wait_younger<NSTAGE - 1, JN>(min(NSTAGE - 1, nk - 1), true);             // K-step 0 has landed
         __syncthreads();
         uint4 af0[TM], bf0[TN], af1[TM], bf1[TN];
@@ -474,7 +483,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         mfma_block(af1, bf1);
     } else {
     preload_c();
-    load_bias();
+    if constexpr (HOIST_B) load_bias();
 #pragma unroll
     for (int sgi = 0; sgi < NSTAGE - 1; ++sgi)
         if (sgi < nk) stage_load(sgi, sgi);
@@ -528,8 +537,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float bv4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
+            bias_j(j, bv4);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float vq[4];
@@ -622,8 +630,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         for (int j = 0; j < TN; ++j) {
             const int col = nw + j * 16 + lg * 4;
             float bv4[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
+            bias_j(j, bv4);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const float4 o = oldpre[i][j];
@@ -754,8 +761,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float bv4[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
+                        bias_j(j, bv4);
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
                             float v[4];
@@ -854,9 +860,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         unsigned char* ws = lds + wave * (TM * 16 * RBS);
         float bvs[TN][4];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bvs[j][r] = bvh[j][r];
+        for (int j = 0; j < TN; ++j) bias_j(j, bvs[j]);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float v[TN][4];
@@ -911,8 +915,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     float bv4[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) bv4[r] = bvh[j][r];
+                    bias_j(j, bv4);
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         float v[4];
@@ -960,9 +963,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     // per-column-group constants (this lane's 4 consecutive columns of each of the TN tiles)
     float bv[TN][4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bv[j][r] = bvh[j][r];
+    for (int j = 0; j < TN; ++j) bias_j(j, bv[j]);
     if constexpr (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL) {
         if (p.fast_c && (EPI == M5_EPI_F32 || PRELOAD_C)) {
             float* Cf = reinterpret_cast<float*>(Cb);
@@ -1233,7 +1234,8 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
     int cfg = 0;
     if (const char* ce = m5_tool_env("M5_XATTN_CFG")) cfg = atoi(ce);
     if (const char* pf = m5_tool_env("M5_GEMM_PF")) { if (atoi(pf) == 0 && cfg == 0) cfg = 3; }         // same-process A/B (tools build)
-    const bool off32 = ((int64_t)M * ldx * 2 < (1ll << 32)) && ((int64_t)n_heads * Lp * K * 2 < (1ll << 32));
+    if (ldx >= (1ll << 22) || K >= (1 << 22)) return M5_ERR_UNSUPPORTED;          // tile-local DMA offsets are 32-bit
+    const bool off32 = true;
     const int BM = cfg == 1 ? 64 : (cfg == 2 ? 128 : 96);
     p.tilesM = (M + BM - 1) / BM; p.tilesN = p.N / BN;
     const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
@@ -1351,8 +1353,8 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     const int span_div = (sc && sc->vt) ? sc->n_heads * sc->head_dim : 0;
     int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div, epi);
     if (cfg < 0 || cfg >= kNumCfg || (span_div && (span_div % (kCfg[cfg].tn * 16)))) cfg = 0;
-    // the prefetched-fragment loop addresses operand rows with 32-bit byte offsets from a scalar base
-    const bool off32 = ((int64_t)M * lda * 2 < (1ll << 32)) && ((int64_t)N * ldw * 2 < (1ll << 32));
+    if (lda >= (1ll << 22) || ldw >= (1ll << 22)) return M5_ERR_UNSUPPORTED;       // tile-local DMA offsets (rows x leading dimension) are 32-bit
+    const bool off32 = true;
     if (const char* pf = m5_tool_env("M5_GEMM_PF")) { if (atoi(pf) == 0 && cfg == 7) cfg = 3; }      // same-process A/B (tools build)
     if (cfg == 7 && !off32) cfg = 3;
     // (PF on the multi-wave configurations 2 and 0 measured SLOWER -- their co-resident waves already cover the LDS latency:

@@ -13,6 +13,10 @@ for s in "$@"; do
           find $OUT/yard -name "*kernel_trace.csv" -size +20M -delete ;;
     abl) for a in 0 1 2 3; do echo "== M5_GEMM_ABL=$a"; M5_GEMM_ABL=$a ONLY="nar self qkv,nar out_proj,nar swiglu,nar linear2" timeout 300 python tools/gemm_bench.py 2>&1 | grep "nar "; done > $OUT/gemm_abl.log 2>&1; echo "abl rc=$?"; cat $OUT/gemm_abl.log ;;
     attnq) CASES="${ATTN_CASES:-1,16,1349,1349;2,16,1024,1349;2,16,1349,1349;2,16,1536,1349;2,16,2048,1349;2,16,3072,1349;4,16,1349,1349}" timeout 300 python tools/attn_bench.py > $OUT/attn_grid.log 2>&1; echo "attnq rc=$?"; cat $OUT/attn_grid.log ;;
+    narbase) M5_HIP_TOOLS_LIB=$PWD/mars5-tts_amd/libmars5_hip_tools_base.so timeout 600 python tools/nar_step_bench.py "BASE=r2" > $OUT/narbase.log 2>&1; echo "narbase rc=$?"; grep round $OUT/narbase.log
+             timeout 600 python tools/nar_step_bench.py "CUR=r3" > $OUT/narcur.log 2>&1; grep round $OUT/narcur.log ;;
+    arbase) M5_HIP_TOOLS_LIB=$PWD/mars5-tts_amd/libmars5_hip_tools_base.so timeout 600 python tools/ar_step_bench.py "BASE=r2" > $OUT/arbase.log 2>&1; echo "arbase rc=$?"; grep round $OUT/arbase.log
+            timeout 600 python tools/ar_step_bench.py "CUR=r3" > $OUT/arcur.log 2>&1; grep round $OUT/arcur.log ;;
     narab) timeout 900 python tools/nar_step_bench.py ${NARAB} > $OUT/narab.log 2>&1; echo "narab rc=$?"; grep round $OUT/narab.log ;;
     arab) timeout 900 python tools/ar_step_bench.py ${ARAB} > $OUT/arab.log 2>&1; echo "arab rc=$?"; grep round $OUT/arab.log ;;
     c3) timeout 900 python bench.py --workload c3 --batch 32 --steps 1 --warmup 1 > $OUT/c3.json 2> $OUT/c3.err; echo "c3 rc=$?"; cat $OUT/c3.json; tail -2 $OUT/c3.err ;;
