@@ -19,6 +19,8 @@
 #define MARS5_HIP_H
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: only the entry points below are exported. */
+#define M5_API __attribute__((visibility("default")))
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -32,8 +34,8 @@ extern "C" {
 #define M5_F16 1
 #define M5_BF16 2
 
-int m5_version(void);                 /* ABI version, currently 1 */
-const char* m5_build_info(void);      /* "gfx950 ..." */
+M5_API int m5_version(void);                 /* ABI version, currently 1 */
+M5_API const char* m5_build_info(void);      /* "gfx950 ..." */
 
 /* ------------------------------------------------------------------------------------
  * GEMM  C[M,N] = A[M,K] . W[N,K]^T (+bias)   -- both operands K-contiguous (nn.Linear
@@ -60,19 +62,19 @@ typedef struct {
     int64_t vt_bs, vt_hs, vt_ds; /* batch, head, d-row (s contiguous)                     */
 } M5QkvScatter;               /* columns are laid out [present sections in q,k,v order] x (n_heads*head_dim) */
 
-int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+M5_API int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
             void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
             int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, void* stream);
 
 /* LayerNorm rows (fp32 in): y = (x-mean)*rsqrt(var+eps)*gamma+beta, out fp32 or dtype.
  * n_affine > 1 applies several (gamma,beta) sets to the same normalised row (the 8 NAR
  * heads, model.py:236-242,342).  D % 64 == 0, D <= 2048.  nn.LayerNorm on the path. */
-int m5_layernorm(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+M5_API int m5_layernorm(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                  void* y, int64_t ldy, int M, int D, int n_affine, int64_t affine_stride, int64_t y_affine_stride,
                  void* stream);
 
 /* RMSNorm rows (nn_future.py:301-312): y = dtype((x * rsqrt(mean(x^2)+eps)) * w). */
-int m5_rmsnorm(int out_dtype, const float* x, int64_t ldx, const float* w, float eps, void* y, int64_t ldy,
+M5_API int m5_rmsnorm(int out_dtype, const float* x, int64_t ldx, const float* w, float eps, void* y, int64_t ldy,
                int M, int D, void* stream);
 
 /* ------------------------------------------------------------------------------------
@@ -94,19 +96,19 @@ typedef struct {
     int64_t kv_index_stride_k;  /* V^T base += (*kv_index) * kv_index_stride_v (selects the          */
     int64_t kv_index_stride_v;  /* pre-computed cross-attention memory of the current DDPM step)     */
 } M5AttnArgs;
-int m5_attention(int dtype, const M5AttnArgs* a, void* stream);
+M5_API int m5_attention(int dtype, const M5AttnArgs* a, void* stream);
 
 /* out[r][:] = table[idx[r]][:] * 1 + alpha * pe[pos[r]][:] + add[add_idx[r]][:]
  * (pe / add optional).  nn.Embedding + SinePositionalEmbedding (nn_future.py:78-83) +
  * timestep-embedding add (model.py:329,337); also the AR prefill embedding (model.py:106,129). */
-int m5_gather_rows(float* out, int64_t ldo, int R, int D, const float* table, const int64_t* idx,
+M5_API int m5_gather_rows(float* out, int64_t ldo, int R, int D, const float* table, const int64_t* idx,
                    const float* alpha, const float* pe, const int32_t* pos,
                    const float* add, const int32_t* add_idx, void* stream);
 
 /* ChunkedEmbedding (model.py:147-159) + optional leading identity row + sine positional
  * embedding + optional add row selected by a DEVICE index (the DDPM step):
  * out[rep][r][:] = concat_q tables[q][codes[r-lead][q]] + alpha*pe[r] + add[*add_index]. */
-int m5_chunked_embed(float* out, int64_t ld_rep, int n_rep, int R, int D, int n_q, int n_codes,
+M5_API int m5_chunked_embed(float* out, int64_t ld_rep, int n_rep, int R, int D, int n_q, int n_codes,
                      const float* tables, const int64_t* codes, const float* lead_row,
                      const float* alpha, const float* pe, const float* add, const int32_t* add_index,
                      void* stream);
@@ -114,7 +116,7 @@ int m5_chunked_embed(float* out, int64_t ld_rep, int n_rep, int R, int D, int n_
 /* AR prefill: rotate q,k (interleaved-pair RoPE, nn_future.py:181-191) of a row-major
  * [M][3D] qkv buffer at positions pos0..pos0+M-1; write Q head-major, K and V into the KV
  * cache ([h][slot][hd], slot = pos % window, nn_future.py:249-252) and V^T scratch. */
-int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos0, const float* rope,
+M5_API int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos0, const float* rope,
                   void* q_out, void* kcache, void* vcache, int64_t cache_hs, int window,
                   void* vt_out, int64_t vt_hs, int64_t vt_ds, void* stream);
 
@@ -125,7 +127,7 @@ int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos0, cons
  * {K base address, V^T base address, Le, Lep, step stride of K, step stride of V^T (elements)} with K [H][Le][64] and
  * V^T [H][64][Lep] inside the block selected by the device index *step (the DDPM step).  Returns M5_ERR_UNSUPPORTED
  * (nothing launched; use m5_gemm(EPI_QKV) + m5_attention) unless 16-bit operands, max_le <= 64, even n_heads. */
-int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+M5_API int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                          int M, int n_heads, int K, const int64_t* mem_table, int max_le, int rows_per_seq,
                          const int32_t* step, float scale, void* out, int64_t ld_out, void* stream);
 
@@ -140,9 +142,9 @@ int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, i
  *    Wo ([D][D] row-major), bq (fp32 [D]) or 0, 0}.  Lp = 48 or 64 >= every Le.
  *  - m5_xattn_scores: P[b] = per-head softmax(X[b] A[b]^T + c[b]) (16-bit [M][n_heads*Lp], row stride ldp) for `batch`
  *    sequences (strides sX, sA_tab, sc_tab, sP in elements).  Then m5_gemm(P, B^T, EPI_RESIDUAL, batch) finishes the block. */
-int m5_xattn_absorb(int dtype, const int64_t* tab_seq, const int64_t* tab_layer, int n_layers, int n_seq, int n_heads,
+M5_API int m5_xattn_absorb(int dtype, const int64_t* tab_seq, const int64_t* tab_layer, int n_layers, int n_seq, int n_heads,
                     int D, int Lp, const int32_t* step, float scale, void* stream);
-int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+M5_API int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
                     void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, void* stream);
 
 /* x[M][N] += A . W^T + bias (the RESIDUAL epilogue of m5_gemm) with the LayerNorm that follows it in every pre-LN
@@ -156,7 +158,7 @@ int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const voi
  * tag_step a device int32 (or NULL = 0) -- under hipGraph replay the kernel arguments are frozen, so the varying part
  * must live in device memory (the DDPM step counter).  scratch[0] (uint32) counts wait timeouts (0 in a healthy run;
  * waits are bounded, a launch never hangs). */
-int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+M5_API int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                         float* C, int64_t ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
                         float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes,
                         const int32_t* tag_step, int tag, void* stream);
@@ -206,7 +208,7 @@ typedef struct {
     unsigned long long* dbg;                               /* diagnostics: phase stamps of workgroup 0 (NULL = off) */
     M5Prefetch pf;                                         /* optional: the NEXT launch's weights (streaming geometry only) */
 } M5GemvArgs;
-int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void* stream);
+M5_API int m5_ar_gemv(int dtype, int pro, int epi, const M5GemvArgs* a, void* stream);
 
 typedef struct {
     const void* qbuf; const void* kcache; const void* vcache;
@@ -221,7 +223,7 @@ typedef struct {
     M5Prefetch pf;                                         /* optional: a later launch's weights (batch 1 only) */
 } M5AttnDecodeArgs;
 /* nn_future.py:257-272 decode branch: q . K[:min(pos+1,W)] softmax . V, split over keys. */
-int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream);
+M5_API int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream);
 
 /* Batched decode step (BASELINE config 3: B sequences advance one token per step; the projections run
  * as M = B row GEMMs through m5_gemm, whose M <= 32 path streams every weight once for the whole batch).
@@ -230,16 +232,16 @@ int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* stream);
  *    q -> qbuf + b*q_bs ([h][64]), k / v -> this layer's cache of sequence b at slot pos % window
  *    (same arithmetic as m5_rope_cache, nn_future.py:181-191,249-252).
  *  - m5_ar_attn_combine_batch: merges the split-KV partials of m5_ar_attn_decode into out[b][D] (dtype). */
-int m5_ar_rope_cache_batch(int dtype, const void* qkv, int B, int n_heads, const float* rope, const int32_t* state,
+M5_API int m5_ar_rope_cache_batch(int dtype, const void* qkv, int B, int n_heads, const float* rope, const int32_t* state,
                            int32_t state_bs, void* qbuf, int64_t q_bs, void* kcache, void* vcache, int64_t cache_bs,
                            int64_t cache_hs, int window, void* stream);
 /*  - m5_ar_qkv_rope_batch: the QKV projection of the batched step with that rotation and the cache write fused
  *    into its epilogue: xn [B][K] (dtype) x wqkv [3D][K] -> qbuf / caches; qkv_tmp [B][3D] is scratch for the fp32
  *    (parity mode) path, which runs m5_gemm + m5_ar_rope_cache_batch. */
-int m5_ar_qkv_rope_batch(int dtype, const void* xn, int64_t lda, const void* wqkv, int64_t ldw, int B, int n_heads, int K,
+M5_API int m5_ar_qkv_rope_batch(int dtype, const void* xn, int64_t lda, const void* wqkv, int64_t ldw, int B, int n_heads, int K,
                          const float* rope, const int32_t* state, int32_t state_bs, void* qbuf, int64_t q_bs,
                          void* kcache, void* vcache, int64_t cache_bs, int64_t cache_hs, int window, void* qkv_tmp, void* stream);
-int m5_ar_attn_combine_batch(int dtype, const float* part, int64_t part_bs, int B, int n_heads, int nsplit,
+M5_API int m5_ar_attn_combine_batch(int dtype, const float* part, int64_t part_bs, int B, int n_heads, int nsplit,
                              const int32_t* state, int32_t state_bs, void* out, int64_t out_bs, void* stream);
 
 /* The n_layers Mistral layers of one decode step as ONE persistent launch (csrc/ar_mega.hip): 256 co-resident workgroups,
@@ -263,7 +265,7 @@ typedef struct {
     uint64_t* gran; uint32_t* err;
     unsigned long long* dbg;                               /* diagnostics (tools build): phase stamps of workgroup 0, or NULL */
 } M5ArMegaArgs;
-int m5_ar_layers_persistent(int dtype, const M5ArMegaArgs* a, void* stream);
+M5_API int m5_ar_layers_persistent(int dtype, const M5ArMegaArgs* a, void* stream);
 
 /* Sampler chain of ar_generate.py:74-115 + samplers.py:20-93 on device, then the
  * multinomial draw argmax(p / q) with caller-supplied Exp(1) noise, EOS / max_len
@@ -286,7 +288,7 @@ typedef struct {
     int64_t logits_bs, tokens_bs, noise_bs, xres_bs, eos_table_bs;
     const int32_t* n_est_b; const int32_t* max_len_b;
 } M5SampleArgs;
-int m5_ar_sample(const M5SampleArgs* a, void* stream);
+M5_API int m5_ar_sample(const M5SampleArgs* a, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * NAR reverse-diffusion step tail (diffuser.py:364-393 + :467-468): CFG mix, temperature,
@@ -304,37 +306,37 @@ typedef struct {
     float guidance_w, temperature, log_eps;         /* log_eps = log(1e-7f)                    */
     int32_t div_mode, q0_override_steps;
 } M5NarSampleArgs;
-int m5_nar_sample(const M5NarSampleArgs* a, void* stream);
+M5_API int m5_nar_sample(const M5NarSampleArgs* a, void* stream);
 
 /* AR -> NAR hand-off on device (reference inference.py:272-275 with speechtok.decode_int, minbpe/codebook.py:88-126):
  * tokens[i] (global AR ids, i < n) -> speech-vocabulary id max(tokens[i] - n_text, 0) -> the run of codebook-0 codes that
  * BPE token was merged from: vals[off[id] .. off[id + 1]) (CSR over n_vocab ids; special tokens have empty runs),
  * concatenated in order into out[0 .. *total) (at most out_cap are written; *total is the full length). */
-int m5_expand_tokens(const int64_t* tokens, int n, int n_text, const int32_t* off, const int64_t* vals, int n_vocab,
+M5_API int m5_expand_tokens(const int64_t* tokens, int n, int n_text, const int32_t* off, const int64_t* vals, int n_vocab,
                      int64_t* out, int out_cap, int32_t* total, void* stream);
 
 /* Silence trim on device (reference mars5/trim.py:110-178, librosa.effects.trim semantics with centred reflect-padded
  * frames): y mono fp32 [n]; power: scratch of n_frames = 1 + n / hop floats (left holding the frame powers);
  * bounds[0..1] = [start, end) in samples (0, 0 when everything is silent).  Needs n > frame_length / 2. */
-int m5_trim_bounds(const float* y, int n, int frame_length, int hop, float top_db, float* power, int n_frames,
+M5_API int m5_trim_bounds(const float* y, int n, int frame_length, int hop, float top_db, float* power, int n_frames,
                    int32_t* bounds, void* stream);
 
-int m5_add_int(int32_t* p, int32_t delta, void* stream);
+M5_API int m5_add_int(int32_t* p, int32_t delta, void* stream);
 
 /* hipGraph helpers (capture the launches issued between begin/end on `stream`). */
-int m5_graph_begin(void* stream);
-int m5_graph_end(void* stream, void** graph_exec);
-int m5_graph_launch(void* graph_exec, void* stream);
-int m5_graph_destroy(void* graph_exec);
+M5_API int m5_graph_begin(void* stream);
+M5_API int m5_graph_end(void* stream, void** graph_exec);
+M5_API int m5_graph_launch(void* graph_exec, void* stream);
+M5_API int m5_graph_destroy(void* graph_exec);
 
 /* HIP-event timing on an arbitrary stream (bench roofline measurements). */
-int m5_event_create(void** ev);
-int m5_event_record(void* ev, void* stream);
-int m5_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
-int m5_event_destroy(void* ev);
+M5_API int m5_event_create(void** ev);
+M5_API int m5_event_record(void* ev, void* stream);
+M5_API int m5_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);   /* synchronises on ev_stop */
+M5_API int m5_event_destroy(void* ev);
 /* In-graph timing (bench roofline leg): a one-lane launch that stores the 100 MHz wall clock into *slot (device memory).
  * Captured between two launches of a hipGraph, consecutive stamps bracket the launch between them as the replay runs it. */
-int m5_clock_stamp(uint64_t* slot, void* stream);
+M5_API int m5_clock_stamp(uint64_t* slot, void* stream);
 
 #ifdef M5_TOOLS
 /* ---- tools library only (libmars5_hip_tools.so, built with -DM5_TOOLS; the scripts under tools/ load it with M5_HIP_TOOLS=1).  The
@@ -342,33 +344,33 @@ int m5_clock_stamp(uint64_t* slot, void* stream);
 
 /* Diagnostics: placement census of a grid (nblocks x threads, lds_bytes of LDS per workgroup);
  * out[6 * block] = {XCC_ID, HW_ID, start clock lo/hi, end clock lo/hi}.  tools/census.py. */
-int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int spin, void* stream);
+M5_API int m5_debug_census(uint32_t* out, int nblocks, int threads, int lds_bytes, int spin, void* stream);
 
 /* Diagnostics: n dependent trivial launches (blocks x threads; touch = 1: one read-modify-write of
  * buf[0] per launch) on `stream` -- measures the per-launch floor, eager vs hipGraph.  tools/launch_floor.py. */
-int m5_debug_launch_chain(int32_t* buf, int n, int blocks, int threads, int touch, void* stream);
+M5_API int m5_debug_launch_chain(int32_t* buf, int n, int blocks, int threads, int touch, void* stream);
 
 /* Diagnostics: ONE launch of `blocks` co-resident workgroups that cross `iters` device-wide barriers (agent-scope
  * atomic arrive + bounded acquire spin; mode 1 also passes one word per workgroup across each barrier).
  * scratch: blocks + 4 words; after the run scratch[1] = spin timeouts, scratch[2] = stale reads.  tools/grid_barrier.py. */
-int m5_debug_grid_barrier(uint32_t* scratch, int blocks, int threads, int iters, int mode, void* stream);
+M5_API int m5_debug_grid_barrier(uint32_t* scratch, int blocks, int threads, int iters, int mode, void* stream);
 
 /* Diagnostics: subsequent 16-bit m5_gemm launches record {shader clock, 100 MHz wall clock} at the entry
  * and at the end of the main loop of workgroup 0 into buf[0..3] (device memory); NULL disables. */
-int m5_debug_gemm_clock(unsigned long long* buf);
+M5_API int m5_debug_gemm_clock(unsigned long long* buf);
 
 /* Diagnostics: operand-feed probe -- every workgroup stages the same L2-resident panel into LDS `iters`
  * times; mode 0 LDS-DMA, 1 global_load -> ds_write, 2 global loads only.  tools/feed_probe.py. */
-int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int iters, int row_bytes, int mode, int blocks, int threads,
+M5_API int m5_debug_feed_probe(const void* src, int64_t panel_bytes, int iters, int row_bytes, int mode, int blocks, int threads,
                         float* sink, void* stream);
 
 /* Diagnostics: workgroup b streams chunk (b + shift) % blocks of buf (chunk_bytes each; nt = non-temporal loads): pairs of
  * launches with equal / different shifts measure whether an XCD's L2 keeps lines across a kernel boundary.  tools/l2_retention.py. */
-int m5_debug_l2_touch(const void* buf, int64_t chunk_bytes, int blocks, int threads, int shift, int nt, float* sink, void* stream);
+M5_API int m5_debug_l2_touch(const void* buf, int64_t chunk_bytes, int blocks, int threads, int shift, int nt, float* sink, void* stream);
 /* All-gather edge probe (tools/edge_probe.py): `blocks` co-resident workgroups each publish `per` values of an n-vector
  * as 8-byte {fp32, tag} granules and sweep the whole vector, `iters` times in one launch, optionally under a weight
  * stream of stream_kb KiB per workgroup and edge: the price of one dependency edge of a persistent decode step. */
-int m5_debug_edge_probe(uint64_t* gran, int n, int per, int blocks, int threads, int iters, uint32_t base_tag,
+M5_API int m5_debug_edge_probe(uint64_t* gran, int n, int per, int blocks, int threads, int iters, uint32_t base_tag,
                         const void* wbuf, int stream_kb, uint32_t* err, float* sums, void* stream);
 #endif /* M5_TOOLS */
 

@@ -53,14 +53,17 @@ class ARSamplingConfig:
 # them dispatched at the same time from two streams could each hold half of the CUs and spin for the other half (the spins
 # are bounded, so the result would be an error, not a hang).  Sessions therefore enqueue their persistent launches under
 # one per-device lock, each batch of launches behind the event that closed the previous session's batch.
-_MEGA_LOCK = threading.Lock()
+_MEGA_LOCKS: Dict[int, threading.Lock] = {}
+_MEGA_LOCKS_GUARD = threading.Lock()
 _MEGA_LAST: Dict[int, "torch.cuda.Event"] = {}
 
 
 @contextlib.contextmanager
 def _mega_exclusive(stream: "torch.cuda.Stream", dev: torch.device):
-    with _MEGA_LOCK:
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _MEGA_LOCKS_GUARD:
+        lock = _MEGA_LOCKS.setdefault(key, threading.Lock())       # one lock per device: sessions on different GPUs do not serialise
+    with lock:
         last = _MEGA_LAST.get(key)
         if last is not None:
             stream.wait_event(last)
@@ -321,6 +324,16 @@ class ARSession:
         ev0, ev1 = ops.Event(), ops.Event()
         ev0.record(st)
         done = 0
+        # Recovery point of the persistent form: (steps done, state words, residual-stream input of the next step) at the last
+        # poll whose error word was clean.  If a persistent launch gives up (grid not co-resident: a foreign workgroup held a
+        # CU past the spin bound) the error word is sticky, the remaining launches of the batch return at once and the sampler
+        # runs on a stale residual stream; the host then restores this point, switches the session to the per-launch form
+        # (bit-identical arithmetic, tests/test_gpu_parity16.py) and replays from there -- the request is never lost.
+        snap = None
+        self.mega_recovered = 0
+        if self.mega:
+            with torch.cuda.stream(self.stream):
+                snap = (0, self.state.clone(), self.xdec.clone())
         while done < budget:
             n = min(poll, budget - done)
             need(done + n + 1)                                 # the n steps below read rows done+1 .. done+n
@@ -332,20 +345,40 @@ class ARSession:
                         self.enqueue_layers(st)
                         self.enqueue_head_and_sample(st)
             done += n
+            inject = getattr(self, "_inject_mega_err_at", None)         # tests only: the kernel's sticky error word, set from outside
+            if self.mega and inject is not None and done >= inject:
+                self._inject_mega_err_at = None
+                with torch.cuda.stream(self.stream):
+                    self.mega_err.fill_(1)
+                    self.xdec.mul_(0.5)                                # ... and what it leaves behind: a residual stream that is not the step's
+                    self.state[L.ST_POS] += 3
             with torch.cuda.stream(self.stream):
                 flag = self.state.cpu()                        # syncs this stream only
+                bad = bool(int(self.mega_err.cpu()[0])) if self.mega else False
+            if bad:
+                done0, st0, x0 = snap
+                with torch.cuda.stream(self.stream):
+                    self.state.copy_(st0)
+                    self.xdec.copy_(x0)
+                    self.mega_err.zero_()
+                self.mega = False
+                self.mega_recovered += 1
+                if use_graph:
+                    self.capture()                             # the per-launch form of the step
+                done = done0
+                continue
+            if self.mega:
+                with torch.cuda.stream(self.stream):
+                    snap = (done, self.state.clone(), self.xdec.clone())
             if int(flag[L.ST_DONE]):
                 break
         ev1.record(st)
         self.stream.synchronize()
         final = self.state.cpu()
-        if self.mega and int(self.mega_err.cpu()[0]):
-            raise RuntimeError("persistent AR decode step: a workgroup gave up waiting for its peers (grid not co-resident?); "
-                               "set M5_AR_MEGA=0 to use the per-launch form")
         n_tok = int(final[L.ST_NTOK])
         self.ended_on_eos = bool(int(final[L.ST_DONE])) and int(final[L.ST_LAST]) == int(self._sample_args.eos_idx)
         LAST_STATS.update(decode_ms=ev0.elapsed_ms(ev1), decode_steps_launched=done, n_generated=n_tok - self.P,
-                          prefill_len=self.P + 1, final_len=n_tok, persistent=bool(self.mega))
+                          prefill_len=self.P + 1, final_len=n_tok, persistent=bool(self.mega), persistent_recoveries=self.mega_recovered)
         return self.tokens[:n_tok].clone()
 
 

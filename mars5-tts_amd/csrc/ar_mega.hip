@@ -587,14 +587,10 @@ extern "C" int m5_ar_layers_persistent(int dtype, const M5ArMegaArgs* a, void* s
         a->window <= 0 || a->w_alloc <= 0)
         return M5_ERR_UNSUPPORTED;
     if ((((uintptr_t)a->wqkv | (uintptr_t)a->wo | (uintptr_t)a->w13 | (uintptr_t)a->w2) & 15) || ((uintptr_t)a->gran & 7)) return M5_ERR_ARG;
-    // every workgroup must be resident at once: one per CU
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return M5_ERR_LAUNCH;
-        cus = pr.multiProcessorCount;
-    }
+    // every workgroup must be resident at once: one per CU of the device the CURRENT context runs on (queried per call: the
+    // attribute read is a table lookup, and a process may drive several GPUs from several threads)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return M5_ERR_LAUNCH;
     if (cus < 256) return M5_ERR_UNSUPPORTED;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == M5_F16) hipLaunchKernelGGL(ar_mega_kernel<F16T>, dim3(256), dim3(512), 0, s, *a);

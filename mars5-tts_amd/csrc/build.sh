@@ -4,7 +4,7 @@
 #   libmars5_hip_tools.so  the same sources with -DM5_TOOLS: tuning sweeps / A-B knobs / probes for tools/*.py
 set -e
 cd "$(dirname "$0")"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result"
 SRCS="gemm gemm16 gemm_skinny attention attention16 xattn_absorb rowops ar_decode ar_mega ar_batch nar_sample util"
 build_one() {   # $1 = object dir, $2 = extra flags, $3 = output library
   mkdir -p $1

@@ -73,13 +73,17 @@ __device__ inline float lane_xor1(float v) { return dppf<0xB1>(v); }
 __device__ inline float lane_xor2(float v) { return dppf<0x4E>(v); }
 __device__ inline float lane_xor4(float v) { return dppf<0x141>(dppf<0x1B>(v)); }
 __device__ inline float lane_xor8(float v) { return dppf<0x128>(v); }
+// (All of these exchange between lanes of FULLY ACTIVE waves: DPP reads 0 from an inactive partner (bound_ctrl), the
+// permlane swaps leave an inactive lane's half untouched -- unlike __shfl_xor, which returns the caller's own value.
+// The half a lane keeps is chosen by its LANE id, so block shapes other than 1-D multiples of 64 work too.)
+__device__ inline int m5_lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ inline float lane_xor16(float v) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+    return __uint_as_float((m5_lane_id() & 16) ? r[0] : r[1]);
 }
 __device__ inline float lane_xor32(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+    return __uint_as_float((m5_lane_id() & 32) ? r[0] : r[1]);
 }
 __device__ inline float wave_sum(float v) {                  // v += partner for lane ^ 32, 16, 8, 4, 2, 1
     { const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false); v = __uint_as_float(r[0]) + __uint_as_float(r[1]); }

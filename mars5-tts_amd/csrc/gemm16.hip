@@ -1168,13 +1168,8 @@ int pick_config(int M, int N, int K, int batch, int span_div, int epi) {
 unsigned long long* g_gemm_dbg = nullptr;
 
 int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
     return n;
 }
 

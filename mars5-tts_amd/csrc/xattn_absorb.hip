@@ -30,15 +30,17 @@ __device__ inline f4a_t mfma_a<BF16T>(const uint4& a, const uint4& b, f4a_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const b8a_t*>(&a), *reinterpret_cast<const b8a_t*>(&b), c, 0, 0, 0);
 }
 
-// grid (H, n_seq * n_layers, 2): blockIdx.z = 0 builds A and c, 1 builds B^T, of head blockIdx.x for (layer, sequence)
-// blockIdx.y.  256 threads = 4 waves; wave w owns a quarter of the 1024-wide model dimension.
+// grid (H, n_seq * n_layers, 2 * NPART): blockIdx.z & 1 = 0 builds A and c, 1 builds B^T, of head blockIdx.x for (layer,
+// sequence) blockIdx.y; blockIdx.z >> 1 = which NPART-th of the model dimension.  256 threads = 4 waves; wave w owns a
+// quarter of the workgroup's columns.  (The loop is latency-bound -- global fragments, two MFMAs, a store -- so the
+// columns are spread over 4x more workgroups than rows of work would need: 66 -> ~35 us per reverse step, round 3.)
 // MFMA 16x16x32 with the gemm16 operand order: mfma(Pfrag, Qfrag) -> acc[r] = C[row of Q = l15][row of P = 4 lg + r].
 template <typename T, int JT>      // JT = Lp / 16 key tiles (3 or 4)
 __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, const int64_t* tab_layer, int n_seq, int D, const int32_t* step,
                                                      float scale) {
     using st = typename T::storage;
     constexpr int Lp = JT * 16;
-    const int h = blockIdx.x, ls = blockIdx.y, which = blockIdx.z;
+    const int h = blockIdx.x, ls = blockIdx.y, which = blockIdx.z & 1, part = blockIdx.z >> 1, npart = gridDim.z >> 1;
     const int layer = ls / n_seq;
     const int64_t* ts = tab_seq + (int64_t)ls * 8;
     const int64_t* tl = tab_layer + (int64_t)layer * 4;
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
     const int64_t stp = *step;
     const int H = gridDim.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
-    const int nq = D / 4;                                   // model-dimension columns per wave
+    const int nq = D / (4 * npart);                         // model-dimension columns per wave
+    const int col0 = part * (D / npart);                    // first column of this workgroup
     // memory rows of this head at this step: [Le][64], 16-bit
     const st* mem = reinterpret_cast<const st*>(which == 0 ? ts[0] : ts[1]) + stp * ts[3] + (int64_t)h * le * 64;
     uint4 mf[JT][2];                                        // fragments of the memory rows: row 16 jt + l15, k chunk 4 ks + lg
@@ -68,11 +71,11 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    wf[u][ks] = *reinterpret_cast<const uint4*>(wq + (int64_t)(wave * nq + min(nt0 + u, nq / 16 - 1) * 16 + l15) * 64 + (ks * 4 + lg) * 8);
+                    wf[u][ks] = *reinterpret_cast<const uint4*>(wq + (int64_t)(col0 + wave * nq + min(nt0 + u, nq / 16 - 1) * 16 + l15) * 64 + (ks * 4 + lg) * 8);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (nt0 + u >= nq / 16) break;
-                const int n0 = wave * nq + (nt0 + u) * 16;
+                const int n0 = col0 + wave * nq + (nt0 + u) * 16;
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
                     f4a_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -86,13 +89,13 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
             }
         }
         // c[h Lp + j] = scale * K[j] . bq[h 64 ..]  (fp32);  padded keys: -1e30 (their softmax weight is exactly 0)
-        if (threadIdx.x < Lp) {
+        if (part == 0 && threadIdx.x < Lp) {
             const int j = threadIdx.x;
             float cv = -1e30f;
             if (j < le) {
-                const float* bq = reinterpret_cast<const float*>(tl[2]) + h * 64;
+                const float* bq0 = reinterpret_cast<const float*>(tl[2]);       // nullptr: no query bias
                 float s = 0.f;
-                for (int d = 0; d < 64; ++d) s = fmaf(T::to_f32(mem[(int64_t)j * 64 + d]), bq ? bq[d] : 0.f, s);
+                for (int d = 0; d < 64; ++d) s = fmaf(T::to_f32(mem[(int64_t)j * 64 + d]), bq0 ? bq0[h * 64 + d] : 0.f, s);
                 cv = s * scale;
             }
             reinterpret_cast<float*>(ts[5])[h * Lp + j] = cv;
@@ -108,11 +111,11 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    wf[u][ks] = *reinterpret_cast<const uint4*>(wo + (int64_t)(wave * nq + min(nt0 + u, nq / 16 - 1) * 16 + l15) * D + (ks * 4 + lg) * 8);
+                    wf[u][ks] = *reinterpret_cast<const uint4*>(wo + (int64_t)(col0 + wave * nq + min(nt0 + u, nq / 16 - 1) * 16 + l15) * D + (ks * 4 + lg) * 8);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (nt0 + u >= nq / 16) break;
-                const int n0 = wave * nq + (nt0 + u) * 16;
+                const int n0 = col0 + wave * nq + (nt0 + u) * 16;
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {
                     f4a_t acc = {0.f, 0.f, 0.f, 0.f};
@@ -134,7 +137,8 @@ extern "C" int m5_xattn_absorb(int dtype, const int64_t* tab_seq, const int64_t*
                                int D, int Lp, const int32_t* step, float scale, void* stream) {
     if (!tab_seq || !tab_layer || !step || n_layers <= 0 || n_seq <= 0 || n_heads <= 0) return M5_ERR_ARG;
     if ((dtype != M5_F16 && dtype != M5_BF16) || (Lp != 48 && Lp != 64) || (D % 64)) return M5_ERR_UNSUPPORTED;
-    const dim3 grid(n_heads, n_seq * n_layers, 2);
+    const int npart = (D % 1024 == 0) ? 4 : ((D % 512 == 0) ? 2 : 1);        // 64 columns per wave
+    const dim3 grid(n_heads, n_seq * n_layers, 2 * npart);
     hipStream_t s = (hipStream_t)stream;
 #define M5_ABS(TT, JT) hipLaunchKernelGGL((absorb_kernel<TT, JT>), grid, dim3(256), 0, s, tab_seq, tab_layer, n_seq, D, step, scale)
     if (dtype == M5_F16) { if (Lp == 48) M5_ABS(F16T, 3); else M5_ABS(F16T, 4); }

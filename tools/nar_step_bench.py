@@ -28,6 +28,11 @@ def main():
             kv = dict(s.split("=") for s in v.split(",") if s)
             for k, val in kv.items():
                 os.environ[k] = val
+            # M5_NAR_SAMEW=1 (experiment, WRONG results): every decoder layer uses layer 0's weights, so the step's ~0.5 GB weight
+            # stream collapses to 30 MB that stay cache-resident -- how much of the step is cold-weight latency?
+            if not hasattr(eng, "_dec_orig"):
+                eng._dec_orig = list(eng.dec)
+            eng.dec = [eng._dec_orig[0]] * len(eng._dec_orig) if os.environ.get("M5_NAR_SAMEW") == "1" else list(eng._dec_orig)
             sess = NARSession(eng, NARConfig(T=200))
             sess.prepare(c_text, ref_codes[0].T.contiguous(), x, z, mm, off, list(range(199, 159, -1)))
             gen = torch.Generator(device=dev).manual_seed(1)

@@ -17,6 +17,11 @@ for s in "$@"; do
              timeout 600 python tools/nar_step_bench.py "CUR=r3" > $OUT/narcur.log 2>&1; grep round $OUT/narcur.log ;;
     arbase) M5_HIP_TOOLS_LIB=$PWD/mars5-tts_amd/libmars5_hip_tools_base.so timeout 600 python tools/ar_step_bench.py "BASE=r2" > $OUT/arbase.log 2>&1; echo "arbase rc=$?"; grep round $OUT/arbase.log
             timeout 600 python tools/ar_step_bench.py "CUR=r3" > $OUT/arcur.log 2>&1; grep round $OUT/arcur.log ;;
+    narprof) export TMPDIR=/tmp
+             M5_HIP_TOOLS_LIB=$PWD/mars5-tts_amd/libmars5_hip_tools_base.so timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pbase -o b -- python tools/nar_step_bench.py "BASE=r2" > $OUT/narprof_base.log 2>&1
+             timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pcur -o c -- python tools/nar_step_bench.py "CUR=r3" > $OUT/narprof_cur.log 2>&1
+             grep round $OUT/narprof_base.log $OUT/narprof_cur.log
+             find $OUT -name "*kernel_trace.csv" -delete ;;
     narab) timeout 900 python tools/nar_step_bench.py ${NARAB} > $OUT/narab.log 2>&1; echo "narab rc=$?"; grep round $OUT/narab.log ;;
     arab) timeout 900 python tools/ar_step_bench.py ${ARAB} > $OUT/arab.log 2>&1; echo "arab rc=$?"; grep round $OUT/arab.log ;;
     c3) timeout 900 python bench.py --workload c3 --batch 32 --steps 1 --warmup 1 > $OUT/c3.json 2> $OUT/c3.err; echo "c3 rc=$?"; cat $OUT/c3.json; tail -2 $OUT/c3.err ;;
