@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-batch-leg", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the configs[2] (32 mixed-length requests) and configs[4] (60 s long-form) "
+                    "one-step legs that the default N = 1 run reports beside the headline")
     ap.add_argument("--pipeline", action="store_true", help="also time the same utterances through tts_stream_from_codes (AR of request i+1 "
                     "enqueued beside the NAR steps of request i); measured in round 2: no overlap on this stack (5.90 vs 5.86 audio-s/s)")
     ap.add_argument("--no-graph", action="store_true")
@@ -576,7 +578,32 @@ def parity_leg(m, bundle, ref_codes, dtype_name, n_ar=48):
         flips = [i for i in range(n_gen) if choices[i] != int(toks[P + i])]
         out.update(ar_steps=n_gen, ar_max_abs_dlogit=round(max(err), 5), ar_max_abs_logit=round(max(float(l.abs().max()) for l in lo), 2),
                    ar_greedy_agreement=round((n_gen - len(flips)) / n_gen, 4), ar_first_divergence=flips[0] if flips else None)
-        del sd, lo
+        # ---- the batched decode step (configs[2]): 4 sequences with prompts of 488 / 300 / 150 / 64 tokens advance 12 steps together;
+        # every sequence's logits against the oracle teacher-forced on that sequence's own tokens
+        from mars5_tts_amd.ar_engine import ARBatchSession
+        Ps = [P, 300, 150, 64]
+        prompts = [prompt[:q].clone() for q in Ps]
+        nb = 12
+        bs = ARBatchSession(eng, [q + nb for q in Ps])
+        bs.configure_sampler(ARSamplingConfig(**kw), n_text, n_text + eos_sp, torch.ones(len(Ps), nb, V, device=dev))
+        bs.prefill(prompts, [ref] * len(Ps))
+        bl = []
+        for i in range(nb):
+            if i:
+                bs.enqueue_layers(bs.stream.cuda_stream)
+            bs.enqueue_head_and_sample(bs.stream.cuda_stream)
+            bs.stream.synchronize()
+            bl.append(bs.logits.clone())
+        bstate = bs.state.cpu()
+        worst_b = 0.0
+        for q in range(len(Ps)):
+            tq = bs.tokens[q, : int(bstate[q, L.ST_NTOK])].clone()
+            _, lob, _ = O.ar_generate_oracle(sd, a.nhead, n_text, bundle.n_speech, eos_sp, prompts[q].to(dev), ref.to(dev), Ps[q] + nb, p,
+                                             noise=torch.ones(nb, V), forced=tq, dt=odt)
+            for i in range(min(int(tq.shape[0]) - Ps[q], len(lob), nb)):
+                worst_b = max(worst_b, float((bl[i][q] - lob[i]).abs().max()))
+        out.update(ar_batch_sequences=len(Ps), ar_batch_steps=nb, ar_batch_max_abs_dlogit=round(worst_b, 5))
+        del sd, lo, bs
         # ---- NAR: one decoder pass and one reverse step at the bench shape
         nengine = m.codecnar.engine()
         g = torch.Generator().manual_seed(3)
@@ -805,20 +832,44 @@ def main():
         out["time_split_ms"] = {"ar_decode": round(ar_engine.LAST_STATS["decode_ms"], 1), "nar_loop": round(nar["ms_per_step"] * 200, 1)}
     if world == 1 and args.workload == "c2" and not args.no_batch_leg:
         # throughput mode beside the headline (BASELINE configs[2] in small): 8 mixed-length requests through the batched
-        # AR decode + batched NAR refinement, one untimed-warmup-free pass (~7 s); `--workload c3` is the full 32-request form
+        # AR decode + batched NAR refinement; the SECOND pass is timed (the first one captures the step graphs of these shapes)
         from inference import InferenceConfig
-        texts, trs, refs, max_lens = c3_requests(m, 8, args.n_gen, seed=11)
         bcfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
                                eos_estimated_gen_length_factor=100.0, eos_penalty_factor=50.0, eos_penalty_decay=0.5)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        res = m.tts_batch_from_codes(texts, [r.to(dev) for r in refs], trs, bcfg, seeds=[1000 + j for j in range(8)], nar_batch=8, ar_batch=8,
-                                     max_lens=max_lens)
-        torch.cuda.synchronize()
-        dtb = time.perf_counter() - t0
-        out["batch8_mixed_lengths"] = {"value": round(sum(int(f.shape[0]) for _, f in res) / 75.0 / dtb, 4), "unit": "audio_s/s", "requests": 8,
-                                       "s_per_batch": round(dtb, 3), "reference_frames": [int(r.shape[-1]) for r in refs],
-                                       "note": "tts_batch_from_codes(ar_batch=8, nar_batch=8), single pass incl. graph captures"}
+
+        def batch_leg(n_req, ar_b, nar_b, passes=2):
+            texts, trs, refs, max_lens = c3_requests(m, n_req, args.n_gen, seed=11)
+            refs = [r.to(dev) for r in refs]
+            dtb, res = None, None
+            for ps in range(passes):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                res = m.tts_batch_from_codes(texts, refs, trs, bcfg, seeds=[1000 + j for j in range(n_req)], nar_batch=nar_b, ar_batch=ar_b,
+                                             max_lens=max_lens)
+                torch.cuda.synchronize()
+                dtb = time.perf_counter() - t0
+            return {"value": round(sum(int(f.shape[0]) for _, f in res) / 75.0 / dtb, 4), "unit": "audio_s/s", "requests": n_req,
+                    "s_per_batch": round(dtb, 3), "reference_frames": [int(r.shape[-1]) for r in refs],
+                    "note": f"tts_batch_from_codes(ar_batch={ar_b}, nar_batch={nar_b}), pass {passes} of {passes} timed (pass 1 captures the graphs)"}
+
+        out["batch8_mixed_lengths"] = batch_leg(8, 8, 8)
+        if not args.no_extra_legs:
+            # BASELINE configs[2] in full (32 mixed-length requests per step) and configs[4] (60 s long-form utterance): one
+            # timed step each after one warm-up step, so that the driver's record carries them (`--workload c3 / c5` are the
+            # stand-alone forms with their own time splits)
+            out["c3_batch32"] = batch_leg(32, args.ar_batch, args.nar_batch)
+            text_c2 = TEXT
+            TEXT = " ".join(WORDS[(7 * i) % len(WORDS)] for i in range(150)).capitalize() + "."
+            p5, nt5 = prompt_len(m, ref_codes)
+            cfg5 = make_cfg(nt5, p5, 4500)
+            run_utterance(m, ref_codes, cfg5, 700)
+            dt5, n5, _ = run_utterance(m, ref_codes, cfg5, 701)
+            from mars5_tts_amd import ar_engine as _ae, nar_engine as _ne
+            out["c5_longform"] = {"value": round(n5 / 75.0 / dt5, 4), "unit": "audio_s/s", "s_per_utterance": round(dt5, 3), "generated_frames": n5,
+                                  "ar_us_per_token": round(1e3 * _ae.LAST_STATS["decode_ms"] / max(_ae.LAST_STATS["n_generated"] - 1, 1), 1),
+                                  "nar_ms_per_step": round(_ne.LAST_STATS["loop_ms"] / _ne.LAST_STATS["steps"], 3), "nar_S": _ne.LAST_STATS["S"],
+                                  "note": "BASELINE configs[4]: 60 s target, AR context past the 3000-slot rotating KV window; second utterance timed"}
+            TEXT = text_c2
     if world == 1 and args.workload == "c2" and args.pipeline:
         # serving mode, reported beside (never as) the headline: the same utterances as a pipelined stream -- request i+1's AR
         # decode overlaps request i's NAR steps (Mars5TTS.tts_stream_from_codes); throughput up, per-request latency not

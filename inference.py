@@ -299,11 +299,7 @@ class Mars5TTS:
                                    pr["prompt_codec"].permute(0, 2, 1), diff.num_timesteps, dsh=self._dsh(cfg), diff=diff,
                                    spk_vec=h.nar_spk if h is not None else None, cond_from=h.cond.get(key) if h is not None else None,
                                    stream=streams[1] if streams else None)
-        if h is not None and key not in h.cond:
-            while len(h.cond) >= max(h.max_cond, 1):
-                h.cond.pop(next(iter(h.cond)))                 # oldest first
-            if h.max_cond > 0:
-                h.cond[key] = nar_sess
+        cache_cond = h is not None and key not in h.cond          # inserted only once the request has completed (below)
         ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
                                fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
                                n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
@@ -317,9 +313,20 @@ class Mars5TTS:
             hook_kw = dict(uniform=rng_hooks.uniform, randint=rng_hooks.randint, on_step=getattr(rng_hooks, "nar_on_step", None))
         final_output = perform_simple_inference(self.codecnar, batch, diff, diff.num_timesteps, torch.float16, dsh=self._dsh(cfg),
                                                 retain_quant0=True, generator=generator, session=nar_sess, wait=wait, **hook_kw)
+        def remember_cond():       # the conditioning joins the handle's cache only after the request that built it went through
+            if cache_cond and key not in h.cond and h.max_cond > 0:
+                while len(h.cond) >= max(h.max_cond, 1):
+                    h.cond.pop(next(iter(h.cond)))             # oldest first
+                h.cond[key] = nar_sess
+
         if not wait:               # pipelined serving: the NAR steps are in flight; the caller collects them later
-            return gen_codes_decoded, (lambda: final_output()[0, skip_front:].to(self.device))
+            def collect():
+                out = final_output()[0, skip_front:].to(self.device)
+                remember_cond()
+                return out
+            return gen_codes_decoded, collect
         final_output = final_output[0, skip_front:].to(self.device)
+        remember_cond()
         return gen_codes_decoded, final_output
 
     @torch.inference_mode()

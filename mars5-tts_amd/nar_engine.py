@@ -163,6 +163,12 @@ class NARSession:
         assert other.cfg == self.cfg and other.m is self.m
         self.times, self.nb, self.t_dec, self.mems, self.consts = other.times, other.nb, other.t_dec, other.mems, other.consts
         self._keep = getattr(other, "_keep", [])
+        # order this session's stream behind the donor's conditioning work (recorded at the end of its prepare_cond): the donor
+        # may still be running on another stream / worker thread
+        ev = getattr(other, "cond_ready", None)
+        if ev is not None:
+            self.stream.wait_event(ev)
+        self.cond_ready = ev
 
     def prepare_cond(self, c_text: torch.Tensor, c_codes: torch.Tensor, times: Optional[List[int]] = None,
                      spk_vec: Optional[torch.Tensor] = None) -> None:
@@ -232,6 +238,8 @@ class NARSession:
                 self.mems.append(CrossMemory(k, vt, Le, Lep, nb))
             self.consts = nar_step_consts(self.times, K, tables=self.diff_tables).to(dev)
             self._keep = [table, t_enc, mem]
+            self.cond_ready = torch.cuda.Event()
+            self.cond_ready.record(self.stream)
 
     def prepare_loop(self) -> None:
         """Loop-body buffers of a single-utterance session."""
