@@ -142,7 +142,13 @@ __device__ inline void wait_younger(int y, bool full_share) {
 // 408 cycles of MFMA issue (profiles/r3a_gemm_ablation.txt); hipBLASLt's 128x96 kernel runs these shapes 1.5-1.8x faster
 // (profiles/r3a_blas_yardstick.txt).  The K-step's fragments are all in registers at the barrier, so the slot just read
 // is refilled one K-step earlier than in the plain loop (NSTAGE K-steps of DMA in flight instead of NSTAGE-1).
-template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false>
+// FAST (round 3): the instantiation for aligned, vectorisable operands -- every shape of the NAR / AR engines.  The general
+// kernel carries a scalar / per-element fallback next to each vector path of its prologue and epilogues; those fallbacks are
+// never taken on the engines' shapes but sit BETWEEN the pieces of the hot path, which a workgroup walks once, instruction-
+// cache cold (the step alternates between a dozen kernels): measured, the identical slow path became 6.5 us per launch slower
+// when the kernel merely grew from 2100 to 2500 instructions, and the "fixed" cost of a launch is ~10 us against 3.6 us for
+// hipBLASLt's kernels (profiles/r3m_*).  FAST compiles the fallbacks out: straight-line code, a fraction of the size.
+template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, bool FAST = false>
 __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_kernel(Gemm16Params p) {
     using st = typename T::storage;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
@@ -263,7 +269,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     auto preload_c = [&]() {
         if constexpr (PRELOAD_C) {
             const float* Cr = reinterpret_cast<const float*>(p.C) + (int64_t)bz * p.sC;
-            if (p.fast_c) {                                  // rows clamped (a row past M is never stored), columns by whole float4s
+            if (FAST || p.fast_c) {                          // rows clamped (a row past M is never stored), columns by whole float4s
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const float* rp = Cr + (int64_t)min(m0 + wm * TM * 16 + i * 16 + l15, p.M - 1) * p.ldc;
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 }
                 return;
             }
+            if constexpr (!FAST) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = m0 + wm * TM * 16 + i * 16 + l15;
@@ -294,6 +301,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                         }
                     }
                 }
+            }
             }
         }
     };
@@ -349,7 +357,14 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     constexpr bool HOIST_B = TM * TN * 4 * (PRELOAD_C ? 2 : 1) + (TM + TN) * 4 * (PF ? 2 : 1) + TN * 4 + 48 <= 512 / WAVES_PER_SIMD;
     float bvh[TN][4];
     auto load_bias = [&]() {
-        if (bias && ((reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (p.N & 3) == 0 && p.N >= 4) {    // whole float4s, column clamped
+        if (FAST && !bias) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bvh[j][r] = 0.f;
+            return;
+        }
+        if (FAST || (bias && ((reinterpret_cast<uintptr_t>(bias) & 15) == 0) && (p.N & 3) == 0 && p.N >= 4)) {    // whole float4s, column clamped
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const float4 t4 = *reinterpret_cast<const float4*>(bias + min(n0 + wn * TN * 16 + j * 16 + lg * 4, p.N - 4));
@@ -357,6 +372,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             }
             return;
         }
+        if constexpr (!FAST) {
         const bool bvec = bias && ((reinterpret_cast<uintptr_t>(bias) & 15) == 0);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -369,6 +385,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 for (int r = 0; r < 4; ++r) bvh[j][r] = bias ? bias[min(col + r, p.N - 1)] : 0.f;
             }
         }
+        }
     };
     // (hipcc cannot sink these loads below the loop: the DMA statements inside it clobber "memory")
     // bias of column tile j as the epilogues consume it: the hoisted registers, or -- no budget for them -- loaded on the spot
@@ -378,8 +395,13 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             for (int r = 0; r < 4; ++r) b4[r] = bvh[j][r];
         } else {
             const int col = n0 + wn * TN * 16 + j * 16 + lg * 4;
+            if constexpr (FAST) {
+                const float4 t4 = bias ? *reinterpret_cast<const float4*>(bias + min(col, p.N - 4)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                b4[0] = t4.x; b4[1] = t4.y; b4[2] = t4.z; b4[3] = t4.w;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) b4[r] = bias ? bias[min(col + r, p.N - 1)] : 0.f;
+                for (int r = 0; r < 4; ++r) b4[r] = bias ? bias[min(col + r, p.N - 1)] : 0.f;
+            }
         }
     };
 
@@ -474,7 +496,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             constexpr int R = decltype(r_tag)::value;
             if (nk - 1 - kt == R) { kstep(kt, std::integral_constant<int, (R - 1 < NSTAGE - 2 ? R - 1 : NSTAGE - 2)>{}, std::false_type{}); ++kt; }
         };
-        static_assert(NSTAGE <= 4, "tail unrolled for up to 3 K-steps");
+        static_assert(NSTAGE <= 5, "tail unrolled for up to 4 K-steps");
+        if constexpr (NSTAGE >= 5) tail(std::integral_constant<int, 4>{});
         if constexpr (NSTAGE >= 4) tail(std::integral_constant<int, 3>{});
         if constexpr (NSTAGE >= 3) tail(std::integral_constant<int, 2>{});
         tail(std::integral_constant<int, 1>{});
@@ -747,8 +770,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         constexpr int RBQ = 128 + 16;                         // Q/K stage row: 64 d
         constexpr int RBV = TM * 32 + 16;                     // V^T stage row: TM*16 s
         constexpr int WSZ = (TM * 16 * RBQ > 64 * RBV) ? TM * 16 * RBQ : 64 * RBV;
+        static_assert(!FAST || NW * WSZ <= NSTAGE * STAGE, "FAST QKV: the staged scatter must fit the stage buffers");
         if constexpr (NW * WSZ <= NSTAGE * STAGE) {
-            if (p.qkv_stage) {
+            if (FAST || p.qkv_stage) {
                 __syncthreads();
                 unsigned char* ws = lds + wave * WSZ;
                 const int ncol0 = n0 + wn * 64;                // this wave's first column: one (section, head)
@@ -908,8 +932,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         constexpr int RB = OUTC * 2;                                      // bytes per output row
         constexpr int RBS = RB + 16;                                      // padded LDS row stride
         constexpr int CPR = RB / 16, RPP = 64 / (CPR > 0 ? CPR : 1);      // 16-byte chunks per row, rows per pass
+        static_assert(!FAST || (RB % 16 == 0 && NW * TM * 16 * RBS <= NSTAGE * STAGE), "FAST 16-bit epilogue: staged stores must fit");
         if constexpr (RB % 16 == 0 && NW * TM * 16 * RBS <= NSTAGE * STAGE) {
-            if (p.vec16) {
+            if (FAST || p.vec16) {
                 __syncthreads();                                          // every wave is done reading the stages
                 unsigned char* ws = lds + wave * (TM * 16 * RBS);
 #pragma unroll
@@ -965,7 +990,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
     for (int j = 0; j < TN; ++j) bias_j(j, bv[j]);
     if constexpr (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL) {
-        if (p.fast_c && (EPI == M5_EPI_F32 || PRELOAD_C)) {
+        static_assert(!FAST || EPI == M5_EPI_F32 || PRELOAD_C, "FAST residual epilogue needs the preloaded C tile");
+        if ((FAST || p.fast_c) && (EPI == M5_EPI_F32 || PRELOAD_C)) {
             float* Cf = reinterpret_cast<float*>(Cb);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -1087,8 +1113,24 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
 }
 
+// Is the FAST instantiation (vector paths only) of epilogue E compilable for this tiling?  (the staged epilogues need their
+// output tile to fit the dead stage buffers; the residual one needs the preloaded C tile)
+constexpr bool fast_ok(int E, int WM, int WN, int TM, int TN, int BKB, int NSTAGE) {
+    const int NW = WM * WN, STAGE = (WM * TM * 16 + WN * TN * 16) * BKB;
+    if (E == M5_EPI_F32) return true;
+    if (E == M5_EPI_RESIDUAL) return TM * TN <= 16;
+    if (E == M5_EPI_DT || E == M5_EPI_SILU_DT) return NW * TM * 16 * (TN * 32 + 16) <= NSTAGE * STAGE;
+    if (E == M5_EPI_SWIGLU) return NW * TM * 16 * (TN * 16 + 16) <= NSTAGE * STAGE;
+    if (E == M5_EPI_QKV) {
+        const int RBQ = 128 + 16, RBV = TM * 32 + 16;
+        const int WSZ = (TM * 16 * RBQ > 64 * RBV) ? TM * 16 * RBQ : 64 * RBV;
+        return TN == 4 && NW * WSZ <= NSTAGE * STAGE;
+    }
+    return false;
+}
+
 template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false>
-int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
+int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = false) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
     const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
@@ -1096,7 +1138,13 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s) {
     p.nblk = (int)nblk;
     p.group_m = max(1, GROUP_M * 128 / BM);
     const dim3 grid(p.nblk), blk(WM * WN * 64);
-#define M5_G16(E) hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF>), grid, blk, 0, s, p)
+#define M5_G16(E)                                                                                                          \
+    do {                                                                                                                   \
+        if constexpr (fast_ok(E, WM, WN, TM, TN, BKB, NSTAGE)) {                                                           \
+            if (fast) { hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, true>), grid, blk, 0, s, p); break; } \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, false>), grid, blk, 0, s, p);        \
+    } while (0)
     switch (epi) {
         case M5_EPI_F32: M5_G16(M5_EPI_F32); break;
         case M5_EPI_DT: M5_G16(M5_EPI_DT); break;
@@ -1122,21 +1170,23 @@ static const CfgInfo kCfg[] = {
     {192, 384, 6, 1, 8.f, 2.10f, M5_EPI_SWIGLU},  // 5: region 192x384, 16 waves (4x4 of 48x96), 2 stages (the QKV / residual
                                                   //    epilogues spill at 128 VGPRs: SwiGLU only)
     {192, 192, 4, 1, 7.f, 1.40f, -2},             // 6: region 192x192, 6 waves (2x3 of 96x64), 3 stages (sweeps: superseded by 2)
-    { 96, 128, 4, 1, 8.f, 0.40f, -1},             // 7: = 3 with the prefetched-fragment K loop (PF)
+    { 96, 128, 4, 1, 8.f, 0.48f, -1},             // 7: = 3 with the prefetched-fragment K loop (PF); 0.45-0.48 us per K-step measured hot
+    { 96, 128, 4, 1, 8.f, 0.48f, -2},             // 8: = 7 with 5 stages (140 KB of LDS: five K-steps of DMA in flight)
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 template <typename T>
-int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s) {
+int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast) {
     switch (cfg) {
-        case 0: return launch16<T, 2, 2, 4, 4, 128, 2, 2>(epi, p, batch, s);
-        case 1: return launch16<T, 2, 4, 6, 6, 128, 2, 1>(epi, p, batch, s);
-        case 2: return launch16<T, 4, 3, 3, 4, 128, 3, 1>(epi, p, batch, s);
-        case 3: return launch16<T, 2, 2, 3, 4, 128, 4, 1>(epi, p, batch, s);
-        case 4: return launch16<T, 2, 4, 3, 2, 128, 2, 2>(epi, p, batch, s);
-        case 5: return launch16<T, 4, 4, 3, 6, 128, 2, 1>(epi, p, batch, s);
-        case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s);
-        case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true>(epi, p, batch, s);
+        case 0: return launch16<T, 2, 2, 4, 4, 128, 2, 2>(epi, p, batch, s, fast);
+        case 1: return launch16<T, 2, 4, 6, 6, 128, 2, 1>(epi, p, batch, s, fast);
+        case 2: return launch16<T, 4, 3, 3, 4, 128, 3, 1>(epi, p, batch, s, fast);
+        case 3: return launch16<T, 2, 2, 3, 4, 128, 4, 1>(epi, p, batch, s, fast);
+        case 4: return launch16<T, 2, 4, 3, 2, 128, 2, 2>(epi, p, batch, s, fast);
+        case 5: return launch16<T, 4, 4, 3, 6, 128, 2, 1>(epi, p, batch, s, fast);
+        case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s, fast);
+        case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true>(epi, p, batch, s, fast);
+        case 8: return launch16<T, 2, 2, 3, 4, 128, 5, 1, true>(epi, p, batch, s, fast);
         default: return M5_ERR_ARG;
     }
 }
@@ -1238,7 +1288,9 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
     p.nblk = (int)nblk; p.group_m = max(1, GROUP_M * 128 / BM);
     const dim3 grid(p.nblk);
     hipStream_t s = (hipStream_t)stream;
-#define M5_XS(TT, WMv, TMv, TNv, NSv, OCv, PFv) hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv, PFv>), grid, dim3(WMv * 128), 0, s, p)
+    const bool xs_fast = (((uintptr_t)c & 15) == 0) && (sc_tab % 4 == 0) && m5_tool_env("M5_GEMM_FAST") == nullptr;
+#define M5_XS(TT, WMv, TMv, TNv, NSv, OCv, PFv) do { if (xs_fast) hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv, PFv, true>), grid, dim3(WMv * 128), 0, s, p); \
+        else hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv, PFv, false>), grid, dim3(WMv * 128), 0, s, p); } while (0)
 #ifdef M5_TOOLS
 #define M5_XS_CFG(TT, TNv) do { if (cfg == 1) M5_XS(TT, 4, 1, TNv, 2, 2, false); else if (cfg == 2) M5_XS(TT, 4, 2, TNv, 2, 2, false); else if (cfg == 3 || !off32) M5_XS(TT, 2, 3, TNv, 4, 1, false); else M5_XS(TT, 2, 3, TNv, 4, 1, true); } while (0)
 #else
@@ -1337,6 +1389,7 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
         p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     }
     if (const char* ab = m5_tool_env("M5_GEMM_ABL")) p.abl = atoi(ab);
+    if (const char* fc = m5_tool_env("M5_GEMM_FASTC")) { if (atoi(fc) == 0) p.fast_c = 0; }
     const char* fe = m5_tool_env("M5_GEMM_CFG");             // tuning sweeps (tools build only); read per call on purpose
     int forced = (fe && fe[0]) ? atoi(fe) : -1;
     if (forced < 0) {                                        // per-epilogue override: M5_GEMM_CFG_E<epi>=<n>
@@ -1354,6 +1407,13 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     if (cfg == 7 && !off32) cfg = 3;
     // (PF on the multi-wave configurations 2 and 0 measured SLOWER -- their co-resident waves already cover the LDS latency:
     // QKV 26.7 -> 37.0 us, 34.8 -> 38.6 us; profiles/r3b_gemm_pf_ab.txt -- and was removed)
-    if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s);
-    return launch_cfg<BF16T>(cfg, epi, p, batch, s);
+    // FAST instantiation: every vector path of this epilogue applies (the engines' shapes always qualify)
+    const bool bias_ok = (N % 4 == 0) && N >= 4 && (!bias || ((((uintptr_t)bias & 15) == 0) && (sBias % 4 == 0)));
+    bool fast = bias_ok && (K % 64 == 0);
+    if (epi == M5_EPI_F32 || epi == M5_EPI_RESIDUAL) fast = fast && p.fast_c;
+    else if (epi == M5_EPI_QKV) fast = fast && p.qkv_stage;
+    else fast = fast && p.vec16;
+    if (const char* fk = m5_tool_env("M5_GEMM_FAST")) { if (atoi(fk) == 0) fast = false; }      // same-process A/B (tools build)
+    if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s, fast);
+    return launch_cfg<BF16T>(cfg, epi, p, batch, s, fast);
 }

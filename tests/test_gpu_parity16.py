@@ -518,6 +518,7 @@ def test_nar_full_size_16bit_forward_and_step_vs_oracle(dev, full_bundle, dt):
             if tq == t:
                 keep = (ref, s_unk, s_kn, u1, u2, sess2.consts)
         ref, s_unk, s_kn, u1, u2, consts_t = keep
+        lc, lu = res["f32"][4], res["f32"][5]                   # the t = 100 logits again (the loop above ended at t = 0)
         # ---- the fused posterior / sample kernel at bench size on the ORACLE's logits: ids equal up to excused ties
         Kp = (K + 3) // 4 * 4
         lgc = torch.zeros(so, 7, Kp)

@@ -122,7 +122,43 @@ CASES = [
     ("big qkv", 35840, 3072, 1024, L.EPI_QKV, True, 2240),
 ]
 
+def run_heads(name="nar heads x7"):
+    """the 7-head logits GEMM of one reverse step exactly as nar_engine enqueues it (batch 7, N = 1025, strided C)"""
+    nb_so, D, K1, Q1 = 1798, 1024, 1025, 7
+    Kp = 1028
+    g = torch.Generator(device="cpu").manual_seed(1)
+    hn = (torch.randn(Q1, nb_so, D, generator=g) * 0.5).to(dev, dt)
+    w = (torch.randn(Q1, K1, D, generator=g) / 32).to(dev, dt)
+    b = torch.randn(Q1, K1, generator=g).to(dev)
+    logits = torch.zeros(nb_so, Q1, Kp, device=dev)
+    stream = torch.cuda.Stream()
+    st = stream.cuda_stream
+    call = lambda: ops.gemm(hn[0], w[0], logits, L.EPI_F32, bias=b, ldc=Q1 * Kp, batch=Q1, sA=nb_so * D, sW=K1 * D, sC=Kp, sBias=K1, stream=st)
+    with torch.cuda.stream(stream):
+        call()
+        stream.synchronize()
+        ref = torch.einsum("qmk,qnk->mqn", hn.float(), w.float()) + b[None]
+        err = float((logits[..., :K1] - ref).abs().max())
+        ops.Graph.begin(st)
+        for _ in range(REP):
+            call()
+        gr = ops.Graph().end(st)
+        gr.launch(st)
+        stream.synchronize()
+        e0, e1 = ops.Event(), ops.Event()
+        e0.record(st)
+        for _ in range(5):
+            gr.launch(st)
+        e1.record(st)
+        stream.synchronize()
+    us = e0.elapsed_ms(e1) * 1e3 / (5 * REP)
+    print(f"{name:40s} M={nb_so * Q1:6d} N={K1:5d} K={D:5d} epi=0  {us:8.2f} us  {2.0 * nb_so * Q1 * K1 * D / us / 1e6:7.1f} TF  maxerr={err}", flush=True)
+
+
 if __name__ == "__main__":
+    if os.environ.get("HEADS") == "1":
+        run_heads()
+        sys.exit(0)
     res = []
     cfgs = [int(c) for c in os.environ.get("SWEEP", "").split(",") if c != ""]
     if os.environ.get("M5_GEMM_V1") == "1" or not cfgs:
