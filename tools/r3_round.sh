@@ -4,6 +4,11 @@ TAG=${1:-r3}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+# a box whose GPU faults on the first copy (seen once in round 3: every process died in its first H2D transfer and the last
+# leg then sat in its timeout) must not eat the round's GPU minutes
+if ! timeout 120 python -c "import torch; x = torch.ones(1 << 20, device='cuda'); assert float((x * 2).sum().cpu()) == float(2 << 20)" > $OUT/sanity.log 2>&1; then
+  echo "GPU sanity check failed on this box: giving up"; tail -3 $OUT/sanity.log; exit 3
+fi
 for s in "$@"; do
   case $s in
     test) timeout 1700 python -m pytest tests -m gpu -x -q -s --durations=15 > $OUT/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed|error" $OUT/pytest.log | tail -3 ;;
