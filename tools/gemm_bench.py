@@ -104,6 +104,7 @@ def run_case(name, M, N, K, epi, bias=True, rpb=None, check=True, pad=0):
 
 CASES = [
     ("nar self qkv", 2816, 3072, 1024, L.EPI_QKV, True, 1408),
+    ("nar l0 qkv", 1408, 3072, 1024, L.EPI_QKV, True, 1408),        # layer 0's shared self-attention block: one branch
     ("nar out_proj", 2816, 1024, 1024, L.EPI_RESIDUAL, True, None),
     ("nar cross q", 2816, 1024, 1024, L.EPI_QKV, True, 1408),
     ("nar swiglu", 2816, 6144, 1024, L.EPI_SWIGLU, False, None),

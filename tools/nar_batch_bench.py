@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """NAR reverse-step cost against the number of utterances refined together (BASELINE config 3).
-usage: python tools/nar_batch_bench.py [U ...]   (default 1 2 4 8; all utterances S = 1349 unless MIXED=1)"""
+usage: python tools/nar_batch_bench.py [U ...]   (default 1 2 4 8; all utterances S = 1349 unless MIXED=1)
+CONC=1: for every U also TWO sessions of U utterances each on two streams, steps enqueued alternately (two groups in flight)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -55,6 +56,29 @@ def main():
         fl = sum(eng.flops_per_step(s.S, s.mems[0].Le, s.s_out) for s in sess.subs)
         print(f"U={U:3d} rows={sess.ws.M:6d} (real {sum(2 * s.S for s in sess.subs)})  {ms:8.3f} ms/step  {ms / U:7.3f} ms/step/utt  "
               f"{fl / ms / 1e9:7.1f} TF", flush=True)
+        if os.environ.get("CONC") == "1":
+            pair = []
+            for k in range(2):
+                s2 = NARBatchSession(eng, NARConfig(T=200))
+                s2.prepare(items, times)
+                s2.run(unis, True, n_steps=3)
+                pair.append(s2)
+            ev = [(ops.Event(), ops.Event()) for _ in pair]
+            for s2, (a0, _) in zip(pair, ev):
+                s2.stream.synchronize()
+            for s2, (a0, _) in zip(pair, ev):
+                a0.record(s2.stream.cuda_stream)
+            for _ in range(n):
+                for s2 in pair:
+                    s2.step(unis, True)
+            for s2, (_, a1) in zip(pair, ev):
+                a1.record(s2.stream.cuda_stream)
+            for s2 in pair:
+                s2.stream.synchronize()
+            ms2 = max(a0.elapsed_ms(a1) for a0, a1 in ev) / n
+            print(f"U={U:3d} x 2 sessions on two streams: {ms2:8.3f} ms per step pair  {ms2 / (2 * U):7.3f} ms/step/utt  "
+                  f"({ms / U / (ms2 / (2 * U)):.3f}x the single-session rate)", flush=True)
+            del pair
         del sess, items
 
 

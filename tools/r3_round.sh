@@ -39,6 +39,10 @@ for s in "$@"; do
     gemmtest) timeout 900 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "gemm or absorbed" > $OUT/gemmtest.log 2>&1; echo "gemmtest rc=$?"; tail -5 $OUT/gemmtest.log ;;
     gemmab) for pf in 0 1; do echo "== M5_GEMM_PF=$pf"; M5_GEMM_PF=$pf ONLY="nar out_proj,nar linear2,nar head (1 of 7),big out_proj,big linear2" timeout 300 python tools/gemm_bench.py 2>&1 | grep -E "nar |big "; done > $OUT/gemm_pf_ab.log 2>&1
             echo "gemmab rc=$?"; cat $OUT/gemm_pf_ab.log ;;
+    conc) timeout 600 python tools/nar_concurrent_probe.py > $OUT/conc.log 2>&1; echo "conc rc=$?"; grep -E "round|Error" $OUT/conc.log ;;
+    l0qkv) SWEEP=${SWEEP:-0,1,2,3,4,7} ONLY="nar l0 qkv" timeout 300 python tools/gemm_bench.py > $OUT/l0qkv.log 2>&1; echo "l0qkv rc=$?"; grep "nar " $OUT/l0qkv.log ;;
+    concb) CONC=1 MIXED=${MIXED:-1} timeout 900 python tools/nar_batch_bench.py ${CONCB:-4 8} > $OUT/concb.log 2>&1; echo "concb rc=$?"; grep "U=" $OUT/concb.log ;;
+    pmcres) NOATTN=1 ONLY="nar out_proj,nar linear2" bash tools/pmc_traffic.sh $TAG/pmc > $OUT/pmcres.log 2>&1; echo "pmcres rc=$?"; cat $OUT/pmc/summary.txt | head -60 ;;
     smoke) timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
