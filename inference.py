@@ -332,7 +332,8 @@ class Mars5TTS:
     @torch.inference_mode()
     def tts_batch_from_codes(self, texts: List[str], prompt_codecs: List[Tensor], ref_transcripts: List[Optional[str]],
                              cfg: InferenceConfig = InferenceConfig(), seeds: Optional[List[int]] = None,
-                             nar_batch: int = 8, ar_batch: int = 1, max_lens: Optional[List[int]] = None) -> List[Tuple[Tensor, Tensor]]:
+                             nar_batch: int = 8, ar_batch: int = 1, max_lens: Optional[List[int]] = None,
+                             nar_in_flight: int = 2) -> List[Tuple[Tensor, Tensor]]:
         """Several independent requests on one GPU (BASELINE config 3).  Request i gets a private
         device generator seeded ``seeds[i]`` and consumes it as a lone call would.
         NAR: up to `nar_batch` requests of similar length are refined per decoder pass
@@ -341,7 +342,10 @@ class Mars5TTS:
         AR: `ar_batch` = 1 decodes request by request (the batch-1 weight-streaming GEMV path, bit-equal to
         the lone call); `ar_batch` > 1 decodes that many requests per step (``ar_generate_batch``: the weights
         are read once per step for all of them; logits then differ from the lone call by GEMM summation
-        order, like any batch-size change does in the reference)."""
+        order, like any batch-size change does in the reference).
+        `nar_in_flight`: how many NAR groups are refined at once, each on its own stream (a group's 200 dependent step
+        graphs leave per-launch bubbles that another group's launches fill, and the host prepares the next group while the
+        previous ones run; results do not depend on it)."""
         n = len(texts)
         assert len(prompt_codecs) == n and len(ref_transcripts) == n
         gens = []
@@ -375,12 +379,23 @@ class Mars5TTS:
         # group requests of similar total NAR length: the batch is padded to its longest member
         order = sorted(range(n), key=lambda i: staged[i][1][4].shape[1] + staged[i][2])
         finals: List[Optional[Tensor]] = [None] * n
+        flying: List[tuple] = []                     # (group, callable that waits for it), oldest first
+        lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nar_in_flight))] if self.device.type == "cuda" else [None]
+
+        def land():
+            grp, wait_for = flying.pop(0)
+            for i, o in zip(grp, wait_for()):
+                finals[i] = o[0, staged[i][2]:].to(self.device)
+
         for g0 in range(0, n, max(1, nar_batch)):
             grp = order[g0:g0 + max(1, nar_batch)]
-            outs = perform_batch_inference(self.codecnar, [staged[i][1] for i in grp], diff, diff.num_timesteps, dsh=self._dsh(cfg),
-                                           generators=[gens[i] for i in grp])
-            for i, o in zip(grp, outs):
-                finals[i] = o[0, staged[i][2]:].to(self.device)
+            if len(flying) >= max(1, nar_in_flight):
+                land()
+            lane = lanes[(g0 // max(1, nar_batch)) % len(lanes)]       # a lane's previous group has landed: groups land oldest first
+            flying.append((grp, perform_batch_inference(self.codecnar, [staged[i][1] for i in grp], diff, diff.num_timesteps,
+                                                        dsh=self._dsh(cfg), generators=[gens[i] for i in grp], wait=False, stream=lane)))
+        while flying:
+            land()
         return [(staged[i][0], finals[i]) for i in range(n)]
 
     @torch.inference_mode()

@@ -84,19 +84,29 @@ class SeqWorkspace:
     B > 1.  The pad rows are ordinary finite rows (zero-initialised, never attended to: keys >= S
     are masked and never loaded); V^T rows are padded to whole 64-key tiles."""
 
-    def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev, row_pad: int = 1, fuse_ln: bool = False):
+    def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev, row_pad: int = 1, fuse_ln: bool = False,
+                 inside: Optional["SeqWorkspace"] = None):
+        """`inside`: lay this workspace over the front of a larger one's buffers instead of allocating (a sub-problem that
+        runs strictly between two uses of the larger workspace -- the one-branch layer-0 block, the generated-rows-only last
+        layer: the bytes it touches are then the ones the surrounding launches keep warm in L2 / the Infinity Cache)."""
         self.B, self.S, self.D, self.FF, self.dt = B, S, D, FF, dt
         self.H = D // 64
         self.Sr = round_up(S, row_pad)
         self.Sp = round_up(self.Sr, 64)
         M = B * self.Sr
         self.M = M
-        self.xn = torch.zeros(M, D, dtype=dt, device=dev)
-        self.q = torch.zeros(B, self.H, self.Sr, 64, dtype=dt, device=dev)
-        self.k = torch.zeros(B, self.H, self.Sr, 64, dtype=dt, device=dev)
-        self.vt = torch.zeros(B, self.H, 64, self.Sp, dtype=dt, device=dev)
-        self.att = torch.zeros(M, D, dtype=dt, device=dev)
-        self.hff = torch.zeros(M, FF, dtype=dt, device=dev)
+        if inside is not None:
+            assert inside.dt == dt and inside.D == D and inside.FF == FF and M <= inside.M and B * self.Sp <= inside.B * inside.Sp
+            front = lambda t, *shape: t.view(-1)[: int(torch.Size(shape).numel())].view(*shape)       # noqa: E731
+        else:
+            front = lambda t, *shape: torch.zeros(*shape, dtype=dt, device=dev)                       # noqa: E731
+        src = inside
+        self.xn = front(src.xn if src else None, M, D)
+        self.q = front(src.q if src else None, B, self.H, self.Sr, 64)
+        self.k = front(src.k if src else None, B, self.H, self.Sr, 64)
+        self.vt = front(src.vt if src else None, B, self.H, 64, self.Sp)
+        self.att = front(src.att if src else None, M, D)
+        self.hff = front(src.hff if src else None, M, FF)
         # scratch of the fused residual + LayerNorm GEMM (partials + counters, zero between launches); None = never fuse
         self.ln_scratch = None
         if fuse_ln and dt != torch.float32:
@@ -332,11 +342,15 @@ def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, ste
 
 
 def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
-                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None, xa=None, plan=None, layer: int = 0) -> bool:
+                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None, xa=None, plan=None, layer: int = 0,
+                  before_cross=None) -> bool:
     """One pre-LN decoder layer.  Each residual GEMM tries to leave the NEXT LayerNorm's output in ws.xn (fused
     epilogue); `normed` says the caller (previous layer) already did that for norm1, the return value says whether
-    `next_ln` (the following layer's norm1) has been applied on exit."""
+    `next_ln` (the following layer's norm1) has been applied on exit.  `before_cross()` runs between the self- and the
+    cross-attention block (the join of the side stream that builds the step's cross-attention operands)."""
     n = self_attn_block(x, lw, ws, key_len, stream, normed=normed, next_ln=(lw.n2_w, lw.n2_b))
+    if before_cross is not None:
+        before_cross()
     n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b), xa=xa, plan=plan, layer=layer)
     return ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream, normed=n, next_ln=next_ln)
 

@@ -16,6 +16,12 @@
 // k-slot group of the P^T operand and one ds_read_b128 of the V^T row.
 // LDS image of both tiles: [64 rows][128 B], 16-byte chunk index XOR ((row >> 1) & 7), applied on
 // the DMA source address and on the fragment reads (conflict-free for ds_read_b128's lane groups).
+//
+// KH = 2 (round 3): the 64 keys of a tile are split over TWO waves per 32-query group (keys 32 kh .. +31 of every tile:
+// one 32x32 score block and one k-half of the PV product each); a workgroup is then 2 query groups x 2 key halves = 64
+// queries, and the halves' (m, l, O) merge once through LDS after the key loop.  Same LDS reads and MFMAs per query, twice
+// the waves: at one utterance (352 query blocks of 128 on 256 CUs = 1.4 waves per SIMD) a wave's MFMA, softmax-VALU and
+// ds_read phases have no other wave to overlap with; with 704 workgroups of 64 queries there are 2.75.
 #include "common.h"
 #include <stdlib.h>
 
@@ -53,16 +59,20 @@ constexpr int NST = 3;
 
 // VARIANT: 0 = product kernel; 1..3 = timing ablations (WRONG results; M5_ATTN_VARIANT, tools only):
 // 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.
-template <typename T, int NWAVE, int VARIANT>
+template <typename T, int NWAVE, int VARIANT, int KH = 1>
 __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p) {
     using st = typename T::storage;
-    constexpr int QB = 32 * NWAVE;
+    static_assert(KH == 1 || (KH == 2 && NWAVE % 2 == 0), "key halves");
+    constexpr int NQG = NWAVE / KH;                 // 32-query groups per workgroup
+    constexpr int NKB = 2 / KH;                     // 32-key blocks of a tile per wave
+    constexpr int QB = 32 * NQG;
     constexpr int NJ = 16 / NWAVE;                  // DMA instructions per wave per tile
     __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_B];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
+    const int qg = (KH == 1) ? wave : (wave % NQG), kh = (KH == 1) ? 0 : (wave / NQG);      // wave-uniform
     const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
     int kl = p.key_len ? p.key_len[b] : p.Sk;
     kl = min(kl, p.Sk);
@@ -80,7 +90,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
     if (p.causal) ntiles = min(ntiles, (min(q0 + QB, p.Sq) - 1) / KT + 1);
 
     // ---- Q fragments (B operand of S^T): lane holds Q[query l31][d = 16 ds + 8 hh .. +8]
-    const int qpos = q0 + wave * 32 + l31;
+    const int qpos = q0 + qg * 32 + l31;
     const int qrow = min(qpos, p.Sq - 1);
     uint4 qf[4];
 #pragma unroll
@@ -128,22 +138,22 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
     // ---- fragment read offsets (bytes inside a tile)
     // K: A row i = l31 -> tile row pi(l31) (bits 2,3 swapped) + 32 kb, chunk 2 ds + hh
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
-    int koffs[2][4];
+    int koffs[NKB][4];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
-            const int row = krow + 32 * kb;
+            const int row = krow + 32 * (kb + kh);               // (KH == 2: the wave's own key block kh)
             koffs[kb][ds] = row * 128 + (((2 * ds + hh) ^ ((row >> 1) & 7)) << 4);
         }
     // V^T: A row = d = l31 + 32 db, chunk 4 kb + 2 m + hh  (keys 32 kb + 16 m + 8 hh .. +7)
-    int voffs[2][4];
+    int voffs[2][2 * NKB];
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 2 * NKB; ++c) {
             const int row = l31 + 32 * db;
-            voffs[db][c] = TILE_B + row * 128 + (((2 * c + hh) ^ ((row >> 1) & 7)) << 4);
+            voffs[db][c] = TILE_B + row * 128 + (((2 * (c + 2 * kh) + hh) ^ ((row >> 1) & 7)) << 4);
         }
 
     f16_t oacc[2];
@@ -155,9 +165,9 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
     const float sc2 = p.scale * 1.4426950408889634f;          // scores in the exp2 domain
 
     // S^T = K . Q^T of one tile: s[kb][8 m + j] = score(key 64 kt + 32 kb + 16 m + 8 hh + j, query l31)
-    auto qk_tile = [&](const unsigned char* sb, f16_t (&s)[2]) {
+    auto qk_tile = [&](const unsigned char* sb, f16_t (&s)[NKB]) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
@@ -168,26 +178,26 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         }
     };
     // softmax of tile kt (scores in `s`, overwritten by the probabilities) and O^T += V^T . P^T
-    auto softmax_pv = [&](const unsigned char* sb, int kt, f16_t (&s)[2]) {
+    auto softmax_pv = [&](const unsigned char* sb, int kt, f16_t (&s)[NKB]) {
         const int kbase = kt * KT;
         // mask (only tiles that touch the key limit or the causal diagonal); online softmax in the
         // exp2 domain with the score scale folded into the exponent's fma:
         //   p = exp2(s * sc2 - m),  m = running max of s * sc2   (sc2 > 0, so max commutes)
         // VALU per lane and tile: 16 v_max3 + 16 v_pk_fma + 32 v_exp + 16 v_pk_add + 16 cvt_pk.
-        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);
+        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + qg * 32);
         if (need_mask) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int kidx = kbase + 32 * kb + 16 * (r >> 3) + 8 * hh + (r & 7);
+                    const int kidx = kbase + 32 * (kb + kh) + 16 * (r >> 3) + 8 * hh + (r & 7);
                     const bool vis = kidx < kl && (!p.causal || kidx <= qpos);
                     s[kb][r] = vis ? s[kb][r] : -INFINITY;
                 }
         }
         if (VARIANT == 3) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     st tmp[8];
@@ -203,9 +213,9 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
             l_run = 1.f;
             return;
         }
-        float mx = fmaxf(s[0][0], s[1][0]);
+        float mx = fmaxf(s[0][0], s[NKB - 1][0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);      // -> v_max3_f32
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[NKB - 1][r]);      // -> v_max3_f32
         mx = fmaxf(mx, lane_xor32(mx)) * sc2;
         const float m_new = fmaxf(m_run, mx);
         const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         const f2_t sc2v = {sc2, sc2}, mneg = {-m_use, -m_use};
         f2_t psum = {0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 const f2_t sv = {s[kb][r], s[kb][r + 1]};
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
                 for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 st tmp[8];
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
     // Per tile: wait tile kt+1 -> barrier -> DMA tile kt+2 into the slot tile kt-1 used.
     if (ntiles > 0) stage_load(0, 0);
     if (ntiles > 1) stage_load(1, 1);
-    f16_t sA[2], sB[2];
+    f16_t sA[NKB], sB[NKB];
     if (ntiles > 0) {
         if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NJ) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         qk_tile(lds, sA);
     }
     int slot = 0;                                                // LDS slot of tile kt
-    auto step = [&](int kt, f16_t (&cur)[2], f16_t (&nxt)[2]) {
+    auto step = [&](int kt, f16_t (&cur)[NKB], f16_t (&nxt)[NKB]) {
         const int s1 = (slot == 2) ? 0 : slot + 1;               // slot of tile kt+1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile kt+1 (the only DMA in flight) landed
         if (VARIANT != 2) __syncthreads();                       // ... for every wave; tile kt-1 fully consumed
@@ -278,6 +288,30 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
         if (kt + 1 < ntiles) step(kt + 1, sB, sA);
     }
 
+    // ---- KH == 2: the upper key half hands (m, l, O) to the lower one's same lane through LDS (the stage buffers are free)
+    if constexpr (KH == 2) {
+        float* mg = reinterpret_cast<float*>(lds) + qg * 34 * 64 + lane;         // [qg][34 values][64 lanes]: conflict-free
+        __syncthreads();                                                         // every wave has read its last tile
+        if (kh == 1) {
+            mg[0] = m_run;
+            mg[64] = l_run;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mg[(2 + 16 * db + r) * 64] = oacc[db][r];
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        const float m2 = mg[0], l2 = mg[64];
+        const float mn = fmaxf(m_run, m2);
+        const float mu = (mn == -INFINITY) ? 0.f : mn;
+        const float a1 = __builtin_amdgcn_exp2f(m_run - mu), a2 = __builtin_amdgcn_exp2f(m2 - mu);      // -inf -> 0
+        l_run = l_run * a1 + l2 * a2;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[db][r] = oacc[db][r] * a1 + mg[(2 + 16 * db + r) * 64] * a2;
+    }
     // ---- normalise and store: oacc[db][r] = O[query l31][d = 32 db + (r&3) + 8 (r>>2) + 4 hh]
     const float l_tot = l_run + lane_xor32(l_run);
     if (qpos < p.Sq) {
@@ -305,7 +339,15 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     static const int nw = [] { const char* e = m5_tool_env("M5_ATTN_NW"); return e ? atoi(e) : 4; }();
     static const int var = [] { const char* e = m5_tool_env("M5_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
 #define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a)
-    if (dtype == M5_F16) {
+#define M5_A16K(TT) hipLaunchKernelGGL((attn16_kernel<TT, 4, 0, 2>), dim3((a->Sq + 63) / 64, a->H, a->B), dim3(256), 0, s, *a)
+    // Key-half split (KH = 2, see the header): chosen from the problem's own lengths only -- never from the batch or head
+    // count -- so an utterance gets the same arithmetic alone and inside a batch.  M5_ATTN_KH=1|2 (tools) forces either form.
+    static const int khe = [] { const char* e = m5_tool_env("M5_ATTN_KH"); return e ? atoi(e) : 0; }();
+    const bool split = khe ? (khe == 2) : (!a->causal && a->Sk >= 512);
+    if (split && nw == 4 && var == 0) {
+        if (dtype == M5_F16) M5_A16K(F16T);
+        else M5_A16K(BF16T);
+    } else if (dtype == M5_F16) {
         M5_A16(F16T, 4, 0);
 #ifdef M5_TOOLS
     } else if (nw == 2) {
@@ -324,6 +366,7 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
         M5_A16(BF16T, 4, 0);
     }
 #undef M5_A16
+#undef M5_A16K
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

@@ -1201,6 +1201,7 @@ int pick_config(int M, int N, int K, int batch, int span_div, int epi) {
         const CfgInfo& f = kCfg[c];
         if (f.only_epi == -2 || (f.only_epi >= 0 && f.only_epi != epi)) continue;
         if (span_div && (span_div % (f.tn * 16))) continue;
+        if (epi == M5_EPI_QKV && f.tn != 4) continue;       // one head per wave: only those tilings have the LDS-staged 16-byte scatter
         const int64_t wg = (int64_t)((M + f.bm - 1) / f.bm) * ((N + f.bn - 1) / f.bn) * batch;
         const int64_t slots = 256 * f.occ;
         const int64_t rounds = (wg + slots - 1) / slots;

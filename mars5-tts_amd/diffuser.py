@@ -177,12 +177,14 @@ def perform_batch_inference(model, batches: List[tuple], diff: MultinomialDiffus
                             generators: Optional[List[Optional[torch.Generator]]] = None,
                             uniforms: Optional[List[Callable[[tuple], Tensor]]] = None,
                             randints: Optional[List[Callable]] = None,
-                            use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None) -> List[Tensor]:
+                            use_graph: bool = True, div_mode: int = 0, n_steps: Optional[int] = None, wait: bool = True,
+                            stream: Optional[torch.cuda.Stream] = None):
     """``perform_simple_inference`` for several independent utterances at once (BASELINE config 3):
     one batched decoder pass per reverse step over all of them (``NARBatchSession``).  Utterance i
     draws its random numbers from ``generators[i]`` in the order a lone call would (randint, then
     per step two rand), so result i equals ``perform_simple_inference(batches[i], generator=generators[i])``
-    whatever else is in the batch.  Returns a list of (1, S_i - offset_i, 8) int64 tensors."""
+    whatever else is in the batch.  Returns a list of (1, S_i - offset_i, 8) int64 tensors; with `wait=False` the steps
+    are only enqueued (on the session's own stream) and a callable that waits and returns that list comes back instead."""
     cfg = _nar_config(T, dsh, div_mode)
     eng = model.engine()
     dev = eng.dev
@@ -191,7 +193,7 @@ def perform_batch_inference(model, batches: List[tuple], diff: MultinomialDiffus
     U = len(batches)
     generators = generators if generators is not None else [None] * U
     times = get_schedule(T, jump_n_sample=dsh.jump_n_sample, jump_len=dsh.jump_len)[:-1]
-    sess = NARBatchSession(eng, cfg, diff_tables=_tables(diff))
+    sess = NARBatchSession(eng, cfg, stream=stream, diff_tables=_tables(diff))
     items, offsets, us = [], [], []
     sess.stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(sess.stream):
@@ -205,5 +207,7 @@ def perform_batch_inference(model, batches: List[tuple], diff: MultinomialDiffus
             else:
                 us.append(lambda shape, g=g: torch.rand(shape, dtype=torch.float32, device=dev, generator=g))
     sess.prepare(items, times)
-    outs = sess.run(us, use_graph=use_graph, n_steps=n_steps)
+    outs = sess.run(us, use_graph=use_graph, n_steps=n_steps, wait=wait)
+    if not wait:
+        return lambda: [o[None, off:].clone() for o, off in zip(sess.finish(), offsets)]
     return [o[None, off:].clone() for o, off in zip(outs, offsets)]

@@ -119,6 +119,32 @@ class NARConfig:
     div_mode: int = 0
 
 
+def _build_cross_operands(plan, step_ptr: torch.Tensor, main: torch.cuda.Stream, side: Optional[torch.cuda.Stream], st: int):
+    """Enqueue the launch that rebuilds the step's absorbed cross-attention operands (A, c, B^T of all 16 layers for this
+    step's memory block: HBM-bound, ~65 us, needed first by layer 0's CROSS-attention) and return the function that makes
+    `main` wait for it.  With a side stream (M5_NAR_SIDE=1, an A/B knob) the launch forks off `main` here and joins in front
+    of the first cross-attention block, so it runs beside the embedding and layer 0's self-attention block instead of in
+    front of them (under capture: a parallel branch of the step graph).  Measured on one box: 3.19 ms per step against 3.14
+    with the build in line -- the fork / join of a two-branch graph costs more than the 65 us it hides -- so it is off."""
+    segs = [seg[1] for seg in plan if seg[0] == "absorbed"]
+    if not segs:
+        return lambda: None
+    if side is None:
+        for sg in segs:
+            sg.build(step_ptr, st)
+        return lambda: None
+    side.wait_stream(main)
+    for sg in segs:
+        sg.build(step_ptr, side.cuda_stream)
+    state = {"joined": False}
+
+    def join() -> None:
+        if not state["joined"]:
+            main.wait_stream(side)
+            state["joined"] = True
+    return join
+
+
 class NARSession:
     """One utterance.  ``prepare`` = everything x_t-independent; ``step`` = one reverse step."""
 
@@ -254,7 +280,8 @@ class NARSession:
             # the two guidance branches enter the decoder with the SAME rows (x_t embedding + timestep vector) and first
             # differ in layer 0's cross-attention, so layer 0's self-attention block runs once (one-sequence workspace)
             share0 = os.environ.get("M5_NAR_SHARE0", "1") != "0"          # A/B knob (tools/nar_step_bench.py)
-            self.ws0 = SeqWorkspace(1, S, D, FF, dt, dev, row_pad=64) if (nb == 2 and share0) else None
+            over = self.ws if os.environ.get("M5_NAR_ALIAS", "1") != "0" else None     # A/B knob: private buffers for the two sub-problems
+            self.ws0 = SeqWorkspace(1, S, D, FF, dt, dev, row_pad=64, inside=over) if (nb == 2 and share0) else None
             self.h = torch.zeros(nb, Sr, D, dtype=torch.float32, device=dev)
             self.hf = torch.zeros(nb * Sr, D, dtype=torch.float32, device=dev)
             self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
@@ -271,9 +298,11 @@ class NARSession:
             self.ws_l = None
             so_r = round_up(self.s_out, 64)
             if self.row_offset > 0 and 4 * so_r <= 3 * Sr and os.environ.get("M5_NAR_LASTROWS", "1") != "0":
-                self.ws_l = SeqWorkspace(nb, self.s_out, D, FF, dt, dev, row_pad=64)
+                self.ws_l = SeqWorkspace(nb, self.s_out, D, FF, dt, dev, row_pad=64, inside=over)
                 self.x_l = torch.zeros(nb, so_r, D, dtype=torch.float32, device=dev)
                 self.hf_l = torch.zeros(nb * so_r, D, dtype=torch.float32, device=dev)
+        # A/B knob, off: as a parallel graph branch the build makes the step 45 us SLOWER (profiles/r3w_*): see _build_cross_operands
+        self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
         self.graph = None
 
     # ----------------------------------------------------------------------------- step
@@ -311,9 +340,7 @@ class NARSession:
         hx = self.h.view(nb * Sr, D)
         layers = list(zip(mdl.dec, self.mems))
         self.ws.ln_tag, self.ws.ln_tag_step = 0, self.step_ptr      # fused LN launches: tag = f(step counter, call index)
-        for seg in self.plan:
-            if seg[0] == "absorbed":
-                seg[1].build(self.step_ptr, st)                     # A, c, B^T of all 16 layers for this step's memory block
+        join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
         if self.ws0 is not None:
             ops.chunked_embed(self.h[:1], mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
                               rows=S, stream=st)
@@ -322,6 +349,7 @@ class NARSession:
             ops.mark("torch copy: branch 0 -> branch 1", st)
             with torch.cuda.stream(self.stream):
                 self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
+            join()
             nxt = (mdl.dec[1].n1_w, mdl.dec[1].n1_b) if len(mdl.dec) > 1 else None
             normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b), xa=self.xa[0], plan=self.plan, layer=0)
             normed = ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st, normed=normed, next_ln=nxt)
@@ -335,10 +363,13 @@ class NARSession:
         for k, (lw, mem) in enumerate(layers):
             l = l0 + k                                         # every LayerNorm but the first rides on the residual GEMM before it
             if compact and l == len(mdl.dec) - 1:
+                join()                                         # (a one-layer decoder: no earlier join)
                 self._last_layer_compact(lw, mem, normed, st)
                 break
             nxt = (mdl.dec[l + 1].n1_w, mdl.dec[l + 1].n1_b) if l + 1 < len(mdl.dec) else None
-            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l], plan=self.plan, layer=l)
+            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l], plan=self.plan, layer=l,
+                                   before_cross=join if l == 0 else None)
+        join()
         so = self.s_out
         if compact:
             hf, hrow = self.hf_l, [b * self.ws_l.Sr for b in range(nb)]
@@ -484,6 +515,7 @@ class NARBatchSession:
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
             self.plan = make_cross_plan(mdl.dec, [[sub.mems[l] for sub in self.subs] for l in range(len(mdl.dec))], D, dt, dev)
+        self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
         self.graph = None
 
     def enqueue_forward(self, st: int) -> None:
@@ -494,11 +526,11 @@ class NARBatchSession:
             ops.chunked_embed(self.h[u * nb:(u + 1) * nb], mdl.res_tables, sub.x, None, mdl.pos_alpha, mdl.pe, add=t_dec,
                               add_index=self.step_ptr, rows=sub.S, stream=st)
         hx = self.h.view(-1, D)
-        for seg in self.plan:
-            if seg[0] == "absorbed":
-                seg[1].build(self.step_ptr, st)
+        join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
         for l, lw in enumerate(mdl.dec):
-            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l)
+            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l,
+                          before_cross=join if l == 0 else None)
+        join()
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         for u, sub in enumerate(self.subs):
             so = sub.s_out
@@ -541,7 +573,10 @@ class NARBatchSession:
             ops.add_int(self.step_ptr, 1, stream=st)
         self.step_i += 1
 
-    def run(self, uniforms: List[Callable[[tuple], torch.Tensor]], use_graph: bool = True, n_steps: Optional[int] = None) -> List[torch.Tensor]:
+    def run(self, uniforms: List[Callable[[tuple], torch.Tensor]], use_graph: bool = True, n_steps: Optional[int] = None,
+            wait: bool = True) -> Optional[List[torch.Tensor]]:
+        """`wait=False`: enqueue every step and return without synchronising (the caller keeps a second group in flight on
+        another stream: inference.tts_batch_from_codes); ``finish()`` then returns the results."""
         n = len(self.times) if n_steps is None else n_steps
         st = self.stream.cuda_stream
         ev0, ev1 = ops.Event(), ops.Event()
@@ -549,6 +584,12 @@ class NARBatchSession:
         for _ in range(n):
             self.step(uniforms, use_graph)
         ev1.record(st)
+        self._pending = (ev0, ev1, n)
+        return self.finish() if wait else None
+
+    def finish(self) -> List[torch.Tensor]:
+        """Wait for the steps ``run`` enqueued; x (S_u, 8) per utterance, in the caller's order."""
+        ev0, ev1, n = self._pending
         self.stream.synchronize()
         LAST_STATS.update(loop_ms=ev0.elapsed_ms(ev1), steps=n, S=[sub.S for sub in self.subs], s_out=[sub.s_out for sub in self.subs],
                           Le=[sub.mems[0].Le for sub in self.subs], nb=self.nb, batch=len(self.subs), rows=self.ws.M)

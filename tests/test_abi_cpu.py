@@ -207,7 +207,8 @@ def test_hub_entry_points_assemble_the_reference_checkpoint_dicts(tiny_bundle, t
 def test_batch_entry_point_groups_by_length_and_restores_order(monkeypatch):
     """Host logic of ``tts_batch_from_codes`` (BASELINE config 3) without a GPU: requests are refined in groups of at
     most `nar_batch`, grouped by similar total NAR length, every request keeps ITS generator (seeded with its seed),
-    and results come back in request order."""
+    at most `nar_in_flight` groups are open at once (each enqueued without waiting, landed oldest first), and results come
+    back in request order."""
     import torch
     import inference
     from inference import InferenceConfig, Mars5TTS
@@ -217,6 +218,7 @@ def test_batch_entry_point_groups_by_length_and_restores_order(monkeypatch):
     m.codecnar = object()
     lens = [30, 5, 17, 9, 26, 12, 3]
     calls, seeds_seen = [], {}
+    open_groups, peak = [], [0]
 
     def fake_ar_stage(text, prompt_codec, ref_transcript, cfg, ar_noise, generator):
         i = int(text)
@@ -224,11 +226,19 @@ def test_batch_entry_point_groups_by_length_and_restores_order(monkeypatch):
         x = torch.full((1, lens[i], 8), i, dtype=torch.long)
         return torch.arange(lens[i]), (None, None, None, None, x, None), 2      # frames, batch tuple (x at [4]), skip_front
 
-    def fake_batch(model, batches, diff, T, dsh=None, generators=None, **kw):
+    def fake_batch(model, batches, diff, T, dsh=None, generators=None, wait=True, stream=None, **kw):
         ids = [int(b[4][0, 0, 0]) for b in batches]
         calls.append(ids)
         assert [g.initial_seed() for g in generators] == [1000 + i for i in ids]
-        return [torch.full((1, lens[i] + 2, 8), i, dtype=torch.long) for i in ids]
+        assert wait is False                                   # groups are enqueued, not waited for
+        open_groups.append(ids)
+        peak[0] = max(peak[0], len(open_groups))
+
+        def land():
+            assert open_groups[0] == ids                       # oldest first
+            open_groups.pop(0)
+            return [torch.full((1, lens[i] + 2, 8), i, dtype=torch.long) for i in ids]
+        return land
 
     monkeypatch.setattr(Mars5TTS, "_ar_stage", lambda self, *a: fake_ar_stage(*a))
     monkeypatch.setattr(inference, "perform_batch_inference", fake_batch)
@@ -236,6 +246,7 @@ def test_batch_entry_point_groups_by_length_and_restores_order(monkeypatch):
     out = m.tts_batch_from_codes([str(i) for i in range(n)], [None] * n, [""] * n, InferenceConfig(), seeds=[1000 + i for i in range(n)], nar_batch=3)
     assert seeds_seen == {i: 1000 + i for i in range(n)}
     assert [len(c) for c in calls] == [3, 3, 1]
+    assert peak[0] == 2 and not open_groups                    # nar_in_flight defaults to 2; everything landed
     flat = [i for c in calls for i in c]
     assert sorted(flat) == list(range(n)) and [lens[i] for i in flat] == sorted(lens)      # similar lengths share a pass
     for i, (frames, final) in enumerate(out):
