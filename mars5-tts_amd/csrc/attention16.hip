@@ -21,7 +21,8 @@
 // one 32x32 score block and one k-half of the PV product each); a workgroup is then 2 query groups x 2 key halves = 64
 // queries, and the halves' (m, l, O) merge once through LDS after the key loop.  Same LDS reads and MFMAs per query, twice
 // the waves: at one utterance (352 query blocks of 128 on 256 CUs = 1.4 waves per SIMD) a wave's MFMA, softmax-VALU and
-// ds_read phases have no other wave to overlap with; with 704 workgroups of 64 queries there are 2.75.
+// ds_read phases have no other wave to overlap with; with 704 workgroups of 64 queries there are 2.75.  Measured: no gain
+// there (-2 %), a loss at high occupancy (twice the operand DMA per query) -- a tools-only variant (M5_ATTN_KH=2).
 #include "common.h"
 #include <stdlib.h>
 
@@ -340,14 +341,17 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     static const int var = [] { const char* e = m5_tool_env("M5_ATTN_VARIANT"); return e ? atoi(e) : 0; }();
 #define M5_A16(TT, NWV, VV) hipLaunchKernelGGL((attn16_kernel<TT, NWV, VV>), dim3((a->Sq + 32 * NWV - 1) / (32 * NWV), a->H, a->B), dim3(NWV * 64), 0, s, *a)
 #define M5_A16K(TT) hipLaunchKernelGGL((attn16_kernel<TT, 4, 0, 2>), dim3((a->Sq + 63) / 64, a->H, a->B), dim3(256), 0, s, *a)
-    // Key-half split (KH = 2, see the header): chosen from the problem's own lengths only -- never from the batch or head
-    // count -- so an utterance gets the same arithmetic alone and inside a batch.  M5_ATTN_KH=1|2 (tools) forces either form.
+    // Key-half split (KH = 2, see the header): tools only (M5_ATTN_KH=2).  Measured (profiles/r3x_attn_key_half_split_ab.txt):
+    // -2 % at the NAR shape of one utterance, -25 % on the small one-off problems (AR prefill, speaker encoder: 3 us each),
+    // +16 % at a batched group's 16 x 2240 rows and +10 % at the 5399-row long form -- so the product keeps one form.
+#ifdef M5_TOOLS
     static const int khe = [] { const char* e = m5_tool_env("M5_ATTN_KH"); return e ? atoi(e) : 0; }();
-    const bool split = khe ? (khe == 2) : (!a->causal && a->Sk >= 512);
-    if (split && nw == 4 && var == 0) {
+    if (khe == 2 && nw == 4 && var == 0) {
         if (dtype == M5_F16) M5_A16K(F16T);
         else M5_A16K(BF16T);
-    } else if (dtype == M5_F16) {
+    } else
+#endif
+    if (dtype == M5_F16) {
         M5_A16(F16T, 4, 0);
 #ifdef M5_TOOLS
     } else if (nw == 2) {

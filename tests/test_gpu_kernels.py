@@ -263,7 +263,10 @@ def _ref_attention(q, k, v, key_len, causal):
 
 @pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,H,Sq,Sk,kls,causal", [(2, 3, 150, 150, [150, 77], False), (1, 2, 130, 130, [130], True),
-                                                   (2, 2, 100, 41, [41, 41], False), (1, 1, 70, 300, [300], False)])
+                                                   (2, 2, 100, 41, [41, 41], False), (1, 1, 70, 300, [300], False),
+                                                   # long key ranges (22 / 10 key tiles), ragged query blocks, a key limit inside the first tile
+                                                   (2, 2, 700, 700, [700, 530], False), (1, 3, 95, 1349, [1349], False),
+                                                   (2, 1, 130, 600, [20, 577], False)])
 def test_attention(dev, dt, B, H, Sq, Sk, kls, causal):
     from mars5_tts_amd import _lib as L, ops
     q, k, v = _q(_rand((B, H, Sq, 64), 1, 2.0), dt), _q(_rand((B, H, Sk, 64), 2, 2.0), dt), _q(_rand((B, H, Sk, 64), 3), dt)

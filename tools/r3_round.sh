@@ -43,6 +43,11 @@ for s in "$@"; do
     l0qkv) SWEEP=${SWEEP:-0,1,2,3,4,7} ONLY="nar l0 qkv" timeout 300 python tools/gemm_bench.py > $OUT/l0qkv.log 2>&1; echo "l0qkv rc=$?"; grep "nar " $OUT/l0qkv.log ;;
     concb) CONC=1 MIXED=${MIXED:-1} timeout 900 python tools/nar_batch_bench.py ${CONCB:-4 8} > $OUT/concb.log 2>&1; echo "concb rc=$?"; grep "U=" $OUT/concb.log ;;
     pmcres) NOATTN=1 ONLY="nar out_proj,nar linear2" bash tools/pmc_traffic.sh $TAG/pmc > $OUT/pmcres.log 2>&1; echo "pmcres rc=$?"; cat $OUT/pmc/summary.txt | head -60 ;;
+    attnab) for kh in 1 2; do echo "== M5_ATTN_KH=$kh"; M5_ATTN_KH=$kh timeout 300 python tools/attn_bench.py 2>&1 | grep -E "nar|spk|small|causal"
+              M5_ATTN_KH=$kh CASES="16,16,2240,2240;2,16,5399,5399;1,16,1349,1349;4,16,1349,1349" timeout 300 python tools/attn_bench.py 2>&1 | grep case; done > $OUT/attn_kh_ab.log 2>&1
+            echo "attnab rc=$?"; cat $OUT/attn_kh_ab.log
+            timeout 600 python tools/nar_step_bench.py "M5_ATTN_KH=1" "M5_ATTN_KH=2" > $OUT/nar_kh_ab.log 2>&1; grep round $OUT/nar_kh_ab.log
+            timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "attention" > $OUT/attntest.log 2>&1; echo "attntest rc=$?"; tail -3 $OUT/attntest.log ;;
     smoke) timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
