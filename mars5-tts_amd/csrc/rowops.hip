@@ -56,15 +56,17 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
-    // the affine parameters of the (common) single-affine call are requested now, behind the row itself, so their L2
-    // round trip overlaps the two reductions instead of following them
+    // the affine parameters are requested now, behind the row itself, so their L2 round trip overlaps the two reductions
+    // instead of following them.  Several affines of one normalisation (the 7 codebook heads): one per blockIdx.y -- every
+    // workgroup is a single pass (re-reading the row from L2 is cheaper than 7 dependent parameter round trips per wave:
+    // 18 us per launch for the 450 x 7 head rows of a NAR step before; same arithmetic per (row, affine)).
     float4 g0[NV], b0[NV];
-    const bool one = n_affine == 1;
-    if (one) {
+    const int a_first = blockIdx.y;
+    {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            g0[i] = *reinterpret_cast<const float4*>(gamma + (lane + 64 * i) * 4);
-            b0[i] = *reinterpret_cast<const float4*>(beta + (lane + 64 * i) * 4);
+            g0[i] = *reinterpret_cast<const float4*>(gamma + a_first * affine_stride + (lane + 64 * i) * 4);
+            b0[i] = *reinterpret_cast<const float4*>(beta + a_first * affine_stride + (lane + 64 * i) * 4);
         }
     }
 #pragma unroll
@@ -77,14 +79,13 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
         q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-    for (int a = 0; a < n_affine; ++a) {
-        const float* g = gamma + a * affine_stride;
-        const float* bt = beta + a * affine_stride;
-        st* yr = y + a * y_affine_stride + (int64_t)row * ldy;
+    (void)n_affine;
+    {
+        st* yr = y + a_first * y_affine_stride + (int64_t)row * ldy;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
-            const float4 gg = one ? g0[i] : *reinterpret_cast<const float4*>(g + c), bb = one ? b0[i] : *reinterpret_cast<const float4*>(bt + c);
+            const float4 gg = g0[i], bb = b0[i];
             const float o[4] = {v[i].x * rstd * gg.x + bb.x, v[i].y * rstd * gg.y + bb.y,
                                 v[i].z * rstd * gg.z + bb.z, v[i].w * rstd * gg.w + bb.w};
             if constexpr (sizeof(st) == 4) {
@@ -107,7 +108,7 @@ bool launch_ln_vec(const float* x, int64_t ldx, const float* gamma, const float*
     if (D % 256 || (ldx % 4) || (ldy * es % (es == 4 ? 16 : 8)) || (affine_stride % 4) || (y_affine_stride * es % (es == 4 ? 16 : 8)) ||
         (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
         return false;
-    dim3 grid((M + 3) / 4);
+    dim3 grid((M + 3) / 4, n_affine);
 #define M5_LNV(NV) hipLaunchKernelGGL((layernorm_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (st*)y, ldy, M, n_affine, affine_stride, y_affine_stride)
     switch (D / 256) {
         case 1: M5_LNV(1); break;
