@@ -157,7 +157,7 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
     with torch.cuda.stream(sess.stream):
         xr, x_known, m, offset = _inpaint_state(batch, K, dsh, dev, randint, generator)
         if uniform is None:
-            uniform = lambda shape: torch.rand(shape, dtype=torch.float32, device=dev, generator=generator)   # noqa: E731
+            uniform = _generator_uniform(dev, generator)
     if session is None:
         sess.prepare(c_text[0], c_codes[0].to(dev), xr, x_known, m, offset, times)
     else:
@@ -170,6 +170,19 @@ def perform_simple_inference(model, batch: tuple, diff: MultinomialDiffusion, T,
     if not wait:
         return lambda: sess.finish()[None, offset:].clone()
     return out[None, offset:].clone()
+
+
+def _generator_uniform(dev, generator: Optional[torch.Generator]):
+    """The step's uniform draw as the reference makes it (``torch.rand(shape, device=...)`` on the current / given generator).
+    ``out=``: fill a preallocated buffer instead -- torch.rand IS empty(shape).uniform_(0, 1, generator), so the values and the
+    generator's advance are the same; ``out_ok`` tells the engine it may draw on its second stream (nar_engine._UniformRing)."""
+    def uniform(shape, out: Optional[Tensor] = None) -> Tensor:
+        if out is None:
+            return torch.rand(shape, dtype=torch.float32, device=dev, generator=generator)
+        assert tuple(out.shape) == tuple(shape) and out.dtype == torch.float32
+        return out.uniform_(0.0, 1.0, generator=generator)
+    uniform.out_ok = True
+    return uniform
 
 
 @torch.inference_mode()
@@ -205,7 +218,7 @@ def perform_batch_inference(model, batches: List[tuple], diff: MultinomialDiffus
             if uniforms is not None:
                 us.append(uniforms[i])
             else:
-                us.append(lambda shape, g=g: torch.rand(shape, dtype=torch.float32, device=dev, generator=g))
+                us.append(_generator_uniform(dev, g))
     sess.prepare(items, times)
     outs = sess.run(us, use_graph=use_graph, n_steps=n_steps, wait=wait)
     if not wait:

@@ -145,6 +145,50 @@ def _build_cross_operands(plan, step_ptr: torch.Tensor, main: torch.cuda.Stream,
     return join
 
 
+class _UniformRing:
+    """The step's torch.rand draws (2 x 17 us at the bench shape, independent of the forward) on a second stream, into a ring
+    of two preallocated buffer pairs, so that they execute beside the forward instead of between the forward and the sample
+    kernel.  Only for draw callables that can fill a given buffer (``draw.out_ok``: diffuser's generator-backed ones -- the
+    same calls on the same generator, so the same values); anything else is drawn on the main stream as before.  No allocator
+    traffic crosses streams: pair k is rewritten only after the event recorded behind the sample kernel that read it."""
+
+    def __init__(self, main: torch.cuda.Stream, shapes: List[tuple], dev):
+        self.main = main
+        self.side = torch.cuda.Stream(device=dev)
+        self.buf = [[(torch.empty(sh, dtype=torch.float32, device=dev), torch.empty(sh, dtype=torch.float32, device=dev)) for sh in shapes]
+                    for _ in range(2)]
+        self.read_done: List[Optional[torch.cuda.Event]] = [None, None]
+        self.i = 0
+
+    def draw(self, draws: List[Callable], need_u2: bool) -> List[tuple]:
+        """Enqueue this step's draws on the second stream; returns [(u1, u2 or None)] per draw callable.  Call ``ready()``
+        on the main stream's side before the consumer and ``consumed()`` after it."""
+        k = self.i & 1
+        if self.read_done[k] is not None:
+            self.side.wait_event(self.read_done[k])
+        out = []
+        with torch.cuda.stream(self.side):
+            for d, (b1, b2) in zip(draws, self.buf[k]):
+                u1 = d(tuple(b1.shape), out=b1)
+                out.append((u1, d(tuple(b2.shape), out=b2) if need_u2 else None))
+            self._ev = torch.cuda.Event()
+            self._ev.record(self.side)
+        return out
+
+    def ready(self) -> None:
+        self.main.wait_event(self._ev)
+
+    def consumed(self) -> None:
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.read_done[self.i & 1] = ev
+        self.i += 1
+
+
+def _ring_ok(draws) -> bool:
+    return os.environ.get("M5_NAR_RNG_SIDE", "1") != "0" and all(getattr(d, "out_ok", False) for d in draws)
+
+
 class NARSession:
     """One utterance.  ``prepare`` = everything x_t-independent; ``step`` = one reverse step."""
 
@@ -303,6 +347,7 @@ class NARSession:
                 self.hf_l = torch.zeros(nb * so_r, D, dtype=torch.float32, device=dev)
         # A/B knob, off: as a parallel graph branch the build makes the step 45 us SLOWER (profiles/r3w_*): see _build_cross_operands
         self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
+        self._ring = None                      # _UniformRing, made at the first step that can use it
         self.graph = None
 
     # ----------------------------------------------------------------------------- step
@@ -397,9 +442,17 @@ class NARSession:
         ops.add_int(self.step_ptr, 1, stream=st)
 
     def step(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True) -> None:
-        """One reverse step t = times[step_i]: forward (graph), draw uniforms, sample."""
+        """One reverse step t = times[step_i]: draw uniforms (beside the forward when the callable allows: _UniformRing),
+        forward (graph), sample."""
         st = self.stream.cuda_stream
         t = self.times[self.step_i]
+        shape = (1, self.S, self.m.shape.n_codebooks, self.m.shape.n_quant)
+        ring = None
+        if _ring_ok([uniform]):
+            if self._ring is None:
+                self._ring = _UniformRing(self.stream, [shape], self.m.dev)
+            ring = self._ring
+            (u1, u2), = ring.draw([uniform], t > 0)
         if use_graph:
             if self.graph is None:
                 self.stream.synchronize()
@@ -409,11 +462,15 @@ class NARSession:
             self.graph.launch(st)
         else:
             self.enqueue_forward(st)
-        shape = (1, self.S, self.m.shape.n_codebooks, self.m.shape.n_quant)
         with torch.cuda.stream(self.stream):
-            u1 = uniform(shape)
-            u2 = uniform(shape) if t > 0 else None
+            if ring is None:
+                u1 = uniform(shape)
+                u2 = uniform(shape) if t > 0 else None
+            else:
+                ring.ready()
             self.enqueue_sample(u1[0], u2[0] if u2 is not None else None, st)
+            if ring is not None:
+                ring.consumed()
         self.step_i += 1
 
     def run(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True, n_steps: Optional[int] = None,
@@ -516,6 +573,7 @@ class NARBatchSession:
             self.step_i = 0
             self.plan = make_cross_plan(mdl.dec, [[sub.mems[l] for sub in self.subs] for l in range(len(mdl.dec))], D, dt, dev)
         self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
+        self._ring = None
         self.graph = None
 
     def enqueue_forward(self, st: int) -> None:
@@ -545,6 +603,15 @@ class NARBatchSession:
         st = self.stream.cuda_stream
         s, cfg = self.m.shape, self.cfg
         t = self.times[self.step_i]
+        Q = s.n_codebooks
+        shapes = [(1, sub.S, Q, s.n_quant) for sub in self.subs]
+        draws = [uniforms[self._order[u]] for u in range(len(self.subs))]         # uniforms are in the caller's order
+        ring, drawn = None, None
+        if _ring_ok(draws):
+            if self._ring is None:
+                self._ring = _UniformRing(self.stream, shapes, self.m.dev)
+            ring = self._ring
+            drawn = ring.draw(draws, t > 0)
         if use_graph:
             if self.graph is None:
                 self.stream.synchronize()
@@ -554,13 +621,16 @@ class NARBatchSession:
             self.graph.launch(st)
         else:
             self.enqueue_forward(st)
-        Q = s.n_codebooks
         with torch.cuda.stream(self.stream):
+            if ring is not None:
+                ring.ready()
             for u, sub in enumerate(self.subs):
-                shape = (1, sub.S, Q, s.n_quant)
-                draw = uniforms[self._order[u]]                # uniforms are in the caller's order
-                u1 = draw(shape)
-                u2 = draw(shape) if t > 0 else u1
+                if ring is None:
+                    u1 = draws[u](shapes[u])
+                    u2 = draws[u](shapes[u]) if t > 0 else None
+                else:
+                    u1, u2 = drawn[u]
+                u2 = u2 if u2 is not None else u1
                 lc = self.logits[self.row0[u]:]
                 lu = self.logits[self.row0[u] + sub.s_out:] if self.nb == 2 else None
                 a = L.NarSampleArgs(logits_c=lc.data_ptr(), logits_u=lu.data_ptr() if lu is not None else None,
@@ -571,6 +641,8 @@ class NARBatchSession:
                                     log_eps=log_eps(), div_mode=cfg.div_mode, q0_override_steps=cfg.q0_override_steps)
                 ops.nar_sample(a, stream=st)
             ops.add_int(self.step_ptr, 1, stream=st)
+            if ring is not None:
+                ring.consumed()
         self.step_i += 1
 
     def run(self, uniforms: List[Callable[[tuple], torch.Tensor]], use_graph: bool = True, n_steps: Optional[int] = None,
