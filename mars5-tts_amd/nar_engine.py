@@ -146,7 +146,8 @@ def _build_cross_operands(plan, step_ptr: torch.Tensor, main: torch.cuda.Stream,
 
 
 class _UniformRing:
-    """The step's torch.rand draws (2 x 17 us at the bench shape, independent of the forward) on a second stream, into a ring
+    """(Opt-in, M5_NAR_RNG_SIDE=1: measured slower, see _ring_ok.)
+    The step's torch.rand draws (2 x 17 us at the bench shape, independent of the forward) on a second stream, into a ring
     of two preallocated buffer pairs, so that they execute beside the forward instead of between the forward and the sample
     kernel.  Only for draw callables that can fill a given buffer (``draw.out_ok``: diffuser's generator-backed ones -- the
     same calls on the same generator, so the same values); anything else is drawn on the main stream as before.  No allocator
@@ -186,7 +187,10 @@ class _UniformRing:
 
 
 def _ring_ok(draws) -> bool:
-    return os.environ.get("M5_NAR_RNG_SIDE", "1") != "0" and all(getattr(d, "out_ok", False) for d in draws)
+    # A/B knob, OFF: measured 3.15 vs 3.08 ms per step with the draws on the second stream (profiles/r3z2_*) -- the two
+    # cross-stream event waits per step cost more than the 34 us of draws they take off the chain (same finding as the
+    # operand build on a side stream: on this stack every cross-stream dependency inside a step is a loss).
+    return os.environ.get("M5_NAR_RNG_SIDE", "0") == "1" and all(getattr(d, "out_ok", False) for d in draws)
 
 
 class NARSession:

@@ -70,3 +70,21 @@ def test_request_wire_format_roundtrip():
         assert (a.idx, a.seed, a.n_gen_est, a.n_phones_gen, a.max_len) == (b.idx, b.seed, b.n_gen_est, b.n_phones_gen, b.max_len)
         assert torch.equal(a.text_ids, b.text_ids) and torch.equal(a.ref_codes, b.ref_codes)
     assert sh._unpack(sh._pack([])) == []
+
+
+def test_generator_uniform_fills_a_buffer_with_the_same_draws():
+    """diffuser._generator_uniform(out=buf) -- what the engine's second-stream ring calls -- must produce the values of the
+    reference's ``torch.rand(shape)`` on the same generator AND leave the generator where that call leaves it (the next
+    draw is the same too), for a shape of the step's kind (not a multiple of the Philox unroll)."""
+    from mars5_tts_amd.diffuser import _generator_uniform
+    dev = torch.device("cpu")
+    shape = (1, 37, 8, 1025)
+    ga, gb = torch.Generator().manual_seed(123), torch.Generator().manual_seed(123)
+    ua, ub = _generator_uniform(dev, ga), _generator_uniform(dev, gb)
+    assert getattr(ua, "out_ok", False)
+    buf = torch.empty(shape)
+    for _ in range(3):
+        a = ua(shape)
+        b = ub(shape, out=buf)
+        assert b.data_ptr() == buf.data_ptr() and torch.equal(a, b)
+    assert torch.equal(torch.rand(5, generator=ga), torch.rand(5, generator=gb))
