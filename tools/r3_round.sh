@@ -48,6 +48,8 @@ for s in "$@"; do
             echo "attnab rc=$?"; cat $OUT/attn_kh_ab.log
             timeout 600 python tools/nar_step_bench.py "M5_ATTN_KH=1" "M5_ATTN_KH=2" > $OUT/nar_kh_ab.log 2>&1; grep round $OUT/nar_kh_ab.log
             timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "attention" > $OUT/attntest.log 2>&1; echo "attntest rc=$?"; tail -3 $OUT/attntest.log ;;
+    pmcgemm) SWEEP=-1 ONLY="${PMC_ONLY:-nar out_proj,nar linear2,nar swiglu}" bash tools/pmc_gemm.sh $TAG/pmcg > $OUT/pmcgemm.log 2>&1; echo "pmcgemm rc=$?"
+             python tools/pmc_summary.py $OUT/pmcg > $OUT/pmcg_summary.txt; find $OUT/pmcg -name "*.csv" -size +3M -delete; head -120 $OUT/pmcg_summary.txt ;;
     smoke) timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
