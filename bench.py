@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ar-batch", type=int, default=32)
     ap.add_argument("--nar-batch", type=int, default=8)
+    ap.add_argument("--nar-in-flight", type=int, default=2, help="c3: NAR groups refined at once, each on its own stream")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + rank census only, then exit (no model, no GPU work): with --backend gloo this is how the "
                          "CPU tests check that `--gpus N` really starts N ranks")
@@ -179,7 +180,7 @@ def main_c3(args, m, dev, world, rank, barrier):
     def step(i):
         t0 = time.perf_counter()
         out = m.tts_batch_from_codes(texts, refs, trs, cfg, seeds=[1000 + rank * 10007 + i * args.batch + j for j in range(args.batch)],
-                                     nar_batch=args.nar_batch, ar_batch=args.ar_batch, max_lens=max_lens)
+                                     nar_batch=args.nar_batch, ar_batch=args.ar_batch, max_lens=max_lens, nar_in_flight=args.nar_in_flight)
         torch.cuda.synchronize()
         if span["t0"] is not None:
             split["nar_total_s"] += span["t1"] - span["t0"]
@@ -216,7 +217,7 @@ def main_c3(args, m, dev, world, rank, barrier):
         "config": {"workload": f"BASELINE configs[2]: batch of {args.batch} mixed-length requests per GPU, deep-clone, temperature=0.7 "
                                f"top_k=100, reference 150-900 frames (2-12 s), text+transcript 10-60 tokens, {args.n_gen} generated frames "
                                "each, 200 DDPM steps x CFG, seeded random weights of the real geometry",
-                   "requests_per_step": args.batch, "ar_batch": args.ar_batch, "nar_batch": args.nar_batch,
+                   "requests_per_step": args.batch, "ar_batch": args.ar_batch, "nar_batch": args.nar_batch, "nar_groups_in_flight": args.nar_in_flight,
                    "reference_frames_min_mean_max": [min(ref_frames), round(sum(ref_frames) / len(ref_frames), 1), max(ref_frames)],
                    "parallelism": f"replicas x{world} (requests sharded by rank, no data-path collective)"},
         "time_split_s_per_step": {k: round(v / args.steps, 3) for k, v in split.items()},

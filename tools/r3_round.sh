@@ -50,6 +50,8 @@ for s in "$@"; do
             timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "attention" > $OUT/attntest.log 2>&1; echo "attntest rc=$?"; tail -3 $OUT/attntest.log ;;
     pmcgemm) SWEEP=-1 ONLY="${PMC_ONLY:-nar out_proj,nar linear2,nar swiglu}" bash tools/pmc_gemm.sh $TAG/pmcg > $OUT/pmcgemm.log 2>&1; echo "pmcgemm rc=$?"
              python tools/pmc_summary.py $OUT/pmcg > $OUT/pmcg_summary.txt; find $OUT/pmcg -name "*.csv" -size +3M -delete; head -120 $OUT/pmcg_summary.txt ;;
+    c3fly) for f in ${C3FLY:-1 2 3}; do timeout 600 python bench.py --workload c3 --batch 32 --steps 1 --warmup 1 --nar-in-flight $f > $OUT/c3_fly$f.json 2> $OUT/c3_fly$f.err; echo "c3 in-flight $f rc=$?"
+             python -c "import json,sys; d=json.load(open('$OUT/c3_fly$f.json')); print(d['value'], d['time_split_s_per_step'])"; done ;;
     smoke) timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 $OUT/smoke.log ;;
     *) echo "unknown step $s" ;;
   esac
