@@ -88,3 +88,27 @@ def test_generator_uniform_fills_a_buffer_with_the_same_draws():
         b = ub(shape, out=buf)
         assert b.data_ptr() == buf.data_ptr() and torch.equal(a, b)
     assert torch.equal(torch.rand(5, generator=ga), torch.rand(5, generator=gb))
+
+
+def test_workspace_laid_over_a_larger_one_shares_its_front():
+    """SeqWorkspace(inside=ws): the sub-problem workspaces of a NAR step (one-branch layer 0, generated-rows last layer) are
+    views of the FRONT of the main workspace's buffers -- same strides per sequence as a private workspace would have, no
+    memory of their own -- and a too-large request is refused."""
+    import pytest
+    from mars5_tts_amd.blocks import SeqWorkspace
+    dev, dt = torch.device("cpu"), torch.bfloat16
+    ws = SeqWorkspace(2, 150, 128, 384, dt, dev, row_pad=64)
+    one = SeqWorkspace(1, 150, 128, 384, dt, dev, row_pad=64, inside=ws)
+    part = SeqWorkspace(2, 50, 128, 384, dt, dev, row_pad=64, inside=ws)
+    for sub in (one, part):
+        priv = SeqWorkspace(sub.B, sub.S, 128, 384, dt, dev, row_pad=64)
+        for name in ("xn", "q", "k", "vt", "att", "hff"):
+            a, b, big = getattr(sub, name), getattr(priv, name), getattr(ws, name)
+            assert a.shape == b.shape and a.stride() == b.stride() and a.is_contiguous()
+            assert a.data_ptr() == big.data_ptr() and a.numel() <= big.numel()
+        sc, pc = sub.scatter(), priv.scatter()
+        assert (sc.q_bs, sc.q_hs, sc.k_bs, sc.vt_bs, sc.vt_hs, sc.vt_ds, sc.rows_per_batch) == (pc.q_bs, pc.q_hs, pc.k_bs, pc.vt_bs, pc.vt_hs, pc.vt_ds, pc.rows_per_batch)
+    one.q.fill_(1.0)
+    assert float(ws.q[0].float().min()) == 1.0 and float(ws.q[1].float().abs().max()) == 0.0      # branch 0 of the main workspace, nothing else
+    with pytest.raises(AssertionError):
+        SeqWorkspace(3, 150, 128, 384, dt, dev, row_pad=64, inside=ws)

@@ -1,5 +1,8 @@
 #!/bin/bash
 # Round-3 GPU-box runner.  usage: tools/r3_round.sh <tag> <step>...   (outputs under gpurun_out/<tag>/)
+# narbase / arbase / narprof A/B against the PREVIOUS round's library: build it from that round's tree first, e.g.
+#   git worktree add /tmp/base <round-2 commit> && bash /tmp/base/mars5-tts_amd/csrc/build.sh &&
+#   cp /tmp/base/mars5-tts_amd/libmars5_hip_tools.so mars5-tts_amd/libmars5_hip_tools_base.so   (untracked; travels with gpurun)
 TAG=${1:-r3}; shift
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
