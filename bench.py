@@ -351,12 +351,19 @@ def prompt_len(m, ref_codes, deep=True):
     return len(tt) + len(st), len(tt)
 
 
+STEP_LOG = []       # per timed utterance: wall, the AR decode / NAR loop spans inside it, persistent-step recoveries
+
+
 def run_utterance(m, ref_codes, cfg, seed):
+    from mars5_tts_amd import ar_engine, nar_engine
     torch.manual_seed(seed)
     t0 = time.perf_counter()
     gen, final = m.tts_from_codes(TEXT, ref_codes, TRANSCRIPT, cfg)
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, int(final.shape[0]), int(gen.shape[0])
+    dt = time.perf_counter() - t0
+    STEP_LOG.append((round(dt, 4), round(ar_engine.LAST_STATS.get("decode_ms", 0.0), 1), round(nar_engine.LAST_STATS.get("loop_ms", 0.0), 1),
+                     int(ar_engine.LAST_STATS.get("persistent_recoveries", 0) or 0)))
+    return dt, int(final.shape[0]), int(gen.shape[0])
 
 
 # ------------------------------------------------------------------------------------ roofline
@@ -831,6 +838,8 @@ def main():
         "n_gpus": (collective["ranks_seen"] if collective else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "p50_latency_s": round(statistics.median(lat), 4),
+        "per_step": {"note": "timed utterances in order: wall s, AR decode ms, NAR loop ms, persistent-decode recoveries",
+                     "steps": [list(x) for x in STEP_LOG[-args.steps:]]} if world == 1 else None,
         "config": {"workload": workload_name,
                    "ar_prompt_tokens": p_len, "generated_frames_per_utterance": frames / (args.steps * world),
                    "parallelism": f"replicas x{world} (one utterance stream per GPU; requests scattered / results gathered over "
