@@ -272,7 +272,7 @@ class Mars5TTS:
         generator seeded seeds[i], so result i equals ``torch.manual_seed(seeds[i]); tts_from_codes(...)`` (same property
         as ``tts_batch_from_codes``)."""
         n = len(texts)
-        ar_stream, nar_stream = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+        ar_stream, nar_stream = ops.session_stream(self.device, "ar"), ops.session_stream(self.device, "nar")
         pending = None
         for i in range(n):
             g = torch.Generator(device=self.device)
@@ -380,7 +380,8 @@ class Mars5TTS:
         order = sorted(range(n), key=lambda i: staged[i][1][4].shape[1] + staged[i][2])
         finals: List[Optional[Tensor]] = [None] * n
         flying: List[tuple] = []                     # (group, callable that waits for it), oldest first
-        lanes = [torch.cuda.Stream(device=self.device) for _ in range(max(1, nar_in_flight))] if self.device.type == "cuda" else [None]
+        lanes = ([ops.session_stream(self.device, "nar" if k == 0 else f"nar_lane{k}") for k in range(max(1, nar_in_flight))]
+                 if self.device.type == "cuda" else [None])
 
         def land():
             grp, wait_for = flying.pop(0)

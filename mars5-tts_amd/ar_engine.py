@@ -133,7 +133,7 @@ class ARSession:
         assert max_len + 1 <= model.max_pos
         H, D, F, V = s.nhead, s.dim, s.hidden_dim, s.n_vocab
         bf = buffers or {}
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.stream = stream if stream is not None else ops.session_stream(dev, "ar")
         # the buffers are zero-filled ON the session stream (behind the caller's pending work): a memset left on the
         # caller's stream could otherwise land after this stream has started writing state / KV rows
         self.stream.wait_stream(torch.cuda.current_stream(dev))
@@ -401,7 +401,7 @@ class ARBatchSession:
         self.w_alloc = min(s.sliding_window, max(max_lens) + 1)
         assert max(max_lens) + 1 <= model.max_pos
         H, D, F, V, Lr = s.nhead, s.dim, s.hidden_dim, s.n_vocab, s.n_layers
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+        self.stream = stream if stream is not None else ops.session_stream(dev, "ar")
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         # key-range splits of the cache scan: enough workgroups to fill the chip, no more (each costs a partial + merge)
         self.nsplit = max(1, min(NSPLIT, 1 << max(0, (1024 // (H * B)).bit_length() - 1)))

@@ -199,7 +199,7 @@ class NARSession:
     def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None, diff_tables=None):
         """`diff_tables`: the four fp32 log-tables of the caller's MultinomialDiffusion (None = default schedule)."""
         self.m, self.cfg = model, cfg
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=model.dev)
+        self.stream = stream if stream is not None else ops.session_stream(model.dev, "nar")
         self.graph: Optional[ops.Graph] = None
         self.diff_tables = diff_tables
 
@@ -530,7 +530,7 @@ class NARBatchSession:
 
     def __init__(self, model: NARModel, cfg: NARConfig, stream: Optional[torch.cuda.Stream] = None, diff_tables=None):
         self.m, self.cfg = model, cfg
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=model.dev)
+        self.stream = stream if stream is not None else ops.session_stream(model.dev, "nar")
         self.graph: Optional[ops.Graph] = None
         self.subs: List[NARSession] = []
         self.diff_tables = diff_tables

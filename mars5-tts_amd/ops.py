@@ -7,6 +7,7 @@ import ctypes as C
 from typing import Optional
 
 import os
+import threading
 
 import torch
 
@@ -244,6 +245,25 @@ def clock_stamp(slots: torch.Tensor, i: int, stream: Optional[int] = None) -> No
     """slots[i] (int64, device) = the 100 MHz wall clock when this one-lane launch runs (in-graph timing, bench roofline leg)."""
     assert slots.dtype == torch.int64 and slots.is_cuda and 0 <= i < slots.numel()
     check(lib.m5_clock_stamp(slots.data_ptr() + 8 * i, _s(stream)), "m5_clock_stamp")
+
+
+_SESSION_STREAMS: dict = {}
+
+
+def session_stream(dev, role: str) -> torch.cuda.Stream:
+    """The long-lived stream of one role ("ar", "nar", "nar_lane1", ...) on one device for the calling host thread.
+    Sessions used to make a fresh ``torch.cuda.Stream()`` each: torch hands those out of a pool of 32, and its caching
+    allocator keeps freed blocks PER STREAM, so the ~1.2 GB of per-utterance state (hoisted conditioning, workspaces, KV cache)
+    was hipMalloc'ed again for every utterance until the pool wrapped around -- 50 ms of host time per utterance in front of the
+    decode (tools/host_profile.py).  With one stream per role the blocks of the previous utterance are reused.  Roles keep the
+    concurrency that exists (AR decode beside NAR conditioning; two batch groups in flight); host threads keep their own streams."""
+    d = torch.device(dev)
+    idx = d.index if d.index is not None else torch.cuda.current_device()
+    key = (idx, role, threading.get_ident())
+    st = _SESSION_STREAMS.get(key)
+    if st is None:
+        st = _SESSION_STREAMS[key] = torch.cuda.Stream(device=idx)
+    return st
 
 
 class Graph:

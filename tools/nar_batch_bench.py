@@ -59,7 +59,7 @@ def main():
         if os.environ.get("CONC") == "1":
             pair = []
             for k in range(2):
-                s2 = NARBatchSession(eng, NARConfig(T=200))
+                s2 = NARBatchSession(eng, NARConfig(T=200), stream=torch.cuda.Stream())      # (sessions share one stream by default)
                 s2.prepare(items, times)
                 s2.run(unis, True, n_steps=3)
                 pair.append(s2)
