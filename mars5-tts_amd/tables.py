@@ -72,12 +72,13 @@ def nar_step_consts(times: List[int], num_classes: int = 1025, timesteps: int = 
     la, l1ma, lca, l1mca = [t.detach().to("cpu", torch.float32) for t in tables]
     assert all(0 <= t < la.shape[0] for t in times), f"schedule step outside the diffusion's {la.shape[0]} timesteps"
     lnK = np.log(num_classes)
-    rows = []
-    for t in times:
-        tm1 = max(t - 1, 0)
-        rows.append(torch.stack([lca[tm1], l1mca[tm1] - lnK, la[t], l1ma[t] - lnK, lca[t], l1mca[t] - lnK,
-                                 torch.tensor(float(t), device="cpu"), torch.tensor(0.0, device="cpu")]))
-    return torch.stack(rows).float().contiguous()
+    # one gather per column (was a python loop of 200 x 8 scalar tensors: 3 ms of host time in front of every utterance's decode);
+    # fp32 tensor - python double rounds per element exactly as the scalar form did
+    t_idx = torch.tensor(list(times), dtype=torch.long)
+    tm1 = (t_idx - 1).clamp_(min=0)
+    cols = [lca[tm1], l1mca[tm1] - lnK, la[t_idx], l1ma[t_idx] - lnK, lca[t_idx], l1mca[t_idx] - lnK,
+            t_idx.to(torch.float32), torch.zeros(len(times), dtype=torch.float32)]
+    return torch.stack(cols, dim=1).float().contiguous()
 
 
 def log_eps() -> float:

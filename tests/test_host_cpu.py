@@ -112,3 +112,28 @@ def test_workspace_laid_over_a_larger_one_shares_its_front():
     assert float(ws.q[0].float().min()) == 1.0 and float(ws.q[1].float().abs().max()) == 0.0      # branch 0 of the main workspace, nothing else
     with pytest.raises(AssertionError):
         SeqWorkspace(3, 150, 128, 384, dt, dev, row_pad=64, inside=ws)
+
+
+def test_step_consts_gathered_form_equals_the_scalar_form():
+    """tables.nar_step_consts builds its (steps, 8) table with one gather per column; it must be bit-identical to the
+    step-by-step scalar construction it replaced (fp32 table entry minus the python double ln K, per step), for the default
+    schedule, a jumpy one and a caller's own diffusion tables."""
+    from mars5_tts_amd import tables as T
+
+    def scalar_form(times, K, tabs):
+        la, l1ma, lca, l1mca = [t.detach().to("cpu", torch.float32) for t in tabs]
+        lnK = np.log(K)
+        rows = []
+        for t in times:
+            tm1 = max(t - 1, 0)
+            rows.append(torch.stack([lca[tm1], l1mca[tm1] - lnK, la[t], l1ma[t] - lnK, lca[t], l1mca[t] - lnK,
+                                     torch.tensor(float(t)), torch.tensor(0.0)]))
+        return torch.stack(rows).float().contiguous()
+
+    for steps, times in ((200, list(range(199, -1, -1))), (200, [199, 198, 199, 198, 3, 0, 1, 0]), (37, list(range(36, -1, -1)))):
+        tabs = T.diffusion_log_tables(steps)
+        got = T.nar_step_consts(times, 1025, tables=tabs)
+        ref = scalar_form(times, 1025, tabs)
+        assert got.shape == ref.shape == (len(times), 8) and got.dtype == torch.float32
+        assert torch.equal(got, ref)
+    assert torch.equal(T.nar_step_consts([5, 4], 77), scalar_form([5, 4], 77, T.diffusion_log_tables(200)))
