@@ -202,7 +202,7 @@ class ARSession:
                 ops.gemm(hb, m.w2[l], x, L.EPI_RESIDUAL, stream=st)
             self.xdec.copy_(x[M - 1])
             self.tokens[:P].copy_(prompt)
-            self.state.copy_(torch.tensor([P, 0, 0, P, -1, 0, 0, 0], dtype=torch.int32), non_blocking=False)
+            self.state.copy_(torch.tensor([P, 0, 0, P, -1, 0, 0, 0], dtype=torch.int32, device="cpu"), non_blocking=False)
             self.gran.zero_()                                  # granule tags are unique within one utterance only
             self.mega_err.zero_()
             self._keep = [table, x]
@@ -440,7 +440,7 @@ class ARBatchSession:
         if any(e is not None for e in ests):
             assert all(e is not None for e in ests)
             n_max = max(int(e) for e in ests)
-            eos_tab = torch.zeros(B, n_max + 1, dtype=torch.float32)
+            eos_tab = torch.zeros(B, n_max + 1, dtype=torch.float32, device="cpu")
             for b, e in enumerate(ests):
                 eos_tab[b, : int(e) + 1] = eos_penalty_table(int(e), cfg.eos_penalty_decay, cfg.eos_penalty_factor)
             eos_tab = eos_tab.to(m.dev)

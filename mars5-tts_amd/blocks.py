@@ -195,7 +195,7 @@ def cross_memory_table(mems, dev) -> tuple:
         for b in range(mem.Bm):
             rows.append([mem.k.data_ptr() + b * H * mem.Le * 64 * esz, mem.vt.data_ptr() + b * H * 64 * mem.Lep * esz, mem.Le, mem.Lep,
                          mem.Bm * H * mem.Le * 64, mem.Bm * H * 64 * mem.Lep])
-    return torch.tensor(rows, dtype=torch.int64).to(dev), max(m.Le for m in mems)
+    return torch.tensor(rows, dtype=torch.int64, device="cpu").to(dev), max(m.Le for m in mems)
 
 
 class AbsorbedCross:
@@ -226,8 +226,8 @@ class AbsorbedCross:
                                  mem.Bm * H * mem.Le * 64, self.A[l, s].data_ptr(), self.c[l, s].data_ptr(), self.Bt[l, s].data_ptr(), 0])
                     s += 1
             lrows.append([lw.ca_q_wT.data_ptr(), lw.ca_out_w.data_ptr(), lw.ca_q_b.data_ptr() if lw.ca_q_b is not None else 0, 0])
-        self.tab_seq = torch.tensor(rows, dtype=torch.int64).to(dev)
-        self.tab_layer = torch.tensor(lrows, dtype=torch.int64).to(dev)
+        self.tab_seq = torch.tensor(rows, dtype=torch.int64, device="cpu").to(dev)
+        self.tab_layer = torch.tensor(lrows, dtype=torch.int64, device="cpu").to(dev)
 
     @staticmethod
     def lp_of(Le: int, H: int) -> int:

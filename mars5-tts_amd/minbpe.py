@@ -251,7 +251,7 @@ class CodebookTokenizer(_BPEBase):
         for run in table:
             vals.extend(run)
             off.append(len(vals))
-        return torch.tensor(off, dtype=torch.int32), torch.tensor(vals or [0], dtype=torch.int64), max((len(r) for r in table), default=1)
+        return torch.tensor(off, dtype=torch.int32, device="cpu"), torch.tensor(vals or [0], dtype=torch.int64, device="cpu"), max((len(r) for r in table), default=1)
 
 
 def train_merges(seqs: List[List[int]], n_merges: int, first_new_id: int) -> List[_Pair]:

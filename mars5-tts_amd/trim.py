@@ -28,7 +28,7 @@ def trim(y, top_db: float = 60, ref=torch.max, frame_length: int = 2048, hop_len
     yt = y if isinstance(y, torch.Tensor) else torch.as_tensor(np.asarray(y))
     mono = torch.mean(yt, dim=0) if yt.dim() > 1 else yt
     power = _frame_power(mono.to(torch.float32), frame_length, hop_length)
-    amin = torch.tensor(1e-10)
+    amin = torch.tensor(1e-10, device=power.device)
     ref_value = ref(power) if callable(ref) else torch.abs(torch.as_tensor(ref, dtype=torch.float32))
     db = 10.0 * torch.log10(torch.maximum(amin, power)) - 10.0 * torch.log10(torch.maximum(amin, ref_value))
     nz = torch.nonzero(db > -top_db).reshape(-1)
@@ -37,7 +37,7 @@ def trim(y, top_db: float = 60, ref=torch.max, frame_length: int = 2048, hop_len
         end = min(int(yt.shape[-1]), (int(nz[-1]) + 1) * hop_length)
     else:
         start, end = 0, 0
-    return yt[..., start:end], torch.tensor([start, end])
+    return yt[..., start:end], torch.tensor([start, end], device="cpu")
 
 
 def trim_device(y: torch.Tensor, top_db: float = 60, frame_length: int = 2048, hop_length: int = 512) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -47,10 +47,10 @@ def trim_device(y: torch.Tensor, top_db: float = 60, frame_length: int = 2048, h
     from . import ops
     mono = (torch.mean(y, dim=0) if y.dim() > 1 else y).to(torch.float32).contiguous()
     if mono.shape[0] <= frame_length // 2:                 # shorter than the reflect padding: nothing to analyse
-        return y, torch.tensor([0, int(y.shape[-1])])
+        return y, torch.tensor([0, int(y.shape[-1])], device="cpu")
     b = ops.trim_bounds(mono, top_db, frame_length, hop_length).cpu()
     start, end = int(b[0]), int(b[1])
-    return y[..., start:end], torch.tensor([start, end])
+    return y[..., start:end], torch.tensor([start, end], device="cpu")
 
 
 def nuke_weight_norm(module) -> None:

@@ -137,3 +137,44 @@ def test_step_consts_gathered_form_equals_the_scalar_form():
         assert got.shape == ref.shape == (len(times), 8) and got.dtype == torch.float32
         assert torch.equal(got, ref)
     assert torch.equal(T.nar_step_consts([5, 4], 77), scalar_form([5, 4], 77, T.diffusion_log_tables(200)))
+
+
+def test_host_tables_ignore_the_ambient_default_device():
+    """Every host-side table builder must return the SAME CPU tensor whatever the ambient default device is
+    (``with torch.device(dev)`` in the parity tests / ``torch.set_default_device("cuda")`` in a user's program): round 3
+    lost its driver records to a ``torch.tensor(list(times))`` that followed the ambient device and then indexed CPU
+    tables.  The meta device stands in for "not the CPU" here: a factory call that forgets ``device=`` produces a meta
+    tensor, and mixing it with the CPU tables raises (or yields a meta result, caught by the device assert)."""
+    import io
+
+    from mars5_tts_amd import minbpe, tables as T
+    from mars5_tts_amd.diffuser import MultinomialDiffusion, _tables
+    from mars5_tts_amd.trim import trim
+
+    def build():
+        diff_tabs = _tables(MultinomialDiffusion(1025, timesteps=200))
+        return dict(
+            sine=T.sine_pe(33, 64), rope=T.rope_table(64, 50), tse=T.timestep_inputs([199, 100, 0], 64), tse_odd=T.timestep_inputs([5], 63),
+            **{f"dlt{i}": t for i, t in enumerate(T.diffusion_log_tables(200))},
+            consts=T.nar_step_consts(list(range(199, -1, -1)), 1025), consts_own=T.nar_step_consts([150, 3, 0], 1025, tables=diff_tabs),
+            eos=T.eos_penalty_table(40, 0.5, 50.0), log_eps=torch.tensor(T.log_eps(), device="cpu"))
+
+    ref = build()
+    with torch.device("meta"):
+        got = build()
+        y = torch.cat([torch.zeros(4096, device="cpu"), torch.ones(8192, device="cpu"), torch.zeros(4096, device="cpu")])
+        yt, idx = trim(y, top_db=30)
+        assert idx.device.type == "cpu" and yt.device.type == "cpu" and 0 < int(idx[0]) < int(idx[1]) < 16384
+    for k, v in ref.items():
+        assert got[k].device.type == "cpu", k
+        assert got[k].dtype == v.dtype and torch.equal(got[k], v), k
+    # the speech tokenizer's expansion table (device hand-off, SURVEY f2) is host data too
+    st = minbpe.CodebookTokenizer()
+    from mars5_tts_amd import synth
+    b = synth.make_bundle("tiny", seed=0)
+    st.load(io.BytesIO(b.ar_ckpt["vocab"]["speechtok.model"].encode()))
+    a = st.expansion_csr()
+    with torch.device("meta"):
+        c = st.expansion_csr()
+    for x_, y_ in zip(a[:2], c[:2]):
+        assert y_.device.type == "cpu" and torch.equal(x_, y_)
