@@ -32,6 +32,65 @@ PEAK_MFMA_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}     # MI355X_MI
 PEAK_HBM_GBS = 8000.0
 
 
+PREFLIGHT = None     # filled by preflight(): what the pre-flight child saw (also carried in the JSON line)
+
+_PREFLIGHT_CHILD = r"""
+import sys, time, torch
+t0 = time.time()
+i = int(sys.argv[1])
+torch.cuda.set_device(i)
+d = torch.device("cuda", i)
+x = torch.ones(1 << 20, device=d) * 2
+assert float(x.sum().item()) == float(2 << 20), "arithmetic"
+h = torch.arange(1 << 24, dtype=torch.int32).pin_memory()
+g = h.to(d, non_blocking=True)
+big = torch.empty(1 << 28, dtype=torch.uint8, device=d).fill_(7)
+cp = big.clone()
+torch.cuda.synchronize()
+assert int(g[-1].item()) == (1 << 24) - 1 and int(cp[-1].item()) == 7 and int(cp.view(torch.int64).sum().item()) == (0x0707070707070707 * (1 << 25)), "copies"
+sys.path.insert(0, sys.argv[2])
+from mars5_tts_amd import ops                      # the product library loads and one of its kernels runs
+xs = torch.randn(64, 1024, device=d)
+o = torch.empty(64, 1024, device=d, dtype=torch.bfloat16)
+ops.layernorm(xs, torch.ones(1024, device=d), torch.zeros(1024, device=d), 1e-5, o)
+torch.cuda.synchronize()
+ref = torch.nn.functional.layer_norm(xs, (1024,))
+assert float((o.float() - ref).abs().max()) < 0.05, "libmars5_hip layernorm"
+print("PREFLIGHT_OK %.1f" % (time.time() - t0))
+"""
+
+
+def preflight(local: int, timeout_s: float = 240.0) -> dict:
+    """Two seconds of GPU work in a CHILD process before anything else touches the device: fill, host->device and
+    device->device copies, a reduction, one launch of the product library.  A sick box (round 3: `Memory access fault by GPU`
+    before the first utterance had finished) kills the child, not the bench: rank 0 then prints a line that says so and the
+    process exits with code 3 -- distinct from a product failure (1 / 134) and from a refused launch (2)."""
+    import subprocess
+    busy = None
+    try:
+        import glob
+        vals = [int(open(f).read()) for f in sorted(glob.glob("/sys/class/drm/card*/device/gpu_busy_percent"))]
+        busy = vals
+    except Exception:       # noqa: BLE001
+        pass
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, "-c", _PREFLIGHT_CHILD, str(local), ROOT], capture_output=True, text=True, timeout=timeout_s)
+        rc, so, se = r.returncode, r.stdout, r.stderr
+    except subprocess.TimeoutExpired as e:
+        rc, so, se = -9, (e.stdout or b"").decode(errors="replace") if isinstance(e.stdout, bytes) else (e.stdout or ""), "pre-flight child timed out"
+    res = {"ok": rc == 0 and "PREFLIGHT_OK" in so, "rc": rc, "seconds": round(time.perf_counter() - t0, 1), "gpu_busy_percent_before": busy}
+    if not res["ok"]:
+        res["stderr_tail"] = se[-600:]
+    return res
+
+
+def emit(out: dict) -> None:
+    """One JSON line on stdout, flushed.  Called after the timed loop and again after every leg: the LAST line is the
+    complete record, every earlier one is a valid (smaller) record of the same run."""
+    print(json.dumps(out), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -49,6 +108,7 @@ def parse():
     ap.add_argument("--pipeline", action="store_true", help="also time the same utterances through tts_stream_from_codes (AR of request i+1 "
                     "enqueued beside the NAR steps of request i); measured in round 2: no overlap on this stack (5.90 vs 5.86 audio-s/s)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-preflight", action="store_true", help="skip the child-process GPU sanity check in front of the run")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default): BASELINE configs[1], one utterance per step.  c3: configs[2], one step = a batch of "
                          "--batch mixed-length requests through tts_batch_from_codes.  c4: configs[3], one step = --batch x N "
@@ -446,15 +506,23 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     # the launch on an otherwise idle GPU at higher clocks: 12 % rosier than rocprofv3 of the graph, round 2.)
     n_rep = 8
     side, sess.side = sess.side, None        # the stamped capture is one serial chain (the product graph runs the cross-attention
+    capturing = False
     try:                                     # operand build as a parallel branch beside layer 0's self-attention block)
         ops.Graph.begin(st)
+        capturing = True
         sess.enqueue_forward(st)
         ops.clock_stamp(slots, len(labels), stream=st)
+        capturing = False
         g_fwd = ops.Graph().end(st)
     finally:
         sess.side = side
         for k, v in orig.items():
             setattr(ops, k, v)
+        if capturing:                        # an enqueue raised mid-capture: close the capture, or the stream stays unusable for
+            try:                             # every leg after this one
+                ops.Graph().end(st)
+            except Exception:                # noqa: BLE001
+                pass
     n_l = len(labels)
     cal_slots = torch.zeros(64, dtype=torch.int64, device=m.device)
     ops.Graph.begin(st)
@@ -470,6 +538,7 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     cd = (cal_slots[1:] - cal_slots[:-1]).cpu().tolist()
     stamp_us = sorted(cd)[len(cd) // 2] * 0.01
     acc_us = [0.0] * n_l
+    n_clamped = 0
     for r in range(n_rep + 2):
         g_fwd.launch(st)
         ops.add_int(sess.step_ptr, 1, stream=st)
@@ -477,7 +546,9 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
         if r >= 2:
             t = slots[: n_l + 1].cpu().tolist()
             for i in range(n_l):
-                acc_us[i] += max((t[i + 1] - t[i]) * 0.01 - stamp_us, 0.01)
+                d_us = (t[i + 1] - t[i]) * 0.01 - stamp_us
+                n_clamped += d_us < 0.01
+                acc_us[i] += max(d_us, 0.01)
     e0, e1 = ops.Event(), ops.Event()
     g_plain.launch(st)
     e0.record(st)
@@ -524,7 +595,7 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
                 alg_per_launch=(dom[1]["flops"] if mfma_bound else dom[1]["bytes"]) / dom[1]["n"],
                 shapes={k: v["avg_us"] for k, v in kernels.items() if k.startswith(dom[0])},
                 forward_sum_of_intervals_us=round(sum_us, 1), forward_graph_replay_us=round(fwd_plain_us, 1),
-                whole_step_frac=round(fwd_flops / fwd_plain_us / 1e6 / peak, 4))
+                whole_step_frac=round(fwd_flops / fwd_plain_us / 1e6 / peak, 4), intervals_clamped_to_10ns=int(n_clamped))
     # NAR loop as a whole (graph replay + RNG + sample kernel), from the last timed utterance
     step_ms = ns["loop_ms"] / ns["steps"]
     nar = dict(ms_per_step=round(step_ms, 3), tflops=round(eng.flops_per_step(S, Le, s_out) / step_ms / 1e9, 1), S=S, Le=Le,
@@ -669,7 +740,7 @@ def parity_leg(m, bundle, ref_codes, dtype_name, n_ar=48):
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=40.0):
+def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=24.0):
     """The oracle (a torch-CPU restatement of the reference path, incl. the reference's
     per-token speaker-encoder recompute and per-forward NAR speaker encoder so the COST is the
     reference's) on a bounded sample of the same workload, extrapolated linearly:
@@ -721,7 +792,9 @@ def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=40.0):
         ratio = round(rj["port_extrapolated_s_per_utterance"] / rj["reference_extrapolated_s_per_utterance"], 3)
     except Exception:
         pass
+    blas = "mkl" if torch.backends.mkl.is_available() else ("openblas/other" if torch.backends.openmp.is_available() else "unknown")
     return dict(value=round(audio_s / total, 5), unit="audio_s/s", cores=cores, kind="port", host_cpu=cpu_name, host_logical_cpus=os.cpu_count(),
+                torch=torch.__version__, blas=blas, mkldnn=bool(torch.backends.mkldnn.is_available()), sample_wall_s=round(time.perf_counter() - t_start, 1),
                 port_over_reference_time=ratio,
                 sample=(f"oracle/mars5_oracle.py (torch-CPU fp32 port of the reference path with the reference's cost model) on this host, "
                         f"{cores} threads: AR prefill P={prompt.shape[0]} {t_prefill:.2f}s + {n_tok} decode tokens at {t_tok:.3f}s/token, "
@@ -743,6 +816,16 @@ def main():
         launch_check(args, world, rank)
         return
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    global PREFLIGHT
+    if not args.no_preflight:
+        PREFLIGHT = preflight(local)
+        if not PREFLIGHT["ok"]:
+            msg = {"preflight_failed": True, "rank": rank, "local_rank": local, "preflight": PREFLIGHT,
+                   "meaning": "the GPU of this box failed a fill / copy / one-kernel sanity check in a child process BEFORE bench.py "
+                              "touched it: a box problem, not a product result; nothing was measured"}
+            print(json.dumps(msg), flush=True)
+            print("bench.py: GPU pre-flight failed (exit code 3): " + json.dumps(PREFLIGHT), file=sys.stderr, flush=True)
+            sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -846,19 +929,51 @@ def main():
                                   f"{'RCCL' if world > 1 else 'nothing at N = 1'} outside the timed region)",
                    "hipgraph": not args.no_graph},
         "collective": collective,
+        "preflight": PREFLIGHT,
+        "legs_done": [],
     }
+    # The headline goes out NOW, before any optional leg: every leg below re-prints the enriched line when it finishes (the LAST
+    # line is the complete one), and a leg that raises is recorded as "<leg>_error" instead of taking the measurement with it
+    # (round 3 lost its driver record to an exception in a leg that ran two minutes after the timed loop had finished).
+    emit(out)
+
+    def leg(name, fn):
+        t_leg = time.perf_counter()
+        try:
+            fn()
+            out["legs_done"].append(name)
+        except Exception as e:          # noqa: BLE001 -- a diagnostic leg must never cost the headline
+            import traceback
+            out[f"{name}_error"] = f"{type(e).__name__}: {e}"[:600]
+            traceback.print_exc(file=sys.stderr)
+            try:
+                torch.cuda.synchronize()
+            except Exception as e2:     # noqa: BLE001
+                out[f"{name}_error"] += f" | device unusable afterwards: {e2}"[:200]
+        out.setdefault("leg_seconds", {})[name] = round(time.perf_counter() - t_leg, 1)
+        emit(out)
+
+    single = world == 1
     if not args.no_roofline:
-        from mars5_tts_amd import ar_engine, nar_engine
-        ar_stats, nar_stats = dict(ar_engine.LAST_STATS), dict(nar_engine.LAST_STATS)
-        roof, ar_roof, nar, kernels = roofline_leg(m, ref_codes, cfg, args.dtype)
-        ar_engine.LAST_STATS.update(ar_stats)
-        nar_engine.LAST_STATS.update(nar_stats)
-        out["roofline"] = roof
-        out["roofline_ar_decode"] = ar_roof
-        out["nar_loop"] = nar
-        out["kernels"] = kernels
-        out["time_split_ms"] = {"ar_decode": round(ar_engine.LAST_STATS["decode_ms"], 1), "nar_loop": round(nar["ms_per_step"] * 200, 1)}
-    if world == 1 and args.workload == "c2" and not args.no_batch_leg:
+        def _roofline():
+            from mars5_tts_amd import ar_engine, nar_engine
+            ar_stats, nar_stats = dict(ar_engine.LAST_STATS), dict(nar_engine.LAST_STATS)
+            try:
+                roof, ar_roof, nar, kernels = roofline_leg(m, ref_codes, cfg, args.dtype)
+            finally:
+                ar_engine.LAST_STATS.update(ar_stats)
+                nar_engine.LAST_STATS.update(nar_stats)
+            out["roofline"] = roof
+            out["roofline_ar_decode"] = ar_roof
+            out["nar_loop"] = nar
+            out["kernels"] = kernels
+            out["time_split_ms"] = {"ar_decode": round(ar_engine.LAST_STATS["decode_ms"], 1), "nar_loop": round(nar["ms_per_step"] * 200, 1)}
+        leg("roofline", _roofline)
+    if single and not args.no_cpu_baseline:
+        leg("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baseline_leg(m, bundle, ref_codes, cfg, args.n_gen)))
+    if single and not args.no_parity and args.workload == "c2":
+        leg("parity", lambda: out.__setitem__("parity", parity_leg(m, bundle, ref_codes, args.dtype)))
+    if single and args.workload == "c2" and not args.no_batch_leg:
         # throughput mode beside the headline (BASELINE configs[2] in small): 8 mixed-length requests through the batched
         # AR decode + batched NAR refinement; the SECOND pass is timed (the first one captures the step graphs of these shapes)
         from inference import InferenceConfig
@@ -880,43 +995,46 @@ def main():
                     "s_per_batch": round(dtb, 3), "reference_frames": [int(r.shape[-1]) for r in refs],
                     "note": f"tts_batch_from_codes(ar_batch={ar_b}, nar_batch={nar_b}), pass {passes} of {passes} timed (pass 1 captures the graphs)"}
 
-        out["batch8_mixed_lengths"] = batch_leg(8, 8, 8)
+        leg("batch8_mixed_lengths", lambda: out.__setitem__("batch8_mixed_lengths", batch_leg(8, 8, 8)))
         if not args.no_extra_legs:
             # BASELINE configs[2] in full (32 mixed-length requests per step) and configs[4] (60 s long-form utterance): one
             # timed step each after one warm-up step, so that the driver's record carries them (`--workload c3 / c5` are the
             # stand-alone forms with their own time splits)
-            out["c3_batch32"] = batch_leg(32, args.ar_batch, args.nar_batch)
-            text_c2 = TEXT
-            TEXT = " ".join(WORDS[(7 * i) % len(WORDS)] for i in range(150)).capitalize() + "."
-            p5, nt5 = prompt_len(m, ref_codes)
-            cfg5 = make_cfg(nt5, p5, 4500)
-            run_utterance(m, ref_codes, cfg5, 700)
-            dt5, n5, _ = run_utterance(m, ref_codes, cfg5, 701)
-            from mars5_tts_amd import ar_engine as _ae, nar_engine as _ne
-            out["c5_longform"] = {"value": round(n5 / 75.0 / dt5, 4), "unit": "audio_s/s", "s_per_utterance": round(dt5, 3), "generated_frames": n5,
-                                  "ar_us_per_token": round(1e3 * _ae.LAST_STATS["decode_ms"] / max(_ae.LAST_STATS["n_generated"] - 1, 1), 1),
-                                  "nar_ms_per_step": round(_ne.LAST_STATS["loop_ms"] / _ne.LAST_STATS["steps"], 3), "nar_S": _ne.LAST_STATS["S"],
-                                  "note": "BASELINE configs[4]: 60 s target, AR context past the 3000-slot rotating KV window; second utterance timed"}
-            TEXT = text_c2
-    if world == 1 and args.workload == "c2" and args.pipeline:
+            leg("c3_batch32", lambda: out.__setitem__("c3_batch32", batch_leg(32, args.ar_batch, args.nar_batch)))
+
+            def _c5():
+                global TEXT
+                text_c2 = TEXT
+                try:
+                    TEXT = " ".join(WORDS[(7 * i) % len(WORDS)] for i in range(150)).capitalize() + "."
+                    p5, nt5 = prompt_len(m, ref_codes)
+                    cfg5 = make_cfg(nt5, p5, 4500)
+                    run_utterance(m, ref_codes, cfg5, 700)
+                    dt5, n5, _ = run_utterance(m, ref_codes, cfg5, 701)
+                finally:
+                    TEXT = text_c2
+                from mars5_tts_amd import ar_engine as _ae, nar_engine as _ne
+                out["c5_longform"] = {"value": round(n5 / 75.0 / dt5, 4), "unit": "audio_s/s", "s_per_utterance": round(dt5, 3), "generated_frames": n5,
+                                      "ar_us_per_token": round(1e3 * _ae.LAST_STATS["decode_ms"] / max(_ae.LAST_STATS["n_generated"] - 1, 1), 1),
+                                      "nar_ms_per_step": round(_ne.LAST_STATS["loop_ms"] / _ne.LAST_STATS["steps"], 3), "nar_S": _ne.LAST_STATS["S"],
+                                      "note": "BASELINE configs[4]: 60 s target, AR context past the 3000-slot rotating KV window; second utterance timed"}
+            leg("c5_longform", _c5)
+    if single and args.workload == "c2" and args.pipeline:
         # serving mode, reported beside (never as) the headline: the same utterances as a pipelined stream -- request i+1's AR
         # decode overlaps request i's NAR steps (Mars5TTS.tts_stream_from_codes); throughput up, per-request latency not
-        n_p = max(args.steps, 3)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        fr = 0
-        for _, fin in m.tts_stream_from_codes([TEXT] * n_p, [ref_codes] * n_p, [TRANSCRIPT] * n_p, cfg, seeds=[3000 + i for i in range(n_p)]):
-            fr += int(fin.shape[0])
-        torch.cuda.synchronize()
-        dtp = time.perf_counter() - t0
-        out["pipelined_stream"] = {"value": round(fr / 75.0 / dtp, 4), "unit": "audio_s/s", "requests": n_p, "s_per_request": round(dtp / n_p, 4),
-                                   "note": "AR decode of request i+1 overlapped with the NAR steps of request i on two HIP streams; "
-                                           "results identical to sequential seeded calls (tests/test_gpu_e2e.py)"}
-    if world == 1 and not args.no_parity and args.workload == "c2":
-        out["parity"] = parity_leg(m, bundle, ref_codes, args.dtype)
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_leg(m, bundle, ref_codes, cfg, args.n_gen)
-    print(json.dumps(out), flush=True)
+        def _pipe():
+            n_p = max(args.steps, 3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fr = 0
+            for _, fin in m.tts_stream_from_codes([TEXT] * n_p, [ref_codes] * n_p, [TRANSCRIPT] * n_p, cfg, seeds=[3000 + i for i in range(n_p)]):
+                fr += int(fin.shape[0])
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - t0
+            out["pipelined_stream"] = {"value": round(fr / 75.0 / dtp, 4), "unit": "audio_s/s", "requests": n_p, "s_per_request": round(dtp / n_p, 4),
+                                       "note": "AR decode of request i+1 overlapped with the NAR steps of request i on two HIP streams; "
+                                               "results identical to sequential seeded calls (tests/test_gpu_e2e.py)"}
+        leg("pipelined_stream", _pipe)
     if world > 1:
         dist.destroy_process_group()
 
