@@ -47,7 +47,8 @@ g = h.to(d, non_blocking=True)
 big = torch.empty(1 << 28, dtype=torch.uint8, device=d).fill_(7)
 cp = big.clone()
 torch.cuda.synchronize()
-assert int(g[-1].item()) == (1 << 24) - 1 and int(cp[-1].item()) == 7 and int(cp.view(torch.int64).sum().item()) == (0x0707070707070707 * (1 << 25)), "copies"
+assert int(g[-1].item()) == (1 << 24) - 1 and int(g.to(torch.int64).sum().item()) == ((1 << 24) - 1) * (1 << 23), "host -> device copy"
+assert bool(cp.view(torch.int64).eq(0x0707070707070707).all().item()), "fill / device -> device copy"
 sys.path.insert(0, sys.argv[2])
 from mars5_tts_amd import ops                      # the product library loads and one of its kernels runs
 xs = torch.randn(64, 1024, device=d)
