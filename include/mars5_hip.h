@@ -141,11 +141,50 @@ M5_API int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const voi
  *    (elements), A out, c out, B^T out, 0};  tab_layer [n_layers][4]: {WqT ([H][D][64]: Wq[h*64+d][n] at [h][n][d]),
  *    Wo ([D][D] row-major), bq (fp32 [D]) or 0, 0}.  Lp = 48 or 64 >= every Le.
  *  - m5_xattn_scores: P[b] = per-head softmax(X[b] A[b]^T + c[b]) (16-bit [M][n_heads*Lp], row stride ldp) for `batch`
- *    sequences (strides sX, sA_tab, sc_tab, sP in elements).  Then m5_gemm(P, B^T, EPI_RESIDUAL, batch) finishes the block. */
+ *    sequences (strides sX, sA_tab, sc_tab, sP in elements).  Then m5_gemm(P, B^T, EPI_RESIDUAL, batch) finishes the block.
+ *    Deferred LayerNorm (below): tab_seq[..][7] = s out (fp32 [n_heads*Lp]) and tab_layer[..][3] = fp32 [D] row sums of the
+ *    query weights make m5_xattn_absorb also write s[h Lp + j] = scale K_h[j] . rowsum(Wq_h) = sum_k A[h Lp + j][k]. */
 M5_API int m5_xattn_absorb(int dtype, const int64_t* tab_seq, const int64_t* tab_layer, int n_layers, int n_seq, int n_heads,
                     int D, int Lp, const int32_t* step, float scale, void* stream);
 M5_API int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
                     void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, void* stream);
+
+/* LayerNorm DEFERRED into the GEMM that consumes it (NAR decoder, model.py:179-203: norm1 / norm2 / norm3 of the pre-LN
+ * nn.TransformerDecoderLayer).  For rows x (fp32 residual stream, D features) and a Linear (W, b) behind LayerNorm(gamma, beta):
+ *     LN(x) W^T + b = r (xt W'^T - d s) + b',   xt = dtype(x - cen),  W' = dtype(W diag gamma),  s[n] = sum_k W'[n][k],
+ *     b' = b + W beta,  d = mean(x - cen),  r = 1 / sqrt(var(x) + eps)           (cen: any per-row constant near the mean)
+ * so the LayerNorm launch, its read of x and the normalised copy disappear:
+ *  - mode 1, the PRODUCER: m5_gemm_dln(M5_EPI_RESIDUAL) updates x in place as m5_gemm does and also writes xt (row stride
+ *    ld_xt) and, per row and 128-column tile tn, part[row][tn] = {sum, sum of squares} of (x_new - cen_in[row]) over the tile
+ *    (np = N / 128, even, <= 8; cen_in NULL = 0).
+ *  - mode 2, a CONSUMER: m5_gemm_dln(M5_EPI_QKV / M5_EPI_SWIGLU) and m5_xattn_scores_dln take A = xt and W = W', bias = b',
+ *    derive (d, r) per row from the np partial pairs (n_feat = D, eps) and apply the formula in their epilogues; the column
+ *    tile 0 workgroups also write cen_out[row] = cen_in[row] + d (= the row's mean: the next producer's centre).
+ * Rows of xt / part / cen are numbered bz * rows_bs + m for batched launches.  m5_layernorm_mean starts a chain (an explicit
+ * LayerNorm that also leaves the row means).  16-bit operands only; M5_ERR_UNSUPPORTED for shapes / tilings without the
+ * vector epilogues (N % 128 for a producer).  Exact in exact arithmetic; in 16 bits the rounding moves from LN(x) to x - cen and
+ * from W to W diag gamma (same count and magnitude: tests/test_gpu_kernels.py, tests/test_gpu_parity16.py). */
+typedef struct {
+    int32_t mode;             /* 1 producer, 2 consumer                                           */
+    int32_t np;               /* partial pairs per row                                            */
+    void* xt; int64_t ld_xt;  /* producer: centred operand-type copy of the updated rows          */
+    float* part;              /* [rows][np][2] fp32                                               */
+    const float* cen_in;      /* [rows] fp32 or NULL                                              */
+    float* cen_out;           /* consumer: [rows] fp32 or NULL                                    */
+    const float* s;           /* consumer: [N] fp32 row sums of W'                                */
+    int64_t s_bs;             /* consumer: batch stride of s (elements)                           */
+    float eps;                /* consumer                                                         */
+    int32_t n_feat;           /* consumer: D                                                      */
+    int32_t rows_bs;          /* rows per batch entry                                             */
+} M5DeferredLN;
+M5_API int m5_gemm_dln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
+                int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, const M5DeferredLN* dl, void* stream);
+M5_API int m5_xattn_scores_dln(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                        void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
+                        void* stream);
+M5_API int m5_layernorm_mean(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                      void* y, int64_t ldy, int M, int D, float* mean_out, void* stream);
 
 /* x[M][N] += A . W^T + bias (the RESIDUAL epilogue of m5_gemm) with the LayerNorm that follows it in every pre-LN
  * block (model.py:179-203: norm2 / norm3 / the next layer's norm1) fused into the same launch:

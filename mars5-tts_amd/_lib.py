@@ -117,6 +117,12 @@ class NarSampleArgs(C.Structure):
                 ("div_mode", i32), ("q0_override_steps", i32)]
 
 
+class DeferredLN(C.Structure):
+    """M5DeferredLN (include/mars5_hip.h): a LayerNorm deferred into the GEMM that consumes it."""
+    _fields_ = [("mode", i32), ("np", i32), ("xt", vp), ("ld_xt", i64), ("part", vp), ("cen_in", vp), ("cen_out", vp),
+                ("s", vp), ("s_bs", i64), ("eps", f32), ("n_feat", i32), ("rows_bs", i32)]
+
+
 # name -> (restype, argtypes); also the list the symbol-export test checks against the header
 PROTOTYPES = {
     "m5_version": (C.c_int, []),
@@ -128,6 +134,11 @@ PROTOTYPES = {
                                        vp, C.c_int, vp]),
     "m5_xattn_absorb": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
     "m5_xattn_scores": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "m5_gemm_dln": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int,
+                              C.POINTER(QkvScatter), C.c_int, i64, i64, i64, i64, C.POINTER(DeferredLN), vp]),
+    "m5_xattn_scores_dln": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(DeferredLN), vp]),
+    "m5_layernorm_mean": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, vp, vp]),
     "m5_layernorm": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
     "m5_rmsnorm": (C.c_int, [C.c_int, vp, i64, vp, f32, vp, i64, C.c_int, C.c_int, vp]),
     "m5_attention": (C.c_int, [C.c_int, C.POINTER(AttnArgs), vp]),

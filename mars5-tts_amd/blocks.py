@@ -69,7 +69,60 @@ def pack_layer(sd: Dict[str, torch.Tensor], p: str, dt: torch.dtype, dev, cross:
             lw.ca_k_w, lw.ca_v_w = lw.ca_kv_w[:D], lw.ca_kv_w[D:]
         lw.ca_out_b = Fv(f"{p}.multihead_attn.out_proj.bias")
         lw.n3_w, lw.n3_b = Fv(f"{p}.norm3.weight"), Fv(f"{p}.norm3.bias")
+        if DeferredLN.eligible(D, dt):
+            fold_layer_dln(sd, p, lw, act, dt, dev)
     return lw
+
+
+def fold_layer_dln(sd: Dict[str, torch.Tensor], p: str, lw: EncLayerW, act: torch.Tensor, dt: torch.dtype, dev) -> None:
+    """Weights of one decoder layer for the deferred-LayerNorm path (include/mars5_hip.h, M5DeferredLN): for each Linear behind
+    a LayerNorm (norm1 -> in_proj, norm2 -> cross-attention query projection, norm3 -> SwiGLU pair)
+    W' = dtype(W diag gamma), b' = b + W beta (fp32, from the fp32 master weights), s = row sums of W' AS ROUNDED (fp32)."""
+    f = lambda n: sd[n].float()                                      # noqa: E731
+    D = lw.out_w.shape[0]
+    H = D // 64
+
+    def fold(W, b, g, be):
+        Wf = (W * g[None, :]).to(dt)
+        bf = W @ be + (b if b is not None else 0.0)
+        return Wf.to(dev).contiguous(), bf.to(dev, torch.float32).contiguous(), Wf.float().sum(dim=1).to(dev).contiguous()
+
+    lw.in_w_f, lw.in_b_f, lw.in_s = fold(f(f"{p}.self_attn.in_proj_weight"), f(f"{p}.self_attn.in_proj_bias"), f(f"{p}.norm1.weight"), f(f"{p}.norm1.bias"))
+    lw.act_w_f, lw.act_b_f, lw.act_s = fold(act, None, f(f"{p}.norm3.weight"), f(f"{p}.norm3.bias"))
+    cw, cb = f(f"{p}.multihead_attn.in_proj_weight")[:D], f(f"{p}.multihead_attn.in_proj_bias")[:D]
+    wq_f, lw.ca_q_b_f, lw.ca_q_rs = fold(cw, cb, f(f"{p}.norm2.weight"), f(f"{p}.norm2.bias"))
+    lw.ca_q_wT_f = wq_f.view(H, 64, D).permute(0, 2, 1).contiguous()
+
+
+class DeferredLN:
+    """Buffers of a deferred-LayerNorm chain over the rows of a SeqWorkspace (csrc/gemm16.hip, DLN): per row and 128-column
+    tile the partial sums {sum, sum of squares} of (x - centre) left by the residual GEMM that produced x, and the row
+    centres.  The centred 16-bit copy of x lives in ws.xn (the LayerNorm output it replaces)."""
+
+    def __init__(self, ws: "SeqWorkspace", dev):
+        self.np = ws.D // 128
+        self.D = ws.D
+        self.part = torch.zeros(ws.M, self.np, 2, dtype=torch.float32, device=dev)
+        self.cen = torch.zeros(ws.M, dtype=torch.float32, device=dev)
+
+    @staticmethod
+    def eligible(D: int, dt: torch.dtype) -> bool:
+        return dt != torch.float32 and D % 256 == 0 and D // 128 <= 8
+
+    def producer(self, ws: "SeqWorkspace", r0: int = 0, rows_bs: Optional[int] = None) -> L.DeferredLN:
+        """The residual GEMM over rows [r0, ...) also writes the centred copy (ws.xn) and the partials; centre = self.cen."""
+        es = ws.xn.element_size()
+        return L.DeferredLN(mode=1, np=self.np, xt=ws.xn.data_ptr() + r0 * ws.D * es, ld_xt=ws.D, part=self.part.data_ptr() + r0 * self.np * 8,
+                            cen_in=self.cen.data_ptr() + r0 * 4, cen_out=None, s=None, s_bs=0, eps=0.0, n_feat=self.D,
+                            rows_bs=rows_bs if rows_bs is not None else ws.M)
+
+    def consumer(self, s: torch.Tensor, r0: int = 0, rows_bs: Optional[int] = None, s_bs: int = 0, M: Optional[int] = None) -> L.DeferredLN:
+        """A GEMM whose A operand is the centred copy applies LayerNorm in its epilogue (s: row sums of the folded weights) and
+        moves the row centres to the rows' means."""
+        assert s.dtype == torch.float32 and s.is_contiguous()
+        cen = self.cen.data_ptr() + r0 * 4
+        return L.DeferredLN(mode=2, np=self.np, xt=None, ld_xt=0, part=self.part.data_ptr() + r0 * self.np * 8, cen_in=cen, cen_out=cen,
+                            s=s.data_ptr(), s_bs=s_bs, eps=LAYERNORM_EPS, n_feat=self.D, rows_bs=rows_bs if rows_bs is not None else (M or 1 << 30))
 
 
 def round_up(x: int, m: int) -> int:
@@ -205,7 +258,7 @@ class AbsorbedCross:
     GEMM with the residual epilogue, both batched over the sequences.  Lp is a function of the utterance's own Le, so an
     utterance is computed with the same arithmetic alone and inside any batch."""
 
-    def __init__(self, layers, mems_per_layer, s0: int, D: int, dt: torch.dtype, dev):
+    def __init__(self, layers, mems_per_layer, s0: int, D: int, dt: torch.dtype, dev, dln: bool = False):
         H = D // 64
         self.H, self.D, self.dt, self.s0 = H, D, dt, s0
         self.n_seq = sum(mem.Bm for mem in mems_per_layer[0])
@@ -216,16 +269,24 @@ class AbsorbedCross:
         self.A = torch.zeros(self.n_layers, self.n_seq, N, D, dtype=dt, device=dev)
         self.c = torch.zeros(self.n_layers, self.n_seq, N, dtype=torch.float32, device=dev)
         self.Bt = torch.zeros(self.n_layers, self.n_seq, D, N, dtype=dt, device=dev)
+        # deferred LayerNorm (`dln`): layers >= 1 take the gamma-folded query weights and also get s = row sums of A
+        self.dln = dln and all(hasattr(lw, "ca_q_wT_f") for lw in layers)
+        self.sA = torch.zeros(self.n_layers, self.n_seq, N, dtype=torch.float32, device=dev) if self.dln else None
         rows, lrows = [], []
         es = self.A.element_size()
         for l, (lw, mems) in enumerate(zip(layers, mems_per_layer)):
             s = 0
             for mem in mems:
                 for b in range(mem.Bm):
+                    folded = self.dln and l >= 1
                     rows.append([mem.k.data_ptr() + b * H * mem.Le * 64 * es, mem.v_rows.data_ptr() + b * H * mem.Le * 64 * es, mem.Le,
-                                 mem.Bm * H * mem.Le * 64, self.A[l, s].data_ptr(), self.c[l, s].data_ptr(), self.Bt[l, s].data_ptr(), 0])
+                                 mem.Bm * H * mem.Le * 64, self.A[l, s].data_ptr(), self.c[l, s].data_ptr(), self.Bt[l, s].data_ptr(),
+                                 self.sA[l, s].data_ptr() if folded else 0])
                     s += 1
-            lrows.append([lw.ca_q_wT.data_ptr(), lw.ca_out_w.data_ptr(), lw.ca_q_b.data_ptr() if lw.ca_q_b is not None else 0, 0])
+            if self.dln and l >= 1:
+                lrows.append([lw.ca_q_wT_f.data_ptr(), lw.ca_out_w.data_ptr(), lw.ca_q_b_f.data_ptr(), lw.ca_q_rs.data_ptr()])
+            else:
+                lrows.append([lw.ca_q_wT.data_ptr(), lw.ca_out_w.data_ptr(), lw.ca_q_b.data_ptr() if lw.ca_q_b is not None else 0, 0])
         self.tab_seq = torch.tensor(rows, dtype=torch.int64, device="cpu").to(dev)
         self.tab_layer = torch.tensor(lrows, dtype=torch.int64, device="cpu").to(dev)
 
@@ -256,7 +317,25 @@ class AbsorbedCross:
                  sC=ws.Sr * self.D, sBias=0, stream=stream)
 
 
-def make_cross_plan(layers, mems_per_layer, D: int, dt: torch.dtype, dev) -> list:
+    def block_dln(self, l: int, x: torch.Tensor, lw: EncLayerW, ws: "SeqWorkspace", dl: DeferredLN, consume: bool, stream=None) -> None:
+        """``block`` inside a deferred-LayerNorm chain: `consume` = ws.xn holds the centred copy of x (the scores GEMM applies
+        norm2 in its epilogue; layers >= 1), else ws.xn = LN2(x); the P.B GEMM always leaves the centred copy + partials of
+        the updated rows for norm3."""
+        N = self.H * self.Lp
+        r0, rows = self.s0 * ws.Sr, self.n_seq * ws.Sr
+        assert N <= ws.FF and self.dln
+        P = ws.hff.view(-1)[r0 * N: (r0 + rows) * N].view(rows, N)
+        if consume:
+            assert l >= 1
+            ops.xattn_scores_dln(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq,
+                                 dl.consumer(self.sA[l], r0=r0, rows_bs=ws.Sr, s_bs=N), stream=stream)
+        else:
+            ops.xattn_scores(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq, stream=stream)
+        ops.gemm_dln(P, self.Bt[l, 0], x[r0:], L.EPI_RESIDUAL, dl.producer(ws, r0=r0, rows_bs=ws.Sr), bias=lw.ca_out_b, M=ws.Sr, batch=self.n_seq,
+                     sA=ws.Sr * N, sW=self.D * N, sC=ws.Sr * self.D, sBias=0, stream=stream)
+
+
+def make_cross_plan(layers, mems_per_layer, D: int, dt: torch.dtype, dev, dln: bool = False) -> list:
     """Split the workspace's sequences (in order; mems_per_layer[l] = one CrossMemory per utterance) into maximal runs of
     utterances that take the same cross-attention path: ("absorbed", AbsorbedCross) for 16-bit engines and memories of
     <= 64 rows (one run per padded length), ("plain", s0, s1, utterance indices) otherwise."""
@@ -272,7 +351,7 @@ def make_cross_plan(layers, mems_per_layer, D: int, dt: torch.dtype, dev) -> lis
             j += 1
         n = sum(m.Bm for m in mems0[i:j])
         if cls:
-            plan.append(("absorbed", AbsorbedCross(layers, [ml[i:j] for ml in mems_per_layer], s, D, dt, dev)))
+            plan.append(("absorbed", AbsorbedCross(layers, [ml[i:j] for ml in mems_per_layer], s, D, dt, dev, dln=dln)))
         else:
             plan.append(("plain", s, s + n, list(range(i, j))))
         s += n
@@ -353,6 +432,47 @@ def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_p
         before_cross()
     n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b), xa=xa, plan=plan, layer=layer)
     return ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream, normed=n, next_ln=next_ln)
+
+
+def plan_allows_dln(plan) -> bool:
+    return plan is not None and len(plan) > 0 and all(seg[0] == "absorbed" and seg[1].dln for seg in plan)
+
+
+def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr: torch.Tensor, dl: DeferredLN, plan, layer: int,
+                      chain_in: bool, chain_out: bool, stream=None, key_len: Optional[torch.Tensor] = None, before_cross=None,
+                      skip_self: bool = False) -> None:
+    """One pre-LN decoder layer with its LayerNorms DEFERRED into the GEMMs that consume them (include/mars5_hip.h,
+    M5DeferredLN; reference model.py:179-203, same mathematics): every residual GEMM leaves a centred 16-bit copy of the rows
+    it updated (ws.xn) + per-tile row partials, the next projection applies the normalisation in its epilogue -- 3 LayerNorm
+    launches per layer less.  `chain_in`: ws.xn / dl already describe x (left by the previous layer's linear2), else norm1
+    is an explicit launch.  Layer 0 keeps explicit norm1 / norm2 launches (its self-attention block runs once for both guidance
+    branches; norm2 starts the chain and leaves the row means as the first centres), so the per-row arithmetic is the same
+    for a lone utterance and inside any batch.  `chain_out`: linear2 leaves the copy for the next layer's norm1.
+    `skip_self`: the caller already ran the self-attention block (layer 0 of a guided lone utterance)."""
+    first = layer == 0
+    assert first or chain_in
+    if not skip_self:
+        if chain_in and not first:
+            ops.gemm_dln(ws.xn, lw.in_w_f, None, L.EPI_QKV, dl.consumer(lw.in_s, M=ws.M), bias=lw.in_b_f, scatter=ws.scatter(), stream=stream)
+        else:
+            ops.layernorm(x, lw.n1_w, lw.n1_b, LAYERNORM_EPS, ws.xn, stream=stream)
+            ops.gemm(ws.xn, lw.in_w, None, L.EPI_QKV, bias=lw.in_b, scatter=ws.scatter(), stream=stream)
+        ops.attention(ws.dt, ws.self_attn_args(key_len), stream=stream)
+        if first:
+            ops.gemm(ws.att, lw.out_w, x, L.EPI_RESIDUAL, bias=lw.out_b, stream=stream)
+        else:
+            ops.gemm_dln(ws.att, lw.out_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.out_b, stream=stream)
+    if before_cross is not None:
+        before_cross()
+    if first:
+        ops.layernorm_mean(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, dl.cen, stream=stream)
+    for seg in plan:
+        seg[1].block_dln(layer, x, lw, ws, dl, consume=not first, stream=stream)
+    ops.gemm_dln(ws.xn, lw.act_w_f, ws.hff, L.EPI_SWIGLU, dl.consumer(lw.act_s, M=ws.M), bias=lw.act_b_f, stream=stream)
+    if chain_out:
+        ops.gemm_dln(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.l2_b, stream=stream)
+    else:
+        ops.gemm(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, bias=lw.l2_b, stream=stream)
 
 
 class SpeakerEncoder:

@@ -62,6 +62,17 @@ struct Gemm16Params {
     const int* xa_step; int xa_rows_per_seq;     // memory block of step *xa_step; rows per sequence in A / out
     unsigned char* xa_out; int64_t xa_ld_out;    // attention output [M][n_heads * 64], operand type
     float xa_scale;
+    // DLN: LayerNorm DEFERRED into the consuming GEMM.  LN(x) W^T + b = r (xt W'^T - d s) + b' with
+    // xt = T(x - cen) a second output of the residual GEMM that produced x (DLN = 1: it also writes per (row, column tile)
+    // partial sums {sum, sum of squares} of x - cen), W' = T(W diag gamma), s = row sums of W', b' = b + W beta, and per row
+    // d = mean(x - cen), r = rsqrt(var + eps) from the partials (DLN = 2: the consumer; it also leaves cen + d for the next
+    // producer of that row).  The LayerNorm launch, its read of x and the normalised copy disappear.
+    unsigned char* dl_xt; int64_t dl_ld_xt;      // producer: centred operand-type copy of the updated rows
+    float* dl_part; int dl_np;                   // [rows][dl_np] {sum, sumsq}: producer writes entry tn (dl_np = its tilesN), consumer reads all
+    const float* dl_cen_in; float* dl_cen_out;   // per-row centre (nullptr in: 0); consumer, column tile 0: cen_out = cen_in + d
+    const float* dl_s; int64_t dl_s_bs;          // consumer: per output column, sum_k W'[n][k] (fp32); batch stride
+    float dl_eps, dl_inv_n;                      // consumer: LayerNorm eps, 1 / feature count
+    int dl_rows_bs;                              // rows per batch entry in dl_part / dl_cen_* / dl_xt (batched launches)
 };
 constexpr int EPI_RESIDUAL_LN = 101;
 constexpr int EPI_Q_CROSS = 102;
@@ -148,19 +159,28 @@ __device__ inline void wait_younger(int y, bool full_share) {
 // cache cold (the step alternates between a dozen kernels): measured, the identical slow path became 6.5 us per launch slower
 // when the kernel merely grew from 2100 to 2500 instructions, and the "fixed" cost of a launch is ~10 us against 3.6 us for
 // hipBLASLt's kernels (profiles/r3m_*).  FAST compiles the fallbacks out: straight-line code, a fraction of the size.
-template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, bool FAST = false>
+constexpr int DL_MAX_NP = 8;                      // deferred LayerNorm: at most 8 column tiles of partials per row (D <= 8 x 128)
+template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, bool FAST = false, int DLN = 0>
 __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_kernel(Gemm16Params p) {
     using st = typename T::storage;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
     constexpr int STAGE = (BM + BN) * BKB;
+    // DLN = 2 (consumer): behind the stages, the tile's BM x np partial pairs (LDS-DMA'd in front of the operand stages) and
+    // the per-row {d, r} derived from them.  DLN = 1 (producer): the per-wave row sums that the WN waves of a row exchange.
+    constexpr int DL_PART = (DLN == 2) ? BM * DL_MAX_NP * 8 : 0;
+    constexpr int DL_BYTES = (DLN == 2) ? DL_PART + BM * 8 : ((DLN == 1) ? NW * TM * 16 * 8 : 0);
+    static_assert(DLN == 0 || FAST, "deferred LayerNorm: FAST instantiations only");
+    static_assert(DLN != 1 || EPI == M5_EPI_RESIDUAL, "deferred LayerNorm producer = residual epilogue");
+    static_assert(DLN != 2 || EPI == M5_EPI_QKV || EPI == M5_EPI_SWIGLU || EPI == EPI_SOFTMAX_HEADS, "deferred LayerNorm consumers");
     constexpr int RPI = 1024 / BKB;                    // rows per 1 KiB DMA instruction (8 or 16)
     constexpr int NQ = (BM + BN) / RPI;                // DMA instructions per stage; instruction q -> wave q % NW
     constexpr int JN = (NQ + NW - 1) / NW;
     constexpr int KS = BKB / 64;                       // MFMA k-steps (32 halves) per stage
     static_assert(BM % RPI == 0 && BN % RPI == 0, "stage tiling");
-    static_assert(NSTAGE * STAGE <= 160 * 1024 && NSTAGE >= 2 && NSTAGE <= 10, "LDS budget");
+    static_assert(NSTAGE * STAGE + DL_BYTES <= 160 * 1024 && NSTAGE >= 2 && NSTAGE <= 10, "LDS budget");
     static_assert((NSTAGE - 2) * JN < 64, "vmcnt range");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE + DL_BYTES];
+    unsigned char* const dl_lds = lds + NSTAGE * STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -407,6 +427,32 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 
     const int nk = p.K * 2 / BKB;
     const bool full_share = (NQ % NW == 0) || (wave < NQ % NW);     // this wave issues JN (else JN - 1) DMAs per stage
+    // ---- deferred LayerNorm.  Rows of dl_part / dl_cen / dl_xt are numbered over the whole (batched) problem.
+    const int dl_row0 = (DLN != 0) ? bz * p.dl_rows_bs + m0 : 0;
+    if constexpr (DLN == 2) {
+        // consumer: this tile's rows x np partial pairs as ONE flat LDS-DMA copy (rows are contiguous in dl_part), requested in
+        // FRONT of the operand stages: the VM counter retires in order, so they have landed when K-step 0 has -- no registers,
+        // no exposed latency.  Rows past M repeat the last 16 bytes (finite junk, never stored).
+        const uint32_t row_b = (uint32_t)p.dl_np * 8;
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readfirstlane(min(BM, p.M - m0)) * row_b;
+        const unsigned char* pb = uniform_ptr(reinterpret_cast<const unsigned char*>(p.dl_part) + (int64_t)dl_row0 * row_b);
+        constexpr int NPQ = (BM * DL_MAX_NP * 8 + 1023) / 1024;
+#pragma unroll
+        for (int q0 = 0; q0 < NPQ; q0 += NW) {
+            const int q = q0 + wave;                                   // wave-uniform
+            if (q < NPQ && (uint32_t)q * 1024 < total) {
+                const uint32_t off = min((uint32_t)q * 1024 + (uint32_t)lane * 16, total - 16);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"(off), "s"(pb), "s"(lds_base + NSTAGE * STAGE + q * 1024) : "memory");
+            }
+        }
+    }
+    float dl_cen[(DLN == 1) ? TM : 1];
+    if constexpr (DLN == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            dl_cen[i] = p.dl_cen_in ? p.dl_cen_in[bz * p.dl_rows_bs + min(m0 + wm * TM * 16 + i * 16 + l15, p.M - 1)] : 0.f;
+    }
     auto mfma_block = [&](const uint4 (&af)[TM], const uint4 (&bf)[TN]) {
         if (EPI == M5_EPI_QKV && vblock) {
 #pragma unroll
@@ -540,6 +586,28 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     }
     }
     if (dbg_on) { dbg[2] = clock64(); dbg[3] = wall_clock64(); }
+    if constexpr (DLN == 2) {
+        // per row {d = mean(x - cen), r = 1 / sqrt(var + eps)} from the np partial pairs (summed in a fixed order: every column
+        // tile of a row derives the same two numbers); column tile 0 leaves the row's new centre for the next producer.
+        // (visible to the epilogues behind their __syncthreads(); the partials are older than every K-step's barrier)
+        float2* rs = reinterpret_cast<float2*>(dl_lds + DL_PART);
+        const int np = p.dl_np;
+        for (int r = tid; r < BM; r += NW * 64) {
+            const float2* pr = reinterpret_cast<const float2*>(dl_lds + r * np * 8);
+            float s1 = 0.f, s2 = 0.f;
+            for (int n = 0; n < np; ++n) { const float2 v = pr[n]; s1 += v.x; s2 += v.y; }
+            const float d = s1 * p.dl_inv_n;
+            const float var = fmaxf(s2 * p.dl_inv_n - d * d, 0.f);
+            rs[r] = make_float2(d, 1.0f / sqrtf(var + p.dl_eps));
+            if (tn == 0 && p.dl_cen_out && m0 + r < p.M) p.dl_cen_out[dl_row0 + r] = (p.dl_cen_in ? p.dl_cen_in[dl_row0 + r] : 0.f) + d;
+        }
+    }
+    // {d, r} of local row lr / the folded weights' row sums of 4 consecutive output columns (both read behind the epilogue's barrier)
+    auto dl_row = [&](int lr) -> float2 { return reinterpret_cast<const float2*>(dl_lds + DL_PART)[lr]; };
+    auto dl_s4 = [&](int col, float (&s4)[4]) {
+        const float4 t4 = *reinterpret_cast<const float4*>(p.dl_s + (int64_t)bz * p.dl_s_bs + min(col, p.N - 4));
+        s4[0] = t4.x; s4[1] = t4.y; s4[2] = t4.z; s4[3] = t4.w;
+    };
     // ---- epilogue.  swapped layout: acc[i][j][r] = C[mw + 16 i + l15][nw + 16 j + 4 lg + r]
     constexpr bool F32OUT = (EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL || EPI == EPI_RESIDUAL_LN);
     unsigned char* Cb = p.C + (int64_t)bz * p.sC * (F32OUT ? 4 : 2);
@@ -782,15 +850,24 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 const float* biasp = p.bias ? p.bias + (int64_t)bz * p.sBias : nullptr;
                 const int mrow0 = m0 + wm * TM * 16;
                 if (!vblock) {
+                    float2 drow[(DLN == 2) ? TM : 1];
+                    if constexpr (DLN == 2) {
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) drow[i] = dl_row(wm * TM * 16 + i * 16 + l15);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float bv4[4];
+                        float bv4[4], sv4[4] = {0.f, 0.f, 0.f, 0.f};
                         bias_j(j, bv4);
+                        if constexpr (DLN == 2) dl_s4(ncol0 + j * 16 + lg * 4, sv4);
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
                             float v[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv4[r];
+                            for (int r = 0; r < 4; ++r) {
+                                if constexpr (DLN == 2) v[r] = drow[i].y * (acc[i][j][r] - drow[i].x * sv4[r]) + bv4[r];
+                                else v[r] = acc[i][j][r] + bv4[r];
+                            }
                             *reinterpret_cast<uint2*>(ws + (i * 16 + l15) * RBQ + (j * 16 + lg * 4) * 2) = pack4<T>(v);
                         }
                     }
@@ -811,11 +888,20 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float bvv = biasp ? biasp[min(ncol0 + j * 16 + l15, p.N - 1)] : 0.f;
+                        float svv = 0.f;
+                        if constexpr (DLN == 2) svv = p.dl_s[(int64_t)bz * p.dl_s_bs + min(ncol0 + j * 16 + l15, p.N - 1)];
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
                             float v[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bvv;
+                            for (int r = 0; r < 4; ++r) {
+                                if constexpr (DLN == 2) {
+                                    const float2 dr = dl_row(wm * TM * 16 + i * 16 + lg * 4 + r);
+                                    v[r] = dr.y * (acc[i][j][r] - dr.x * svv) + bvv;
+                                } else {
+                                    v[r] = acc[i][j][r] + bvv;
+                                }
+                            }
                             *reinterpret_cast<uint2*>(ws + (j * 16 + l15) * RBV + (i * 16 + lg * 4) * 2) = pack4<T>(v);
                         }
                     }
@@ -882,17 +968,28 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         static_assert(NW * TM * 16 * RBS <= NSTAGE * STAGE, "the output tile is staged in the (dead) K-loop stages");
         __syncthreads();
         unsigned char* ws = lds + wave * (TM * 16 * RBS);
-        float bvs[TN][4];
+        float bvs[TN][4], svs[(DLN == 2) ? TN : 1][4];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bias_j(j, bvs[j]);
+        if constexpr (DLN == 2) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dl_s4(nw + j * 16 + lg * 4, svs[j]);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             float v[TN][4];
             float mx = -INFINITY;
+            float2 dr = make_float2(0.f, 1.f);
+            if constexpr (DLN == 2) dr = dl_row(wm * TM * 16 + i * 16 + l15);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[j][r] = (acc[i][j][r] + bvs[j][r]) * 1.4426950408889634f; mx = fmaxf(mx, v[j][r]); }
+                for (int r = 0; r < 4; ++r) {
+                    float a = acc[i][j][r];
+                    if constexpr (DLN == 2) a = dr.y * (a - dr.x * svs[j][r]);
+                    v[j][r] = (a + bvs[j][r]) * 1.4426950408889634f;
+                    mx = fmaxf(mx, v[j][r]);
+                }
             mx = fmaxf(mx, lane_xor16(mx));
             mx = fmaxf(mx, lane_xor32(mx));
             float sum = 0.f;
@@ -937,15 +1034,24 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             if (FAST || p.vec16) {
                 __syncthreads();                                          // every wave is done reading the stages
                 unsigned char* ws = lds + wave * (TM * 16 * RBS);
+                float2 drow[(DLN == 2) ? TM : 1];
+                if constexpr (DLN == 2) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) drow[i] = dl_row(wm * TM * 16 + i * 16 + l15);
+                }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    float bv4[4];
+                    float bv4[4], sv4[4] = {0.f, 0.f, 0.f, 0.f};
                     bias_j(j, bv4);
+                    if constexpr (DLN == 2) dl_s4(n0 + wn * TN * 16 + j * 16 + lg * 4, sv4);
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         float v[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + bv4[r];
+                        for (int r = 0; r < 4; ++r) {
+                            if constexpr (DLN == 2) v[r] = drow[i].y * (acc[i][j][r] - drow[i].x * sv4[r]) + bv4[r];
+                            else v[r] = acc[i][j][r] + bv4[r];
+                        }
                         unsigned char* dst = ws + (i * 16 + l15) * RBS;
                         if constexpr (EPI == M5_EPI_SWIGLU) {
                             st o[2];
@@ -993,10 +1099,12 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         static_assert(!FAST || EPI == M5_EPI_F32 || PRELOAD_C, "FAST residual epilogue needs the preloaded C tile");
         if ((FAST || p.fast_c) && (EPI == M5_EPI_F32 || PRELOAD_C)) {
             float* Cf = reinterpret_cast<float*>(Cb);
+            float ps1[(DLN == 1) ? TM : 1], ps2[(DLN == 1) ? TM : 1];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = mw + i * 16 + l15;
                 float* rp = Cf + (int64_t)row * p.ldc;
+                if constexpr (DLN == 1) { ps1[i] = 0.f; ps2[i] = 0.f; }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int col = nw + j * 16 + lg * 4;
@@ -1006,6 +1114,36 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                         o.x = oldpre[i][j].x + o.x; o.y = oldpre[i][j].y + o.y; o.z = oldpre[i][j].z + o.z; o.w = oldpre[i][j].w + o.w;
                     }
                     if (row < p.M && col < p.N) *reinterpret_cast<float4*>(rp + col) = o;
+                    if constexpr (DLN == 1) {
+                        // the deferred LayerNorm's operand: the updated row minus its centre, in the operand type; row sums of it
+                        float xc[4] = {o.x - dl_cen[i], o.y - dl_cen[i], o.z - dl_cen[i], o.w - dl_cen[i]};
+                        if (col < p.N) {
+                            ps1[i] += (xc[0] + xc[1]) + (xc[2] + xc[3]);
+                            ps2[i] += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
+                            if (row < p.M)
+                                *reinterpret_cast<uint2*>(reinterpret_cast<st*>(p.dl_xt) + (int64_t)(bz * p.dl_rows_bs + row) * p.dl_ld_xt + col) = pack4<T>(xc);
+                        }
+                    }
+                }
+            }
+            if constexpr (DLN == 1) {
+                // row sums over this wave's columns (the 4 lane groups of a row), then over the WN waves of the row through LDS,
+                // in a fixed order; one {sum, sumsq} pair per (row, column tile) goes out
+                float2* xs = reinterpret_cast<float2*>(dl_lds);                   // [NW][TM * 16]
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float s1 = ps1[i], s2 = ps2[i];
+                    s1 += lane_xor16(s1); s1 += lane_xor32(s1);
+                    s2 += lane_xor16(s2); s2 += lane_xor32(s2);
+                    if (lg == 0) xs[wave * TM * 16 + i * 16 + l15] = make_float2(s1, s2);
+                }
+                __syncthreads();
+                for (int r = tid; r < BM; r += NW * 64) {
+                    const int wmr = r / (TM * 16), lr = r - wmr * (TM * 16);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WN; ++w) { const float2 v = xs[(wmr * WN + w) * TM * 16 + lr]; s1 += v.x; s2 += v.y; }
+                    if (m0 + r < p.M) reinterpret_cast<float2*>(p.dl_part)[(int64_t)(dl_row0 + r) * p.dl_np + tn] = make_float2(s1, s2);
                 }
             }
             if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
@@ -1129,9 +1267,45 @@ constexpr bool fast_ok(int E, int WM, int WN, int TM, int TN, int BKB, int NSTAG
     return false;
 }
 
-template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false>
-int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = false) {
+// Deferred-LayerNorm instantiations (DLN = 1: residual producer; DLN = 2: QKV / SwiGLU consumers) exist for the tilings the
+// engines' shapes use (DLNC: bit 0 = producer, bit 1 = consumers); anything else answers M5_ERR_UNSUPPORTED.
+template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, int DLNC = 0>
+int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = false, int dln = 0) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    if (dln) {
+        if (!fast) return M5_ERR_UNSUPPORTED;
+        p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
+        const int64_t nb = (int64_t)p.tilesM * p.tilesN * batch;
+        if (nb > 0x7fffffff) return M5_ERR_UNSUPPORTED;
+        p.nblk = (int)nb;
+        p.group_m = max(1, GROUP_M * 128 / BM);
+        const dim3 grid(p.nblk), blk(WM * WN * 64);
+        if constexpr ((DLNC & 1) != 0 && fast_ok(M5_EPI_RESIDUAL, WM, WN, TM, TN, BKB, NSTAGE)) {
+            if (dln == 1 && epi == M5_EPI_RESIDUAL) {
+                if (p.N % BN || p.dl_np != p.tilesN) return M5_ERR_UNSUPPORTED;       // one partial pair per (row, column tile)
+                hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_RESIDUAL, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, true, 1>), grid, blk, 0, s, p);
+                M5_CHECK_LAUNCH();
+                return M5_OK;
+            }
+        }
+        if constexpr ((DLNC & 2) != 0) {
+            if constexpr (fast_ok(M5_EPI_QKV, WM, WN, TM, TN, BKB, NSTAGE)) {
+                if (dln == 2 && epi == M5_EPI_QKV) {
+                    hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_QKV, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, true, 2>), grid, blk, 0, s, p);
+                    M5_CHECK_LAUNCH();
+                    return M5_OK;
+                }
+            }
+            if constexpr (fast_ok(M5_EPI_SWIGLU, WM, WN, TM, TN, BKB, NSTAGE)) {
+                if (dln == 2 && epi == M5_EPI_SWIGLU) {
+                    hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_SWIGLU, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, true, 2>), grid, blk, 0, s, p);
+                    M5_CHECK_LAUNCH();
+                    return M5_OK;
+                }
+            }
+        }
+        return M5_ERR_UNSUPPORTED;
+    }
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
     const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
     if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
@@ -1176,17 +1350,17 @@ static const CfgInfo kCfg[] = {
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 template <typename T>
-int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast) {
+int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast, int dln = 0) {
     switch (cfg) {
-        case 0: return launch16<T, 2, 2, 4, 4, 128, 2, 2>(epi, p, batch, s, fast);
-        case 1: return launch16<T, 2, 4, 6, 6, 128, 2, 1>(epi, p, batch, s, fast);
-        case 2: return launch16<T, 4, 3, 3, 4, 128, 3, 1>(epi, p, batch, s, fast);
-        case 3: return launch16<T, 2, 2, 3, 4, 128, 4, 1>(epi, p, batch, s, fast);
-        case 4: return launch16<T, 2, 4, 3, 2, 128, 2, 2>(epi, p, batch, s, fast);
-        case 5: return launch16<T, 4, 4, 3, 6, 128, 2, 1>(epi, p, batch, s, fast);
-        case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s, fast);
-        case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true>(epi, p, batch, s, fast);
-        case 8: return launch16<T, 2, 2, 3, 4, 128, 5, 1, true>(epi, p, batch, s, fast);
+        case 0: return launch16<T, 2, 2, 4, 4, 128, 2, 2, false, 3>(epi, p, batch, s, fast, dln);
+        case 1: return launch16<T, 2, 4, 6, 6, 128, 2, 1, false, 2>(epi, p, batch, s, fast, dln);
+        case 2: return launch16<T, 4, 3, 3, 4, 128, 3, 1, false, 2>(epi, p, batch, s, fast, dln);
+        case 3: return launch16<T, 2, 2, 3, 4, 128, 4, 1>(epi, p, batch, s, fast, dln);
+        case 4: return launch16<T, 2, 4, 3, 2, 128, 2, 2>(epi, p, batch, s, fast, dln);
+        case 5: return launch16<T, 4, 4, 3, 6, 128, 2, 1, false, 2>(epi, p, batch, s, fast, dln);
+        case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s, fast, dln);
+        case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true, 1>(epi, p, batch, s, fast, dln);
+        case 8: return launch16<T, 2, 2, 3, 4, 128, 5, 1, true>(epi, p, batch, s, fast, dln);
         default: return M5_ERR_ARG;
     }
 }
@@ -1194,12 +1368,14 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool
 // Cheapest configuration under: time = rounds x (fixed + K-steps x per-step time), rounds =
 // ceil(workgroups / (256 CUs x workgroups per CU)).  `span_div`: for QKV scatters with a V section
 // the per-wave column span must divide the section width.
-int pick_config(int M, int N, int K, int batch, int span_div, int epi) {
+int pick_config(int M, int N, int K, int batch, int span_div, int epi, int dln = 0) {
     int best = 0;
     float best_t = 1e30f;
     for (int c = 0; c < kNumCfg; ++c) {
         const CfgInfo& f = kCfg[c];
         if (f.only_epi == -2 || (f.only_epi >= 0 && f.only_epi != epi)) continue;
+        if (dln == 1 && c != 0 && c != 7) continue;                // deferred-LayerNorm producer: 128-column tiles with the preloaded C tile
+        if (dln == 2 && c != 0 && c != 1 && c != 2 && c != 5) continue;
         if (span_div && (span_div % (f.tn * 16))) continue;
         if (epi == M5_EPI_QKV && f.tn != 4) continue;       // one head per wave: only those tilings have the LDS-staged 16-byte scatter
         const int64_t wg = (int64_t)((M + f.bm - 1) / f.bm) * ((N + f.bn - 1) / f.bn) * batch;
@@ -1225,6 +1401,22 @@ int num_cus() {
 }
 
 }  // namespace
+
+// deferred-LayerNorm arguments -> kernel parameters (shared by m5_gemm16_dispatch and m5_xattn_scores); M5_OK or an error
+static int dl_fill(Gemm16Params& p, const M5DeferredLN* dl, int epi_kind /* 1 producer, 2 consumer */, int N) {
+    if (dl->mode != epi_kind) return M5_ERR_ARG;
+    if (!dl->part || dl->np <= 0 || dl->np > DL_MAX_NP || (dl->np & 1) || dl->rows_bs <= 0) return M5_ERR_UNSUPPORTED;
+    if (((uintptr_t)dl->part & 15)) return M5_ERR_ARG;
+    p.dl_part = dl->part; p.dl_np = dl->np; p.dl_cen_in = dl->cen_in; p.dl_cen_out = dl->cen_out; p.dl_rows_bs = dl->rows_bs;
+    if (epi_kind == 1) {
+        if (!dl->xt || (dl->ld_xt % 4) || ((uintptr_t)dl->xt & 7)) return M5_ERR_ARG;
+        p.dl_xt = (unsigned char*)dl->xt; p.dl_ld_xt = dl->ld_xt;
+    } else {
+        if (!dl->s || ((uintptr_t)dl->s & 15) || (dl->s_bs % 4) || dl->n_feat <= 0 || !(dl->eps > 0.f) || (N % 4) || N < 4) return M5_ERR_ARG;
+        p.dl_s = dl->s; p.dl_s_bs = dl->s_bs; p.dl_eps = dl->eps; p.dl_inv_n = 1.0f / (float)dl->n_feat;
+    }
+    return M5_OK;
+}
 
 // Q projection with the cross-attention it feeds fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
 // (M5_ERR_UNSUPPORTED otherwise; the caller then runs m5_gemm(EPI_QKV) + m5_attention): 16-bit operands, head_dim 64,
@@ -1262,8 +1454,8 @@ extern "C" int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const
 
 // Scores + per-head softmax of the absorbed cross-attention (include/mars5_hip.h, xattn_absorb.hip): P[b] = softmax_heads(
 // X[b] A[b]^T + c[b]) for `batch` sequences, head blocks of Lp = 48 or 64 columns (one per wave), 96-row tiles.
-extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
-                               void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, void* stream) {
+static int xattn_scores_impl(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                             void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl, void* stream) {
     if (!X || !A || !c || !P || M <= 0 || n_heads <= 0 || K <= 0 || batch <= 0) return M5_ERR_ARG;
     if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
     if ((Lp != 48 && Lp != 64) || (n_heads % 2) || (K % 64)) return M5_ERR_UNSUPPORTED;
@@ -1274,6 +1466,10 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
     p.M = M; p.N = n_heads * Lp; p.K = K;
     p.sc.n_heads = 1; p.sc.head_dim = 1; p.sc.rows_per_batch = 1;
     p.vec16 = 1; p.vec_c = 1;
+    if (dl) {
+        const int rc = dl_fill(p, dl, 2, n_heads * Lp);
+        if (rc != M5_OK) return rc;
+    }
     const int BN = 2 * Lp;
     // tile shape: 96 x 2Lp with 4 waves and 4 stages (one workgroup per CU), or -- tools build, M5_XATTN_CFG=1 / 2 -- 64 x 2Lp /
     // 128 x 2Lp with 8 waves, 2 stages and two workgroups per CU
@@ -1290,6 +1486,15 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
     const dim3 grid(p.nblk);
     hipStream_t s = (hipStream_t)stream;
     const bool xs_fast = (((uintptr_t)c & 15) == 0) && (sc_tab % 4 == 0) && m5_tool_env("M5_GEMM_FAST") == nullptr;
+    if (dl) {
+        if (!xs_fast || cfg != 0) return M5_ERR_UNSUPPORTED;
+#define M5_XSD(TT, TNv) hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, 2, 2, 3, TNv, 128, 4, 1, true, true, 2>), grid, dim3(256), 0, s, p)
+        if (dtype == M5_F16) { if (Lp == 48) M5_XSD(F16T, 3); else M5_XSD(F16T, 4); }
+        else { if (Lp == 48) M5_XSD(BF16T, 3); else M5_XSD(BF16T, 4); }
+#undef M5_XSD
+        M5_CHECK_LAUNCH();
+        return M5_OK;
+    }
 #define M5_XS(TT, WMv, TMv, TNv, NSv, OCv, PFv) do { if (xs_fast) hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv, PFv, true>), grid, dim3(WMv * 128), 0, s, p); \
         else hipLaunchKernelGGL((gemm16_kernel<TT, EPI_SOFTMAX_HEADS, WMv, 2, TMv, TNv, 128, NSv, OCv, PFv, false>), grid, dim3(WMv * 128), 0, s, p); } while (0)
 #ifdef M5_TOOLS
@@ -1303,6 +1508,20 @@ extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX
 #undef M5_XS
     M5_CHECK_LAUNCH();
     return M5_OK;
+}
+
+extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                               void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, void* stream) {
+    return xattn_scores_impl(dtype, X, ldx, sX, A, sA_tab, c, sc_tab, P, ldp, sP, M, n_heads, Lp, K, batch, nullptr, stream);
+}
+
+// ... with the LayerNorm that produced X deferred into the epilogue (M5DeferredLN, mode 2): X is the centred copy, A the
+// operands built from the gamma-folded query weights.
+extern "C" int m5_xattn_scores_dln(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                                   void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
+                                   void* stream) {
+    if (!dl) return M5_ERR_ARG;
+    return xattn_scores_impl(dtype, X, ldx, sX, A, sA_tab, c, sc_tab, P, ldp, sP, M, n_heads, Lp, K, batch, dl, stream);
 }
 
 // Residual GEMM with the following LayerNorm fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
@@ -1354,8 +1573,15 @@ extern "C" int m5_debug_gemm_clock(unsigned long long* buf) {   // diagnostics (
 // Called by m5_gemm (gemm.hip) for F16 / BF16 operands after argument validation.
 int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc, const int* sec_kind,
-                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s) {
+                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s, const M5DeferredLN* dl) {
     Gemm16Params p{};
+    int dln = 0;
+    if (dl) {
+        dln = (epi == M5_EPI_RESIDUAL) ? 1 : 2;
+        if (epi != M5_EPI_RESIDUAL && epi != M5_EPI_QKV && epi != M5_EPI_SWIGLU) return M5_ERR_UNSUPPORTED;
+        const int rc = dl_fill(p, dl, dln, N);
+        if (rc != M5_OK) return rc;
+    }
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = sA; p.sW = sW; p.sC = sC; p.sBias = sBias;
     p.M = M; p.N = N; p.K = K;
@@ -1400,7 +1626,7 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
         if (fe2 && fe2[0]) forced = atoi(fe2);
     }
     const int span_div = (sc && sc->vt) ? sc->n_heads * sc->head_dim : 0;
-    int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div, epi);
+    int cfg = forced >= 0 ? forced : pick_config(M, N, K, batch, span_div, epi, dln);
     if (cfg < 0 || cfg >= kNumCfg || (span_div && (span_div % (kCfg[cfg].tn * 16)))) cfg = 0;
     if (lda >= (1ll << 22) || ldw >= (1ll << 22)) return M5_ERR_UNSUPPORTED;       // tile-local DMA offsets (rows x leading dimension) are 32-bit
     const bool off32 = true;
@@ -1415,6 +1641,7 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     else if (epi == M5_EPI_QKV) fast = fast && p.qkv_stage;
     else fast = fast && p.vec16;
     if (const char* fk = m5_tool_env("M5_GEMM_FAST")) { if (atoi(fk) == 0) fast = false; }      // same-process A/B (tools build)
-    if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s, fast);
-    return launch_cfg<BF16T>(cfg, epi, p, batch, s, fast);
+    if (dln && !fast) return M5_ERR_UNSUPPORTED;
+    if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s, fast, dln);
+    return launch_cfg<BF16T>(cfg, epi, p, batch, s, fast, dln);
 }

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, int64_t 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int64_t ldx, const float* gamma, const float* beta,
                                                             float eps, typename T::storage* y, int64_t ldy, int M,
-                                                            int n_affine, int64_t affine_stride, int64_t y_affine_stride) {
+                                                            int n_affine, int64_t affine_stride, int64_t y_affine_stride, float* mean_out) {
     using st = typename T::storage;
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
 #pragma unroll
     for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mean = wave_sum(s) / (float)D;
+    if (mean_out && lane == 0 && blockIdx.y == 0) mean_out[row] = mean;      // m5_layernorm_mean: the row's centre for a deferred LayerNorm chain
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -102,14 +103,14 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
 
 template <typename T>
 bool launch_ln_vec(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y, int64_t ldy, int M,
-                   int D, int n_affine, int64_t affine_stride, int64_t y_affine_stride, hipStream_t s) {
+                   int D, int n_affine, int64_t affine_stride, int64_t y_affine_stride, hipStream_t s, float* mean_out = nullptr) {
     using st = typename T::storage;
     const int es = sizeof(st);
     if (D % 256 || (ldx % 4) || (ldy * es % (es == 4 ? 16 : 8)) || (affine_stride % 4) || (y_affine_stride * es % (es == 4 ? 16 : 8)) ||
         (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15))
         return false;
     dim3 grid((M + 3) / 4, n_affine);
-#define M5_LNV(NV) hipLaunchKernelGGL((layernorm_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (st*)y, ldy, M, n_affine, affine_stride, y_affine_stride)
+#define M5_LNV(NV) hipLaunchKernelGGL((layernorm_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (st*)y, ldy, M, n_affine, affine_stride, y_affine_stride, mean_out)
     switch (D / 256) {
         case 1: M5_LNV(1); break;
         case 2: M5_LNV(2); break;
@@ -383,6 +384,22 @@ extern "C" int m5_layernorm(int out_dtype, const float* x, int64_t ldx, const fl
         case M5_BF16: hipLaunchKernelGGL(layernorm_kernel<BF16T>, grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, (uint16_t*)y, ldy, M, D, n_affine, affine_stride, y_affine_stride); break;
         default: return M5_ERR_ARG;
     }
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+// m5_layernorm that also leaves each row's mean in mean_out[M] (fp32): the first centre of a deferred-LayerNorm chain
+// (M5DeferredLN).  Vector rows only (D % 256 == 0, 16-byte aligned operands), one affine.
+extern "C" int m5_layernorm_mean(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                 void* y, int64_t ldy, int M, int D, float* mean_out, void* stream) {
+    if (!x || !gamma || !beta || !y || !mean_out || M <= 0 || D <= 0) return M5_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    bool done = false;
+    if (out_dtype == M5_F32) done = launch_ln_vec<F32T>(x, ldx, gamma, beta, eps, y, ldy, M, D, 1, 0, 0, s, mean_out);
+    else if (out_dtype == M5_F16) done = launch_ln_vec<F16T>(x, ldx, gamma, beta, eps, y, ldy, M, D, 1, 0, 0, s, mean_out);
+    else if (out_dtype == M5_BF16) done = launch_ln_vec<BF16T>(x, ldx, gamma, beta, eps, y, ldy, M, D, 1, 0, 0, s, mean_out);
+    else return M5_ERR_ARG;
+    if (!done) return M5_ERR_UNSUPPORTED;
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

@@ -99,6 +99,18 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
                 cv = s * scale;
             }
             reinterpret_cast<float*>(ts[5])[h * Lp + j] = cv;
+            // deferred LayerNorm (M5DeferredLN): the scores GEMM also needs s[n] = sum_k A[n][k] = scale K[j] . (row sums of Wq_h)
+            // -- tab_layer[3] = fp32 [D] row sums of the (gamma-folded, operand-rounded) query weights, tab_seq[7] = s out
+            if (ts[7] && tl[3]) {
+                float sv = 0.f;
+                if (j < le) {
+                    const float* wsum = reinterpret_cast<const float*>(tl[3]);
+                    float a = 0.f;
+                    for (int d = 0; d < 64; ++d) a = fmaf(T::to_f32(mem[(int64_t)j * 64 + d]), wsum[h * 64 + d], a);
+                    sv = a * scale;
+                }
+                reinterpret_cast<float*>(ts[7])[h * Lp + j] = sv;
+            }
         }
     } else {
         // Bt[n][h Lp + j] = sum_d Wo[n][h 64 + d] V[j][d]

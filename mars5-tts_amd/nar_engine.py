@@ -30,8 +30,9 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .blocks import (LAYERNORM_EPS, AbsorbedCross, CrossMemory, SeqWorkspace, SpeakerEncoder, cross_attn_block, cross_memory_table,
-                     decoder_layer, encoder_layer, ff_block, make_cross_plan, pack_layer, residual_gemm, round_up, self_attn_block)
+from .blocks import (LAYERNORM_EPS, AbsorbedCross, CrossMemory, DeferredLN, SeqWorkspace, SpeakerEncoder, cross_attn_block,
+                     cross_memory_table, decoder_layer, decoder_layer_dln, encoder_layer, ff_block, make_cross_plan, pack_layer,
+                     plan_allows_dln, residual_gemm, round_up, self_attn_block)
 from .synth import NARShape
 from .tables import log_eps, nar_step_consts, reverse_schedule, sine_pe, timestep_inputs
 
@@ -338,14 +339,19 @@ class NARSession:
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
             # cross-attention path of this utterance: absorbed operands (rebuilt per step by one launch) or the reference order
-            self.plan = make_cross_plan(mdl.dec, [[mem] for mem in self.mems], D, dt, dev)
+            want_dln = DeferredLN.eligible(D, dt) and os.environ.get("M5_NAR_DLN", "1") != "0"      # A/B knob (tools/nar_step_bench.py)
+            self.plan = make_cross_plan(mdl.dec, [[mem] for mem in self.mems], D, dt, dev, dln=want_dln)
+            # LayerNorms deferred into the consuming GEMMs (blocks.decoder_layer_dln) when every utterance takes the absorbed path
+            self.dl = DeferredLN(self.ws, dev) if (want_dln and plan_allows_dln(self.plan)) else None
             self.xa = [cross_memory_table(mem, dev) if mem.vt is not None else None for mem in self.mems]   # opt-in fused q-proj + attention
             # Deep clone: the prompt frames (row_offset of S rows) are never sampled, so in the LAST decoder layer their
             # rows are needed only as keys / values.  That layer's queries, projections and feed-forward run on the
             # s_out generated rows of each branch, gathered into a compact workspace (exact: every kernel is row-wise).
             self.ws_l = None
             so_r = round_up(self.s_out, 64)
-            if self.row_offset > 0 and 4 * so_r <= 3 * Sr and os.environ.get("M5_NAR_LASTROWS", "1") != "0":
+            # (not with deferred LayerNorms: the compact layer would cost a row copy + three explicit LayerNorm launches to save
+            # 0.1 % of the step)
+            if self.dl is None and self.row_offset > 0 and 4 * so_r <= 3 * Sr and os.environ.get("M5_NAR_LASTROWS", "1") != "0":
                 self.ws_l = SeqWorkspace(nb, self.s_out, D, FF, dt, dev, row_pad=64, inside=over)
                 self.x_l = torch.zeros(nb, so_r, D, dtype=torch.float32, device=dev)
                 self.hf_l = torch.zeros(nb * so_r, D, dtype=torch.float32, device=dev)
@@ -382,11 +388,40 @@ class NARSession:
         ff_block(xl, lw, wl, lw.n3_w, lw.n3_b, st)
         ops.layernorm(xl, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf_l, stream=st)
 
+    def _enqueue_decoder_dln(self, st: int) -> None:
+        """The 16 decoder layers with deferred LayerNorms (blocks.decoder_layer_dln)."""
+        mdl, s = self.m, self.m.shape
+        S, Sr, nb, D = self.S, self.Sr, self.nb, s.dim
+        hx = self.h.view(nb * Sr, D)
+        nl = len(mdl.dec)
+        join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
+        skip0 = False
+        if self.ws0 is not None:
+            # layer 0's self-attention block once for both guidance branches (they enter the decoder with the same rows)
+            ops.chunked_embed(self.h[:1], mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
+                              rows=S, stream=st)
+            self_attn_block(hx[:Sr], mdl.dec[0], self.ws0, None, st)
+            ops.mark("torch copy: branch 0 -> branch 1", st)
+            with torch.cuda.stream(self.stream):
+                self.h[1].copy_(self.h[0])
+            skip0 = True
+        else:
+            ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
+                              rows=S, stream=st)
+        for l, lw in enumerate(mdl.dec):
+            decoder_layer_dln(hx, lw, self.ws, self.step_ptr, self.dl, self.plan, l, chain_in=l > 0, chain_out=l + 1 < nl, stream=st,
+                              before_cross=join if l == 0 else None, skip_self=(skip0 and l == 0))
+        join()
+
     def enqueue_forward(self, st: int) -> None:
         """x_t -> logits for both guidance branches (the loop body's GEMM/attention work)."""
         mdl, s = self.m, self.m.shape
         S, Sr, nb, D, Q = self.S, self.Sr, self.nb, s.dim, s.n_codebooks
         hx = self.h.view(nb * Sr, D)
+        if self.dl is not None:
+            self._enqueue_decoder_dln(st)
+            self._enqueue_heads(hx, st)
+            return
         layers = list(zip(mdl.dec, self.mems))
         self.ws.ln_tag, self.ws.ln_tag_step = 0, self.step_ptr      # fused LN launches: tag = f(step counter, call index)
         join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
@@ -419,6 +454,12 @@ class NARSession:
             normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l], plan=self.plan, layer=l,
                                    before_cross=join if l == 0 else None)
         join()
+        self._enqueue_heads(hx, st, compact)
+
+    def _enqueue_heads(self, hx: torch.Tensor, st: int, compact: bool = False) -> None:
+        """Final decoder LayerNorm + the 7 codebook heads on the generated rows of each branch."""
+        mdl, s = self.m, self.m.shape
+        Sr, nb, D, Q = self.Sr, self.nb, s.dim, s.n_codebooks
         so = self.s_out
         if compact:
             hf, hrow = self.hf_l, [b * self.ws_l.Sr for b in range(nb)]
@@ -575,7 +616,9 @@ class NARBatchSession:
             self.logits = torch.empty(self.R, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
-            self.plan = make_cross_plan(mdl.dec, [[sub.mems[l] for sub in self.subs] for l in range(len(mdl.dec))], D, dt, dev)
+            want_dln = DeferredLN.eligible(D, dt) and os.environ.get("M5_NAR_DLN", "1") != "0"
+            self.plan = make_cross_plan(mdl.dec, [[sub.mems[l] for sub in self.subs] for l in range(len(mdl.dec))], D, dt, dev, dln=want_dln)
+            self.dl = DeferredLN(self.ws, dev) if (want_dln and plan_allows_dln(self.plan)) else None
         self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
         self._ring = None
         self.graph = None
@@ -589,7 +632,12 @@ class NARBatchSession:
                               add_index=self.step_ptr, rows=sub.S, stream=st)
         hx = self.h.view(-1, D)
         join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
+        nl = len(mdl.dec)
         for l, lw in enumerate(mdl.dec):
+            if self.dl is not None:
+                decoder_layer_dln(hx, lw, self.ws, self.step_ptr, self.dl, self.plan, l, chain_in=l > 0, chain_out=l + 1 < nl, stream=st,
+                                  key_len=self.key_len, before_cross=join if l == 0 else None)
+                continue
             decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l,
                           before_cross=join if l == 0 else None)
         join()

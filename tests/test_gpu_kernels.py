@@ -177,6 +177,116 @@ def test_gemm_residual_layernorm_fused(dev, dt):
     os.environ.pop("M5_GEMM_LN", None)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M", [2816, 1408, 200, 16384])
+def test_deferred_layernorm_chain(dev, dt, M):
+    """M5DeferredLN: a residual GEMM (producer) leaves the centred 16-bit copy + per-tile row partials of the rows it updated,
+    and the three kinds of consumer -- QKV scatter (Q / K and the transposed V section), SwiGLU pair, per-head-softmax scores --
+    apply LayerNorm in their epilogues, against fp32 torch LayerNorm + Linear; rows with means far from 0 (the centre matters);
+    the consumers move the row centres to the row means; a second producer then centres by them.  Sizes: the NAR step's
+    M = 2816 / 1408, a ragged 200 and a batched group of 16,384 rows (other tile configurations, same arithmetic per row)."""
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.blocks import interleave_rows
+    torch.manual_seed(0)
+    D, K0, H, FF, Lp = 1024, 256, 16, 512, 48
+    eps = 4e-5
+    npart = D // 128
+    a0 = _q(_rand((M, K0), 1), dt)
+    w0 = _q(_rand((D, K0), 2, 2.0 / math.sqrt(K0)), dt)
+    b0 = _rand((D,), 3)
+    x0 = _rand((M, D), 4, 2.0) + 6.0 * _rand((M, 1), 5)                   # row means up to 6, spread ~1.2: |mean| / sigma up to ~5
+    cen0 = (x0.mean(dim=1) + 0.3 * _rand((M,), 6)).contiguous()           # a centre NEAR the mean, as the chain provides
+    x_ref = x0 + a0 @ w0.T + b0
+    # -- producer
+    x = x0.to(dev).clone()
+    xt = torch.zeros(M + 1, D, device=dev, dtype=dt)
+    part = torch.zeros(M, npart, 2, device=dev)
+    cen = cen0.to(dev).clone()
+    dlp = L.DeferredLN(mode=1, np=npart, xt=xt.data_ptr(), ld_xt=D, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=None, s=None, s_bs=0,
+                       eps=0.0, n_feat=D, rows_bs=M)
+    ops.gemm_dln(a0.to(dev, dt), w0.to(dev, dt), x, L.EPI_RESIDUAL, dlp, bias=b0.to(dev))
+    torch.cuda.synchronize()
+    assert _rel(x.cpu(), x_ref) < TOL[dt], _rel(x.cpu(), x_ref)
+    xc = x.cpu() - cen0[:, None]                                            # what the copy and the partials describe (the kernel's own x)
+    assert float((xt[:M].float().cpu() - xc).abs().max()) <= float(xc.abs().max()) * (2 ** -8 if dt == torch.bfloat16 else 2 ** -11) * 1.01
+    assert float(xt[M].float().abs().max()) == 0.0
+    ps = part.cpu()
+    xc_t = xc.view(M, npart, 128)
+    assert torch.allclose(ps[..., 0], xc_t.sum(-1), rtol=1e-4, atol=2e-3) and torch.allclose(ps[..., 1], (xc_t * xc_t).sum(-1), rtol=1e-4, atol=2e-3)
+    # -- consumers: LayerNorm(gamma, beta) + Linear folded the way blocks.fold_layer_dln folds
+    g, be = 1.0 + 0.3 * _rand((D,), 7), 0.2 * _rand((D,), 8)
+    ln = torch.nn.functional.layer_norm(x.cpu(), (D,), g, be, eps)
+
+    def fold(W, b):
+        Wf = (W * g[None, :]).to(dt)
+        return Wf.to(dev).contiguous(), (W @ be + (b if b is not None else 0.0)).to(dev).contiguous(), Wf.float().sum(1).to(dev).contiguous()
+
+    def consumer(s_vec, cen_out=True, rows_bs=M, s_bs=0):
+        return L.DeferredLN(mode=2, np=npart, xt=None, ld_xt=0, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=cen.data_ptr() if cen_out else None,
+                            s=s_vec.data_ptr(), s_bs=s_bs, eps=eps, n_feat=D, rows_bs=rows_bs)
+
+    tol = 1.2e-2 if dt == torch.bfloat16 else 2.5e-3                       # of max |ref|: one operand rounding + one weight rounding
+    # QKV scatter (whole sequence = one batch entry; S rows padded to 64 for the transposed V)
+    wq, bq = _rand((3 * D, D), 9, 1.5 / math.sqrt(D)), _rand((3 * D,), 10)
+    wqf, bqf, sq = fold(wq, bq)
+    ref = (ln @ wq.T + bq).view(M, 3, H, 64)
+    Sp = (M + 63) // 64 * 64
+    q = torch.zeros(1, H, M, 64, device=dev, dtype=dt)
+    k = torch.zeros(1, H, M, 64, device=dev, dtype=dt)
+    vt = torch.zeros(1, H, 64, Sp, device=dev, dtype=dt)
+    sc = L.QkvScatter(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), rows_per_batch=M, n_heads=H, head_dim=64, q_bs=H * M * 64, q_hs=M * 64, q_rs=64,
+                      k_bs=H * M * 64, k_hs=M * 64, k_rs=64, vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp)
+    ops.gemm_dln(xt[:M], wqf, None, L.EPI_QKV, consumer(sq, cen_out=False), bias=bqf, scatter=sc)
+    torch.cuda.synchronize()
+    assert _rel(q[0].float().cpu(), ref[:, 0].permute(1, 0, 2)) < tol
+    assert _rel(k[0].float().cpu(), ref[:, 1].permute(1, 0, 2)) < tol
+    assert _rel(vt[0].float().cpu()[..., :M], ref[:, 2].permute(1, 2, 0)) < tol
+    assert torch.equal(cen.cpu(), cen0)                                     # cen_out = NULL: centres untouched
+    # SwiGLU pair (+ the centres move to the row means)
+    w1, w3 = _rand((FF, D), 11, 1.5 / math.sqrt(D)), _rand((FF, D), 12, 1.5 / math.sqrt(D))
+    wsf, bsf, ss = fold(interleave_rows(w1, w3), None)
+    hff = torch.zeros(M, FF, device=dev, dtype=dt)
+    ops.gemm_dln(xt[:M], wsf, hff, L.EPI_SWIGLU, consumer(ss), bias=bsf)
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.silu(ln @ w1.T) * (ln @ w3.T)
+    assert _rel(hff.float().cpu(), ref) < 2 * tol
+    assert float((cen.cpu() - x.cpu().mean(dim=1)).abs().max()) < 1e-3
+    # scores with per-head softmax: two sequences of M / 2 rows with their own A / c / s tables (batched launch, rows_bs)
+    if M % 128 == 0:
+        Ms = M // 2
+        N = H * Lp
+        A = _rand((2, N, D), 13, 2.0 / math.sqrt(D))
+        c = _rand((2, N), 14)
+        c.view(2, H, Lp)[:, :, 40:] = -1e30                                 # padded keys
+        Af = (A * g[None, None, :]).to(dt)
+        cf = (torch.einsum("bnk,k->bn", A, be) + c).to(dev).contiguous()
+        sA = Af.float().sum(-1).to(dev).contiguous()
+        P = torch.zeros(M, N, device=dev, dtype=dt)
+        cen.copy_(cen0.to(dev))
+        ops.xattn_scores_dln(xt[:M], Ms * D, Af.to(dev).contiguous(), cf, P, Ms * N, Ms, H, Lp, 2, consumer(sA, rows_bs=Ms, s_bs=N))
+        torch.cuda.synchronize()
+        sc_ref = torch.stack([ln[b * Ms:(b + 1) * Ms] @ A[b].T + c[b] for b in range(2)]).view(2, Ms, H, Lp)
+        p_ref = torch.softmax(sc_ref, dim=-1).reshape(M, N)
+        assert float((P.float().cpu() - p_ref).abs().max()) < (2.5e-2 if dt == torch.bfloat16 else 5e-3)
+        assert float(P.float().cpu().view(M, H, Lp)[:, :, 40:].abs().max()) == 0.0
+        assert float((cen.cpu() - x.cpu().mean(dim=1)).abs().max()) < 1e-3
+    # -- a second producer, batched like the P.B GEMM (two sequences, rows_bs), centres by the means the consumer left
+    if M % 128 == 0:
+        Ms = M // 2
+        a1 = _q(_rand((M, K0), 15), dt)
+        w1b = _q(_rand((2, D, K0), 16, 2.0 / math.sqrt(K0)), dt)
+        x2_ref = x.cpu() + torch.cat([a1[b * Ms:(b + 1) * Ms] @ w1b[b].T for b in range(2)]) + b0
+        dlp2 = L.DeferredLN(mode=1, np=npart, xt=xt.data_ptr(), ld_xt=D, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=None, s=None, s_bs=0,
+                            eps=0.0, n_feat=D, rows_bs=Ms)
+        cen_now = cen.cpu().clone()
+        ops.gemm_dln(a1.to(dev, dt), w1b.to(dev, dt)[0], x, L.EPI_RESIDUAL, dlp2, bias=b0.to(dev), M=Ms, batch=2, sA=Ms * K0, sW=D * K0, sC=Ms * D, sBias=0)
+        torch.cuda.synchronize()
+        assert _rel(x.cpu(), x2_ref) < TOL[dt]
+        xc2 = (x.cpu() - cen_now[:, None]).view(M, npart, 128)
+        assert torch.allclose(part.cpu()[..., 0], xc2.sum(-1), rtol=1e-4, atol=2e-3)
+        assert float((xt[:M].float().cpu() - xc2.view(M, D)).abs().max()) <= float(xc2.abs().max()) * (2 ** -8 if dt == torch.bfloat16 else 2 ** -11) * 1.01
+
+
 @pytest.mark.parametrize("dt", DTS)
 def test_gemm_swiglu_and_qkv(dev, dt):
     from mars5_tts_amd import _lib as L, ops
