@@ -454,7 +454,8 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     st = sess.stream.cuda_stream
     es = 2 if dtype_name != "f32" else 4
     names_epi = {L.EPI_F32: "F32", L.EPI_RESIDUAL: "RESIDUAL", L.EPI_SWIGLU: "SWIGLU", L.EPI_QKV: "QKV", L.EPI_DT: "DT", L.EPI_SILU_DT: "SILU"}
-    orig = {k: getattr(ops, k) for k in ("gemm", "attention", "layernorm", "xattn_scores", "xattn_absorb", "chunked_embed")}
+    orig = {k: getattr(ops, k) for k in ("gemm", "gemm_dln", "attention", "layernorm", "layernorm_mean", "xattn_scores", "xattn_scores_dln",
+                                         "xattn_absorb", "chunked_embed")}
 
     slots = torch.zeros(2048, dtype=torch.int64, device=m.device)
     labels = []
@@ -481,6 +482,17 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
 
     orig["mark"] = ops.mark
     ops.gemm = timed(orig["gemm"], gemm_label, gemm_flops, gemm_bytes)
+    # deferred-LayerNorm forms (same kernel names as rocprofv3 prints them: the DLN template argument is part of the instantiation, the
+    # epilogue class is what groups them here)
+    ops.gemm_dln = timed(orig["gemm_dln"], lambda a, w_, out, epi, dl, **kw: gemm_label(a, w_, out, epi, **kw) + (" +dln-producer" if dl.mode == 1 else " +dln-consumer"),
+                         lambda a, w_, out, epi, dl, **kw: gemm_flops(a, w_, out, epi, **kw),
+                         lambda a, w_, out, epi, dl, **kw: gemm_bytes(a, w_, out, epi, **kw) + (float((kw.get("M") or a.shape[-2]) * kw.get("batch", 1) * w_.shape[-2] * es) if dl.mode == 1 else 0.0))
+    ops.layernorm_mean = timed(orig["layernorm_mean"], lambda x_, g_, b_, eps, out, mo, **kw: f"layernorm_vec_kernel D={x_.shape[-1]} affine=1 +mean",
+                               lambda *a, **kw: 0.0,
+                               lambda x_, g_, b_, eps, out, mo, **kw: float((kw.get("M") or x_.shape[0]) * x_.shape[-1] * (4 + out.element_size())))
+    ops.xattn_scores_dln = timed(orig["xattn_scores_dln"], lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: f"gemm16_kernel<EPI_SOFTMAX_HEADS> M={M * batch} N={H * Lp} K={x_.shape[-1]} +dln-consumer",
+                                 lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: 2.0 * M * batch * H * Lp * x_.shape[-1],
+                                 lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: float(M * batch * (x_.shape[-1] + H * Lp) * es + batch * H * Lp * x_.shape[-1] * es))
     ops.attention = timed(orig["attention"], lambda dt, a_, **kw: f"attn16_kernel Sq={a_.Sq} Sk={a_.Sk}",
                           lambda dt, a_, **kw: 4.0 * a_.B * a_.H * a_.Sq * a_.Sk * 64,
                           lambda dt, a_, **kw: float(a_.B * a_.H * (2 * a_.Sq + 2 * a_.Sk) * 64 * es))

@@ -167,8 +167,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     constexpr int STAGE = (BM + BN) * BKB;
     // DLN = 2 (consumer): behind the stages, the tile's BM x np partial pairs (LDS-DMA'd in front of the operand stages) and
     // the per-row {d, r} derived from them.  DLN = 1 (producer): the per-wave row sums that the WN waves of a row exchange.
-    constexpr int DL_PART = (DLN == 2) ? BM * DL_MAX_NP * 8 : 0;
-    constexpr int DL_BYTES = (DLN == 2) ? DL_PART + BM * 8 : ((DLN == 1) ? NW * TM * 16 * 8 : 0);
+    constexpr int DL_PART = (DLN == 2) ? BM * DL_MAX_NP * 8 : 0;     // consumer: [BM][np] pairs ({d, r} of a row later overwrite its first pair)
+    constexpr int DL_BYTES = (DLN == 2) ? DL_PART + 2 * BN * 4 : ((DLN == 1) ? NW * TM * 16 * 8 : 0);   // + bias' and s of the tile's columns
     static_assert(DLN == 0 || FAST, "deferred LayerNorm: FAST instantiations only");
     static_assert(DLN != 1 || EPI == M5_EPI_RESIDUAL, "deferred LayerNorm producer = residual epilogue");
     static_assert(DLN != 2 || EPI == M5_EPI_QKV || EPI == M5_EPI_SWIGLU || EPI == EPI_SOFTMAX_HEADS, "deferred LayerNorm consumers");
@@ -410,7 +410,10 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     // (hipcc cannot sink these loads below the loop: the DMA statements inside it clobber "memory")
     // bias of column tile j as the epilogues consume it: the hoisted registers, or -- no budget for them -- loaded on the spot
     auto bias_j = [&](int j, float (&b4)[4]) {
-        if constexpr (HOIST_B) {
+        if constexpr (DLN == 2) {            // the tile's bias' columns were LDS-DMA'd in front of the operand stages
+            const float4 t4 = *reinterpret_cast<const float4*>(dl_lds + DL_PART + (wn * TN * 16 + j * 16 + lg * 4) * 4);
+            b4[0] = t4.x; b4[1] = t4.y; b4[2] = t4.z; b4[3] = t4.w;
+        } else if constexpr (HOIST_B) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) b4[r] = bvh[j][r];
         } else {
@@ -444,6 +447,24 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 const uint32_t off = min((uint32_t)q * 1024 + (uint32_t)lane * 16, total - 16);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                              :: "v"(off), "s"(pb), "s"(lds_base + NSTAGE * STAGE + q * 1024) : "memory");
+            }
+        }
+        // ... and the tile's BN columns of bias' and of s (row sums of the folded weights): the epilogue reads them from LDS
+        // instead of opening with a dependent global round trip.  Columns past N repeat the last four.
+        constexpr int NPB = (BN * 4 + 1023) / 1024;                     // pieces per vector
+        const unsigned char* vb[2] = {uniform_ptr(reinterpret_cast<const unsigned char*>(p.bias + (int64_t)bz * p.sBias)),
+                                      uniform_ptr(reinterpret_cast<const unsigned char*>(p.dl_s + (int64_t)bz * p.dl_s_bs))};
+#pragma unroll
+        for (int q0 = 0; q0 < 2 * NPB; q0 += NW) {
+            const int q = q0 + wave;                                   // wave-uniform: vector q / NPB, piece q % NPB
+            if (q < 2 * NPB) {
+                const int which = q / NPB, pq = q - which * NPB;
+                const uint32_t o = (uint32_t)pq * 1024 + (uint32_t)lane * 16;
+                if (o < BN * 4) {
+                    const uint32_t off = (uint32_t)min(n0 + (int)(o >> 2), p.N - 4) * 4;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                                 :: "v"(off), "s"(which ? vb[1] : vb[0]), "s"(lds_base + NSTAGE * STAGE + DL_PART + which * BN * 4 + pq * 1024) : "memory");
+                }
             }
         }
     }
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         // MFMA would wait for 11.5 MB of cold fp32 residual).  These loads are younger than K-step 0, so the counted wait
         // below over-waits a little on the first K-step only -- never under-waits.
         preload_c();
-        if constexpr (HOIST_B) load_bias();
+        if constexpr (HOIST_B && DLN != 2) load_bias();
         wait_younger<NSTAGE - 1, JN>(min(NSTAGE - 1, nk - 1), true);             // K-step 0 has landed
         __syncthreads();
         uint4 af0[TM], bf0[TN], af1[TM], bf1[TN];
@@ -552,7 +573,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         mfma_block(af1, bf1);
     } else {
     preload_c();
-    if constexpr (HOIST_B) load_bias();
+    if constexpr (HOIST_B && DLN != 2) load_bias();
 #pragma unroll
     for (int sgi = 0; sgi < NSTAGE - 1; ++sgi)
         if (sgi < nk) stage_load(sgi, sgi);
@@ -590,22 +611,22 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         // per row {d = mean(x - cen), r = 1 / sqrt(var + eps)} from the np partial pairs (summed in a fixed order: every column
         // tile of a row derives the same two numbers); column tile 0 leaves the row's new centre for the next producer.
         // (visible to the epilogues behind their __syncthreads(); the partials are older than every K-step's barrier)
-        float2* rs = reinterpret_cast<float2*>(dl_lds + DL_PART);
         const int np = p.dl_np;
         for (int r = tid; r < BM; r += NW * 64) {
-            const float2* pr = reinterpret_cast<const float2*>(dl_lds + r * np * 8);
+            float2* pr = reinterpret_cast<float2*>(dl_lds + r * np * 8);
             float s1 = 0.f, s2 = 0.f;
             for (int n = 0; n < np; ++n) { const float2 v = pr[n]; s1 += v.x; s2 += v.y; }
             const float d = s1 * p.dl_inv_n;
             const float var = fmaxf(s2 * p.dl_inv_n - d * d, 0.f);
-            rs[r] = make_float2(d, 1.0f / sqrtf(var + p.dl_eps));
+            pr[0] = make_float2(d, 1.0f / sqrtf(var + p.dl_eps));       // in place: this thread is the row's only reader
             if (tn == 0 && p.dl_cen_out && m0 + r < p.M) p.dl_cen_out[dl_row0 + r] = (p.dl_cen_in ? p.dl_cen_in[dl_row0 + r] : 0.f) + d;
         }
     }
-    // {d, r} of local row lr / the folded weights' row sums of 4 consecutive output columns (both read behind the epilogue's barrier)
-    auto dl_row = [&](int lr) -> float2 { return reinterpret_cast<const float2*>(dl_lds + DL_PART)[lr]; };
-    auto dl_s4 = [&](int col, float (&s4)[4]) {
-        const float4 t4 = *reinterpret_cast<const float4*>(p.dl_s + (int64_t)bz * p.dl_s_bs + min(col, p.N - 4));
+    // {d, r} of local row lr / the folded weights' row sums of the tile's columns lcol .. lcol + 3 (tile-local column; both in
+    // LDS, read behind the epilogue's barrier)
+    auto dl_row = [&](int lr) -> float2 { return *reinterpret_cast<const float2*>(dl_lds + lr * p.dl_np * 8); };
+    auto dl_s4 = [&](int lcol, float (&s4)[4]) {
+        const float4 t4 = *reinterpret_cast<const float4*>(dl_lds + DL_PART + BN * 4 + lcol * 4);
         s4[0] = t4.x; s4[1] = t4.y; s4[2] = t4.z; s4[3] = t4.w;
     };
     // ---- epilogue.  swapped layout: acc[i][j][r] = C[mw + 16 i + l15][nw + 16 j + 4 lg + r]
@@ -859,7 +880,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     for (int j = 0; j < 4; ++j) {
                         float bv4[4], sv4[4] = {0.f, 0.f, 0.f, 0.f};
                         bias_j(j, bv4);
-                        if constexpr (DLN == 2) dl_s4(ncol0 + j * 16 + lg * 4, sv4);
+                        if constexpr (DLN == 2) dl_s4(wn * 64 + j * 16 + lg * 4, sv4);
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
                             float v[4];
@@ -887,9 +908,13 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     // unswapped: acc[i][j][r] = C[mrow0 + 16 i + 4 lg + r][ncol0 + 16 j + l15]
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float bvv = biasp ? biasp[min(ncol0 + j * 16 + l15, p.N - 1)] : 0.f;
-                        float svv = 0.f;
-                        if constexpr (DLN == 2) svv = p.dl_s[(int64_t)bz * p.dl_s_bs + min(ncol0 + j * 16 + l15, p.N - 1)];
+                        float bvv, svv = 0.f;
+                        if constexpr (DLN == 2) {
+                            bvv = reinterpret_cast<const float*>(dl_lds + DL_PART)[wn * 64 + j * 16 + l15];
+                            svv = reinterpret_cast<const float*>(dl_lds + DL_PART + BN * 4)[wn * 64 + j * 16 + l15];
+                        } else {
+                            bvv = biasp ? biasp[min(ncol0 + j * 16 + l15, p.N - 1)] : 0.f;
+                        }
 #pragma unroll
                         for (int i = 0; i < TM; ++i) {
                             float v[4];
@@ -973,7 +998,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         for (int j = 0; j < TN; ++j) bias_j(j, bvs[j]);
         if constexpr (DLN == 2) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) dl_s4(nw + j * 16 + lg * 4, svs[j]);
+            for (int j = 0; j < TN; ++j) dl_s4(wn * TN * 16 + j * 16 + lg * 4, svs[j]);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -1043,7 +1068,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 for (int j = 0; j < TN; ++j) {
                     float bv4[4], sv4[4] = {0.f, 0.f, 0.f, 0.f};
                     bias_j(j, bv4);
-                    if constexpr (DLN == 2) dl_s4(n0 + wn * TN * 16 + j * 16 + lg * 4, sv4);
+                    if constexpr (DLN == 2) dl_s4(wn * TN * 16 + j * 16 + lg * 4, sv4);
 #pragma unroll
                     for (int i = 0; i < TM; ++i) {
                         float v[4];
@@ -1115,18 +1140,31 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     }
                     if (row < p.M && col < p.N) *reinterpret_cast<float4*>(rp + col) = o;
                     if constexpr (DLN == 1) {
-                        // the deferred LayerNorm's operand: the updated row minus its centre, in the operand type; row sums of it
+                        // the deferred LayerNorm's operand: the updated row minus its centre, in the operand type (kept in the
+                        // accumulator registers until the staged store below); row sums of it
                         float xc[4] = {o.x - dl_cen[i], o.y - dl_cen[i], o.z - dl_cen[i], o.w - dl_cen[i]};
                         if (col < p.N) {
                             ps1[i] += (xc[0] + xc[1]) + (xc[2] + xc[3]);
                             ps2[i] += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
-                            if (row < p.M)
-                                *reinterpret_cast<uint2*>(reinterpret_cast<st*>(p.dl_xt) + (int64_t)(bz * p.dl_rows_bs + row) * p.dl_ld_xt + col) = pack4<T>(xc);
                         }
+                        acc[i][j] = f4_t{xc[0], xc[1], xc[2], xc[3]};
                     }
                 }
             }
             if constexpr (DLN == 1) {
+                // the centred copy leaves through the (dead) stage buffers as whole 16-byte row chunks (straight from the
+                // accumulator layout a store instruction writes 16 rows x 32 bytes: measured +4 us per launch)
+                constexpr int RBX = TN * 32 + 16;                                 // padded LDS row: TN*16 columns of 2 bytes
+                static_assert(NW * TM * 16 * RBX <= NSTAGE * STAGE, "the centred copy is staged in the K-loop stages");
+                __syncthreads();                                                  // every wave is done reading the stages
+                unsigned char* wsx = lds + wave * (TM * 16 * RBX);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float xv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        *reinterpret_cast<uint2*>(wsx + (i * 16 + l15) * RBX + (j * 16 + lg * 4) * 2) = pack4<T>(xv);
+                    }
                 // row sums over this wave's columns (the 4 lane groups of a row), then over the WN waves of the row through LDS,
                 // in a fixed order; one {sum, sumsq} pair per (row, column tile) goes out
                 float2* xs = reinterpret_cast<float2*>(dl_lds);                   // [NW][TM * 16]
@@ -1138,6 +1176,18 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     if (lg == 0) xs[wave * TM * 16 + i * 16 + l15] = make_float2(s1, s2);
                 }
                 __syncthreads();
+                {
+                    constexpr int CPRX = TN * 2, RPPX = 64 / CPRX;               // 16-byte chunks per row, rows per pass
+                    const int rr = lane / CPRX, ch = lane - rr * CPRX;
+                    st* Xt = reinterpret_cast<st*>(p.dl_xt) + (int64_t)bz * p.dl_rows_bs * p.dl_ld_xt;
+                    const int ocol = nw + ch * 8;
+#pragma unroll
+                    for (int pass = 0; pass < (TM * 16 + RPPX - 1) / RPPX; ++pass) {
+                        const int r = pass * RPPX + rr;
+                        if (rr < RPPX && r < TM * 16 && mw + r < p.M && ocol < p.N)
+                            *reinterpret_cast<uint4*>(Xt + (int64_t)(mw + r) * p.dl_ld_xt + ocol) = *reinterpret_cast<const uint4*>(wsx + r * RBX + ch * 16);
+                    }
+                }
                 for (int r = tid; r < BM; r += NW * 64) {
                     const int wmr = r / (TM * 16), lr = r - wmr * (TM * 16);
                     float s1 = 0.f, s2 = 0.f;
@@ -1409,10 +1459,11 @@ static int dl_fill(Gemm16Params& p, const M5DeferredLN* dl, int epi_kind /* 1 pr
     if (((uintptr_t)dl->part & 15)) return M5_ERR_ARG;
     p.dl_part = dl->part; p.dl_np = dl->np; p.dl_cen_in = dl->cen_in; p.dl_cen_out = dl->cen_out; p.dl_rows_bs = dl->rows_bs;
     if (epi_kind == 1) {
-        if (!dl->xt || (dl->ld_xt % 4) || ((uintptr_t)dl->xt & 7)) return M5_ERR_ARG;
+        if (!dl->xt || (dl->ld_xt % 8) || ((uintptr_t)dl->xt & 15)) return M5_ERR_ARG;      // 16-byte row chunks
         p.dl_xt = (unsigned char*)dl->xt; p.dl_ld_xt = dl->ld_xt;
     } else {
         if (!dl->s || ((uintptr_t)dl->s & 15) || (dl->s_bs % 4) || dl->n_feat <= 0 || !(dl->eps > 0.f) || (N % 4) || N < 4) return M5_ERR_ARG;
+        if (!p.bias || ((uintptr_t)p.bias & 15) || (p.sBias % 4)) return M5_ERR_ARG;           // b' = b + W beta always exists; it travels by LDS-DMA
         p.dl_s = dl->s; p.dl_s_bs = dl->s_bs; p.dl_eps = dl->eps; p.dl_inv_n = 1.0f / (float)dl->n_feat;
     }
     return M5_OK;
@@ -1575,6 +1626,8 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
                        void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc, const int* sec_kind,
                        int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s, const M5DeferredLN* dl) {
     Gemm16Params p{};
+    p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
+    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = sA; p.sW = sW; p.sC = sC; p.sBias = sBias;
     int dln = 0;
     if (dl) {
         dln = (epi == M5_EPI_RESIDUAL) ? 1 : 2;
@@ -1582,8 +1635,6 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
         const int rc = dl_fill(p, dl, dln, N);
         if (rc != M5_OK) return rc;
     }
-    p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
-    p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = sA; p.sW = sW; p.sC = sC; p.sBias = sBias;
     p.M = M; p.N = N; p.K = K;
     p.dbg = g_gemm_dbg;
     const bool f32out = (epi == M5_EPI_F32 || epi == M5_EPI_RESIDUAL);
