@@ -156,10 +156,11 @@ M5_API int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, co
  * so the LayerNorm launch, its read of x and the normalised copy disappear:
  *  - mode 1, the PRODUCER: m5_gemm_dln(M5_EPI_RESIDUAL) updates x in place as m5_gemm does and also writes xt (row stride
  *    ld_xt) and, per row and 128-column tile tn, part[row][tn] = {sum, sum of squares} of (x_new - cen_in[row]) over the tile
- *    (np = N / 128, even, <= 8; cen_in NULL = 0).
+ *    (np = N / 128, even, <= 8).  The row's centre is cen_in[row] + delta[row] (NULL = 0) and is left in cen_out[row].
  *  - mode 2, a CONSUMER: m5_gemm_dln(M5_EPI_QKV / M5_EPI_SWIGLU) and m5_xattn_scores_dln take A = xt and W = W', bias = b',
  *    derive (d, r) per row from the np partial pairs (n_feat = D, eps) and apply the formula in their epilogues; the column
- *    tile 0 workgroups also write cen_out[row] = cen_in[row] + d (= the row's mean: the next producer's centre).
+ *    tile 0 workgroups also write delta[row] = d (centre + d = the row's mean: the next producer's centre; a consumer
+ *    never READS a centre, so nothing in it waits on another launch's small stores).
  * Rows of xt / part / cen are numbered bz * rows_bs + m for batched launches.  m5_layernorm_mean starts a chain (an explicit
  * LayerNorm that also leaves the row means).  16-bit operands only; M5_ERR_UNSUPPORTED for shapes / tilings without the
  * vector epilogues (N % 128 for a producer).  Exact in exact arithmetic; in 16 bits the rounding moves from LN(x) to x - cen and
@@ -169,8 +170,9 @@ typedef struct {
     int32_t np;               /* partial pairs per row                                            */
     void* xt; int64_t ld_xt;  /* producer: centred operand-type copy of the updated rows          */
     float* part;              /* [rows][np][2] fp32                                               */
-    const float* cen_in;      /* [rows] fp32 or NULL                                              */
-    float* cen_out;           /* consumer: [rows] fp32 or NULL                                    */
+    const float* cen_in;      /* producer: [rows] fp32 or NULL (0)                                */
+    float* cen_out;           /* producer: [rows] fp32 or NULL: the centre it used (another buffer than cen_in) */
+    float* delta;             /* [rows] fp32 or NULL: consumer writes d, the next producer reads it */
     const float* s;           /* consumer: [N] fp32 row sums of W'                                */
     int64_t s_bs;             /* consumer: batch stride of s (elements)                           */
     float eps;                /* consumer                                                         */

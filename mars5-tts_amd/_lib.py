@@ -119,7 +119,7 @@ class NarSampleArgs(C.Structure):
 
 class DeferredLN(C.Structure):
     """M5DeferredLN (include/mars5_hip.h): a LayerNorm deferred into the GEMM that consumes it."""
-    _fields_ = [("mode", i32), ("np", i32), ("xt", vp), ("ld_xt", i64), ("part", vp), ("cen_in", vp), ("cen_out", vp),
+    _fields_ = [("mode", i32), ("np", i32), ("xt", vp), ("ld_xt", i64), ("part", vp), ("cen_in", vp), ("cen_out", vp), ("delta", vp),
                 ("s", vp), ("s_bs", i64), ("eps", f32), ("n_feat", i32), ("rows_bs", i32)]
 
 

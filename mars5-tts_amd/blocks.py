@@ -103,26 +103,44 @@ class DeferredLN:
         self.np = ws.D // 128
         self.D = ws.D
         self.part = torch.zeros(ws.M, self.np, 2, dtype=torch.float32, device=dev)
-        self.cen = torch.zeros(ws.M, dtype=torch.float32, device=dev)
+        # A producer centres its rows by cen[k] + delta (the previous producer's centre + the d the consumer in between
+        # measured = the row's mean at that point) and leaves that centre in cen[1 - k]: two buffers, because the other column
+        # tiles of the same launch are still reading cen[k].  `start` = the explicit LayerNorm that begins a chain wrote the
+        # row means into cen[0]; the first producer after it takes them as they are.
+        self.cen = torch.zeros(2, ws.M, dtype=torch.float32, device=dev)
+        self.delta = torch.zeros(ws.M, dtype=torch.float32, device=dev)
+        self.k = 0
+        self.fresh = True
+
+    def start(self) -> torch.Tensor:
+        """The buffer the chain-starting LayerNorm (ops.layernorm_mean) writes the row means to."""
+        self.k, self.fresh = 0, True
+        return self.cen[0]
 
     @staticmethod
     def eligible(D: int, dt: torch.dtype) -> bool:
         return dt != torch.float32 and D % 256 == 0 and D // 128 <= 8
 
-    def producer(self, ws: "SeqWorkspace", r0: int = 0, rows_bs: Optional[int] = None) -> L.DeferredLN:
-        """The residual GEMM over rows [r0, ...) also writes the centred copy (ws.xn) and the partials; centre = self.cen."""
+    def producer(self, ws: "SeqWorkspace", r0: int = 0, rows_bs: Optional[int] = None, advance: bool = True) -> L.DeferredLN:
+        """The residual GEMM over rows [r0, ...) also writes the centred copy (ws.xn) and the partials.  `advance`: this is the
+        last (or only) launch of the producing step -- a step split over several launches (one per run of utterances) passes
+        False for all but the last, so that every launch of the step reads and writes the same pair of buffers."""
         es = ws.xn.element_size()
+        k, fresh = self.k, self.fresh
+        if advance:
+            self.k, self.fresh = 1 - k, False
         return L.DeferredLN(mode=1, np=self.np, xt=ws.xn.data_ptr() + r0 * ws.D * es, ld_xt=ws.D, part=self.part.data_ptr() + r0 * self.np * 8,
-                            cen_in=self.cen.data_ptr() + r0 * 4, cen_out=None, s=None, s_bs=0, eps=0.0, n_feat=self.D,
+                            cen_in=self.cen[k].data_ptr() + r0 * 4, cen_out=self.cen[1 - k].data_ptr() + r0 * 4,
+                            delta=None if fresh else self.delta.data_ptr() + r0 * 4, s=None, s_bs=0, eps=0.0, n_feat=self.D,
                             rows_bs=rows_bs if rows_bs is not None else ws.M)
 
     def consumer(self, s: torch.Tensor, r0: int = 0, rows_bs: Optional[int] = None, s_bs: int = 0, M: Optional[int] = None) -> L.DeferredLN:
         """A GEMM whose A operand is the centred copy applies LayerNorm in its epilogue (s: row sums of the folded weights) and
         moves the row centres to the rows' means."""
         assert s.dtype == torch.float32 and s.is_contiguous()
-        cen = self.cen.data_ptr() + r0 * 4
-        return L.DeferredLN(mode=2, np=self.np, xt=None, ld_xt=0, part=self.part.data_ptr() + r0 * self.np * 8, cen_in=cen, cen_out=cen,
-                            s=s.data_ptr(), s_bs=s_bs, eps=LAYERNORM_EPS, n_feat=self.D, rows_bs=rows_bs if rows_bs is not None else (M or 1 << 30))
+        return L.DeferredLN(mode=2, np=self.np, xt=None, ld_xt=0, part=self.part.data_ptr() + r0 * self.np * 8, cen_in=None, cen_out=None,
+                            delta=self.delta.data_ptr() + r0 * 4, s=s.data_ptr(), s_bs=s_bs, eps=LAYERNORM_EPS, n_feat=self.D,
+                            rows_bs=rows_bs if rows_bs is not None else (M or 1 << 30))
 
 
 def round_up(x: int, m: int) -> int:
@@ -317,7 +335,8 @@ class AbsorbedCross:
                  sC=ws.Sr * self.D, sBias=0, stream=stream)
 
 
-    def block_dln(self, l: int, x: torch.Tensor, lw: EncLayerW, ws: "SeqWorkspace", dl: DeferredLN, consume: bool, stream=None) -> None:
+    def block_dln(self, l: int, x: torch.Tensor, lw: EncLayerW, ws: "SeqWorkspace", dl: DeferredLN, consume: bool, stream=None,
+                  last_segment: bool = True) -> None:
         """``block`` inside a deferred-LayerNorm chain: `consume` = ws.xn holds the centred copy of x (the scores GEMM applies
         norm2 in its epilogue; layers >= 1), else ws.xn = LN2(x); the P.B GEMM always leaves the centred copy + partials of
         the updated rows for norm3."""
@@ -331,7 +350,7 @@ class AbsorbedCross:
                                  dl.consumer(self.sA[l], r0=r0, rows_bs=ws.Sr, s_bs=N), stream=stream)
         else:
             ops.xattn_scores(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq, stream=stream)
-        ops.gemm_dln(P, self.Bt[l, 0], x[r0:], L.EPI_RESIDUAL, dl.producer(ws, r0=r0, rows_bs=ws.Sr), bias=lw.ca_out_b, M=ws.Sr, batch=self.n_seq,
+        ops.gemm_dln(P, self.Bt[l, 0], x[r0:], L.EPI_RESIDUAL, dl.producer(ws, r0=r0, rows_bs=ws.Sr, advance=last_segment), bias=lw.ca_out_b, M=ws.Sr, batch=self.n_seq,
                      sA=ws.Sr * N, sW=self.D * N, sC=ws.Sr * self.D, sBias=0, stream=stream)
 
 
@@ -465,9 +484,9 @@ def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr
     if before_cross is not None:
         before_cross()
     if first:
-        ops.layernorm_mean(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, dl.cen, stream=stream)
-    for seg in plan:
-        seg[1].block_dln(layer, x, lw, ws, dl, consume=not first, stream=stream)
+        ops.layernorm_mean(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, dl.start(), stream=stream)
+    for i, seg in enumerate(plan):
+        seg[1].block_dln(layer, x, lw, ws, dl, consume=not first, stream=stream, last_segment=i + 1 == len(plan))
     ops.gemm_dln(ws.xn, lw.act_w_f, ws.hff, L.EPI_SWIGLU, dl.consumer(lw.act_s, M=ws.M), bias=lw.act_b_f, stream=stream)
     if chain_out:
         ops.gemm_dln(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.l2_b, stream=stream)

@@ -69,7 +69,8 @@ struct Gemm16Params {
     // producer of that row).  The LayerNorm launch, its read of x and the normalised copy disappear.
     unsigned char* dl_xt; int64_t dl_ld_xt;      // producer: centred operand-type copy of the updated rows
     float* dl_part; int dl_np;                   // [rows][dl_np] {sum, sumsq}: producer writes entry tn (dl_np = its tilesN), consumer reads all
-    const float* dl_cen_in; float* dl_cen_out;   // per-row centre (nullptr in: 0); consumer, column tile 0: cen_out = cen_in + d
+    const float* dl_cen_in; float* dl_cen_out;   // producer: per-row centre = cen_in + delta (nullptr: 0); column tile 0 leaves it in cen_out
+    float* dl_delta;                             // consumer, column tile 0: d of the row (producer: read)
     const float* dl_s; int64_t dl_s_bs;          // consumer: per output column, sum_k W'[n][k] (fp32); batch stride
     float dl_eps, dl_inv_n;                      // consumer: LayerNorm eps, 1 / feature count
     int dl_rows_bs;                              // rows per batch entry in dl_part / dl_cen_* / dl_xt (batched launches)
@@ -472,7 +473,11 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     if constexpr (DLN == 1) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-            dl_cen[i] = p.dl_cen_in ? p.dl_cen_in[bz * p.dl_rows_bs + min(m0 + wm * TM * 16 + i * 16 + l15, p.M - 1)] : 0.f;
+        {
+            // centre of the row = the previous producer's centre + the d the consumer in between measured (= the row's mean then)
+            const int gr = bz * p.dl_rows_bs + min(m0 + wm * TM * 16 + i * 16 + l15, p.M - 1);
+            dl_cen[i] = (p.dl_cen_in ? p.dl_cen_in[gr] : 0.f) + (p.dl_delta ? p.dl_delta[gr] : 0.f);
+        }
     }
     auto mfma_block = [&](const uint4 (&af)[TM], const uint4 (&bf)[TN]) {
         if (EPI == M5_EPI_QKV && vblock) {
@@ -619,7 +624,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             const float d = s1 * p.dl_inv_n;
             const float var = fmaxf(s2 * p.dl_inv_n - d * d, 0.f);
             pr[0] = make_float2(d, 1.0f / sqrtf(var + p.dl_eps));       // in place: this thread is the row's only reader
-            if (tn == 0 && p.dl_cen_out && m0 + r < p.M) p.dl_cen_out[dl_row0 + r] = (p.dl_cen_in ? p.dl_cen_in[dl_row0 + r] : 0.f) + d;
+            if (tn == 0 && p.dl_delta && m0 + r < p.M) p.dl_delta[dl_row0 + r] = d;          // a store, no load: nothing here waits on memory
         }
     }
     // {d, r} of local row lr / the folded weights' row sums of the tile's columns lcol .. lcol + 3 (tile-local column; both in
@@ -862,7 +867,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         static_assert(!FAST || NW * WSZ <= NSTAGE * STAGE, "FAST QKV: the staged scatter must fit the stage buffers");
         if constexpr (NW * WSZ <= NSTAGE * STAGE) {
             if (FAST || p.qkv_stage) {
-                __syncthreads();
+                if constexpr (DLN == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS only: the d store stays in flight
+                else __syncthreads();
                 unsigned char* ws = lds + wave * WSZ;
                 const int ncol0 = n0 + wn * 64;                // this wave's first column: one (section, head)
                 if (ncol0 >= p.N) return;                      // (whole-head granularity: N is a multiple of 64)
@@ -991,7 +997,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     if constexpr (EPI == EPI_SOFTMAX_HEADS) {
         constexpr int RB = TN * 32, RBS = RB + 16, CPR = RB / 16, RPP = 64 / CPR;
         static_assert(NW * TM * 16 * RBS <= NSTAGE * STAGE, "the output tile is staged in the (dead) K-loop stages");
-        __syncthreads();
+        if constexpr (DLN == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
         unsigned char* ws = lds + wave * (TM * 16 * RBS);
         float bvs[TN][4], svs[(DLN == 2) ? TN : 1][4];
 #pragma unroll
@@ -1057,7 +1064,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         static_assert(!FAST || (RB % 16 == 0 && NW * TM * 16 * RBS <= NSTAGE * STAGE), "FAST 16-bit epilogue: staged stores must fit");
         if constexpr (RB % 16 == 0 && NW * TM * 16 * RBS <= NSTAGE * STAGE) {
             if (FAST || p.vec16) {
-                __syncthreads();                                          // every wave is done reading the stages
+                if constexpr (DLN == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                else __syncthreads();                                     // every wave is done reading the stages
                 unsigned char* ws = lds + wave * (TM * 16 * RBS);
                 float2 drow[(DLN == 2) ? TM : 1];
                 if constexpr (DLN == 2) {
@@ -1124,39 +1132,38 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         static_assert(!FAST || EPI == M5_EPI_F32 || PRELOAD_C, "FAST residual epilogue needs the preloaded C tile");
         if ((FAST || p.fast_c) && (EPI == M5_EPI_F32 || PRELOAD_C)) {
             float* Cf = reinterpret_cast<float*>(Cb);
-            float ps1[(DLN == 1) ? TM : 1], ps2[(DLN == 1) ? TM : 1];
+            if constexpr (DLN == 1) {
+                // ---- deferred-LayerNorm producer.  Order: ONE wait for the preloaded C tile, all arithmetic in registers, the
+                // centred copy + row sums out through LDS, and the fp32 C tile LAST as twelve back-to-back stores.  (Loads and
+                // stores share the VM counter and retire out of order with respect to each other, so a store issued between two
+                // uses of preloaded values makes hipcc wait for the earlier STORES too: the plain epilogue pays about one store
+                // round trip for that, and anything behind it would queue up behind the whole tile.)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = mw + i * 16 + l15;
-                float* rp = Cf + (int64_t)row * p.ldc;
-                if constexpr (DLN == 1) { ps1[i] = 0.f; ps2[i] = 0.f; }
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int col = nw + j * 16 + lg * 4;
-                    float4 o;
-                    o.x = acc[i][j][0] + bv[j][0]; o.y = acc[i][j][1] + bv[j][1]; o.z = acc[i][j][2] + bv[j][2]; o.w = acc[i][j][3] + bv[j][3];
-                    if constexpr (EPI == M5_EPI_RESIDUAL) {
-                        o.x = oldpre[i][j].x + o.x; o.y = oldpre[i][j].y + o.y; o.z = oldpre[i][j].z + o.z; o.w = oldpre[i][j].w + o.w;
-                    }
-                    if (row < p.M && col < p.N) *reinterpret_cast<float4*>(rp + col) = o;
-                    if constexpr (DLN == 1) {
-                        // the deferred LayerNorm's operand: the updated row minus its centre, in the operand type (kept in the
-                        // accumulator registers until the staged store below); row sums of it
-                        float xc[4] = {o.x - dl_cen[i], o.y - dl_cen[i], o.z - dl_cen[i], o.w - dl_cen[i]};
-                        if (col < p.N) {
-                            ps1[i] += (xc[0] + xc[1]) + (xc[2] + xc[3]);
-                            ps2[i] += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
-                        }
-                        acc[i][j] = f4_t{xc[0], xc[1], xc[2], xc[3]};
+                    for (int j = 0; j < TN; ++j)
+                        asm volatile("" : "+v"(oldpre[i][j].x), "+v"(oldpre[i][j].y), "+v"(oldpre[i][j].z), "+v"(oldpre[i][j].w));
+                float ps1[TM], ps2[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ps1[i] = 0.f; ps2[i] = 0.f;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        float4 o;
+                        o.x = oldpre[i][j].x + (acc[i][j][0] + bv[j][0]); o.y = oldpre[i][j].y + (acc[i][j][1] + bv[j][1]);
+                        o.z = oldpre[i][j].z + (acc[i][j][2] + bv[j][2]); o.w = oldpre[i][j].w + (acc[i][j][3] + bv[j][3]);
+                        oldpre[i][j] = o;                                         // the updated row values (stored at the end)
+                        const float xc[4] = {o.x - dl_cen[i], o.y - dl_cen[i], o.z - dl_cen[i], o.w - dl_cen[i]};
+                        ps1[i] += (xc[0] + xc[1]) + (xc[2] + xc[3]);
+                        ps2[i] += (xc[0] * xc[0] + xc[1] * xc[1]) + (xc[2] * xc[2] + xc[3] * xc[3]);
+                        acc[i][j] = f4_t{xc[0], xc[1], xc[2], xc[3]};             // the deferred LayerNorm's operand, before rounding
                     }
                 }
-            }
-            if constexpr (DLN == 1) {
                 // the centred copy leaves through the (dead) stage buffers as whole 16-byte row chunks (straight from the
                 // accumulator layout a store instruction writes 16 rows x 32 bytes: measured +4 us per launch)
                 constexpr int RBX = TN * 32 + 16;                                 // padded LDS row: TN*16 columns of 2 bytes
                 static_assert(NW * TM * 16 * RBX <= NSTAGE * STAGE, "the centred copy is staged in the K-loop stages");
-                __syncthreads();                                                  // every wave is done reading the stages
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the stages (LDS only: nothing to drain)
                 unsigned char* wsx = lds + wave * (TM * 16 * RBX);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -1175,17 +1182,20 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     s2 += lane_xor16(s2); s2 += lane_xor32(s2);
                     if (lg == 0) xs[wave * TM * 16 + i * 16 + l15] = make_float2(s1, s2);
                 }
-                __syncthreads();
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 {
                     constexpr int CPRX = TN * 2, RPPX = 64 / CPRX;               // 16-byte chunks per row, rows per pass
                     const int rr = lane / CPRX, ch = lane - rr * CPRX;
                     st* Xt = reinterpret_cast<st*>(p.dl_xt) + (int64_t)bz * p.dl_rows_bs * p.dl_ld_xt;
                     const int ocol = nw + ch * 8;
+                    uint4 xq[(TM * 16 + RPPX - 1) / RPPX];
+#pragma unroll
+                    for (int pass = 0; pass < (TM * 16 + RPPX - 1) / RPPX; ++pass)
+                        xq[pass] = *reinterpret_cast<const uint4*>(wsx + min(pass * RPPX + rr, TM * 16 - 1) * RBX + ch * 16);
 #pragma unroll
                     for (int pass = 0; pass < (TM * 16 + RPPX - 1) / RPPX; ++pass) {
                         const int r = pass * RPPX + rr;
-                        if (rr < RPPX && r < TM * 16 && mw + r < p.M && ocol < p.N)
-                            *reinterpret_cast<uint4*>(Xt + (int64_t)(mw + r) * p.dl_ld_xt + ocol) = *reinterpret_cast<const uint4*>(wsx + r * RBX + ch * 16);
+                        if (rr < RPPX && r < TM * 16 && mw + r < p.M) *reinterpret_cast<uint4*>(Xt + (int64_t)(mw + r) * p.dl_ld_xt + ocol) = xq[pass];
                     }
                 }
                 for (int r = tid; r < BM; r += NW * 64) {
@@ -1194,6 +1204,38 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
                     for (int w = 0; w < WN; ++w) { const float2 v = xs[(wmr * WN + w) * TM * 16 + lr]; s1 += v.x; s2 += v.y; }
                     if (m0 + r < p.M) reinterpret_cast<float2*>(p.dl_part)[(int64_t)(dl_row0 + r) * p.dl_np + tn] = make_float2(s1, s2);
+                }
+                // the row's centre for the NEXT producer of these rows (column tile 0, one lane per row)
+                if (tn == 0 && wn == 0 && lg == 0 && p.dl_cen_out) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int row = mw + i * 16 + l15;
+                        if (row < p.M) p.dl_cen_out[bz * p.dl_rows_bs + row] = dl_cen[i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = mw + i * 16 + l15;
+                    float* rp = Cf + (int64_t)row * p.ldc;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (row < p.M) *reinterpret_cast<float4*>(rp + nw + j * 16 + lg * 4) = oldpre[i][j];
+                }
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = mw + i * 16 + l15;
+                float* rp = Cf + (int64_t)row * p.ldc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = nw + j * 16 + lg * 4;
+                    float4 o;
+                    o.x = acc[i][j][0] + bv[j][0]; o.y = acc[i][j][1] + bv[j][1]; o.z = acc[i][j][2] + bv[j][2]; o.w = acc[i][j][3] + bv[j][3];
+                    if constexpr (EPI == M5_EPI_RESIDUAL) {
+                        o.x = oldpre[i][j].x + o.x; o.y = oldpre[i][j].y + o.y; o.z = oldpre[i][j].z + o.z; o.w = oldpre[i][j].w + o.w;
+                    }
+                    if (row < p.M && col < p.N) *reinterpret_cast<float4*>(rp + col) = o;
                 }
             }
             if (dbg_on) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg[4] = clock64(); dbg[5] = wall_clock64(); }
@@ -1457,7 +1499,7 @@ static int dl_fill(Gemm16Params& p, const M5DeferredLN* dl, int epi_kind /* 1 pr
     if (dl->mode != epi_kind) return M5_ERR_ARG;
     if (!dl->part || dl->np <= 0 || dl->np > DL_MAX_NP || (dl->np & 1) || dl->rows_bs <= 0) return M5_ERR_UNSUPPORTED;
     if (((uintptr_t)dl->part & 15)) return M5_ERR_ARG;
-    p.dl_part = dl->part; p.dl_np = dl->np; p.dl_cen_in = dl->cen_in; p.dl_cen_out = dl->cen_out; p.dl_rows_bs = dl->rows_bs;
+    p.dl_part = dl->part; p.dl_np = dl->np; p.dl_cen_in = dl->cen_in; p.dl_cen_out = dl->cen_out; p.dl_delta = dl->delta; p.dl_rows_bs = dl->rows_bs;
     if (epi_kind == 1) {
         if (!dl->xt || (dl->ld_xt % 8) || ((uintptr_t)dl->xt & 15)) return M5_ERR_ARG;      // 16-byte row chunks
         p.dl_xt = (unsigned char*)dl->xt; p.dl_ld_xt = dl->ld_xt;

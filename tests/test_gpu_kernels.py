@@ -202,11 +202,14 @@ def test_deferred_layernorm_chain(dev, dt, M):
     xt = torch.zeros(M + 1, D, device=dev, dtype=dt)
     part = torch.zeros(M, npart, 2, device=dev)
     cen = cen0.to(dev).clone()
-    dlp = L.DeferredLN(mode=1, np=npart, xt=xt.data_ptr(), ld_xt=D, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=None, s=None, s_bs=0,
-                       eps=0.0, n_feat=D, rows_bs=M)
+    cen_b = torch.zeros(M, device=dev)                                      # the centre the producer used, for the next producer
+    delta = torch.zeros(M, device=dev)                                      # d of each row, written by a consumer
+    dlp = L.DeferredLN(mode=1, np=npart, xt=xt.data_ptr(), ld_xt=D, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=cen_b.data_ptr(), delta=None,
+                       s=None, s_bs=0, eps=0.0, n_feat=D, rows_bs=M)
     ops.gemm_dln(a0.to(dev, dt), w0.to(dev, dt), x, L.EPI_RESIDUAL, dlp, bias=b0.to(dev))
     torch.cuda.synchronize()
     assert _rel(x.cpu(), x_ref) < TOL[dt], _rel(x.cpu(), x_ref)
+    assert torch.equal(cen_b.cpu(), cen0)
     xc = x.cpu() - cen0[:, None]                                            # what the copy and the partials describe (the kernel's own x)
     assert float((xt[:M].float().cpu() - xc).abs().max()) <= float(xc.abs().max()) * (2 ** -8 if dt == torch.bfloat16 else 2 ** -11) * 1.01
     assert float(xt[M].float().abs().max()) == 0.0
@@ -221,8 +224,8 @@ def test_deferred_layernorm_chain(dev, dt, M):
         Wf = (W * g[None, :]).to(dt)
         return Wf.to(dev).contiguous(), (W @ be + (b if b is not None else 0.0)).to(dev).contiguous(), Wf.float().sum(1).to(dev).contiguous()
 
-    def consumer(s_vec, cen_out=True, rows_bs=M, s_bs=0):
-        return L.DeferredLN(mode=2, np=npart, xt=None, ld_xt=0, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=cen.data_ptr() if cen_out else None,
+    def consumer(s_vec, d_out=True, rows_bs=M, s_bs=0):
+        return L.DeferredLN(mode=2, np=npart, xt=None, ld_xt=0, part=part.data_ptr(), cen_in=None, cen_out=None, delta=delta.data_ptr() if d_out else None,
                             s=s_vec.data_ptr(), s_bs=s_bs, eps=eps, n_feat=D, rows_bs=rows_bs)
 
     tol = 1.2e-2 if dt == torch.bfloat16 else 2.5e-3                       # of max |ref|: one operand rounding + one weight rounding
@@ -236,12 +239,12 @@ def test_deferred_layernorm_chain(dev, dt, M):
     vt = torch.zeros(1, H, 64, Sp, device=dev, dtype=dt)
     sc = L.QkvScatter(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), rows_per_batch=M, n_heads=H, head_dim=64, q_bs=H * M * 64, q_hs=M * 64, q_rs=64,
                       k_bs=H * M * 64, k_hs=M * 64, k_rs=64, vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp)
-    ops.gemm_dln(xt[:M], wqf, None, L.EPI_QKV, consumer(sq, cen_out=False), bias=bqf, scatter=sc)
+    ops.gemm_dln(xt[:M], wqf, None, L.EPI_QKV, consumer(sq, d_out=False), bias=bqf, scatter=sc)
     torch.cuda.synchronize()
     assert _rel(q[0].float().cpu(), ref[:, 0].permute(1, 0, 2)) < tol
     assert _rel(k[0].float().cpu(), ref[:, 1].permute(1, 0, 2)) < tol
     assert _rel(vt[0].float().cpu()[..., :M], ref[:, 2].permute(1, 2, 0)) < tol
-    assert torch.equal(cen.cpu(), cen0)                                     # cen_out = NULL: centres untouched
+    assert float(delta.abs().max()) == 0.0                                  # delta = NULL: nothing written
     # SwiGLU pair (+ the centres move to the row means)
     w1, w3 = _rand((FF, D), 11, 1.5 / math.sqrt(D)), _rand((FF, D), 12, 1.5 / math.sqrt(D))
     wsf, bsf, ss = fold(interleave_rows(w1, w3), None)
@@ -250,7 +253,7 @@ def test_deferred_layernorm_chain(dev, dt, M):
     torch.cuda.synchronize()
     ref = torch.nn.functional.silu(ln @ w1.T) * (ln @ w3.T)
     assert _rel(hff.float().cpu(), ref) < 2 * tol
-    assert float((cen.cpu() - x.cpu().mean(dim=1)).abs().max()) < 1e-3
+    assert float((cen0 + delta.cpu() - x.cpu().mean(dim=1)).abs().max()) < 1e-3          # centre + d = the row's mean
     # scores with per-head softmax: two sequences of M / 2 rows with their own A / c / s tables (batched launch, rows_bs)
     if M % 128 == 0:
         Ms = M // 2
@@ -262,26 +265,27 @@ def test_deferred_layernorm_chain(dev, dt, M):
         cf = (torch.einsum("bnk,k->bn", A, be) + c).to(dev).contiguous()
         sA = Af.float().sum(-1).to(dev).contiguous()
         P = torch.zeros(M, N, device=dev, dtype=dt)
-        cen.copy_(cen0.to(dev))
+        delta.zero_()
         ops.xattn_scores_dln(xt[:M], Ms * D, Af.to(dev).contiguous(), cf, P, Ms * N, Ms, H, Lp, 2, consumer(sA, rows_bs=Ms, s_bs=N))
         torch.cuda.synchronize()
         sc_ref = torch.stack([ln[b * Ms:(b + 1) * Ms] @ A[b].T + c[b] for b in range(2)]).view(2, Ms, H, Lp)
         p_ref = torch.softmax(sc_ref, dim=-1).reshape(M, N)
         assert float((P.float().cpu() - p_ref).abs().max()) < (2.5e-2 if dt == torch.bfloat16 else 5e-3)
         assert float(P.float().cpu().view(M, H, Lp)[:, :, 40:].abs().max()) == 0.0
-        assert float((cen.cpu() - x.cpu().mean(dim=1)).abs().max()) < 1e-3
+        assert float((cen0 + delta.cpu() - x.cpu().mean(dim=1)).abs().max()) < 1e-3
     # -- a second producer, batched like the P.B GEMM (two sequences, rows_bs), centres by the means the consumer left
     if M % 128 == 0:
         Ms = M // 2
         a1 = _q(_rand((M, K0), 15), dt)
         w1b = _q(_rand((2, D, K0), 16, 2.0 / math.sqrt(K0)), dt)
         x2_ref = x.cpu() + torch.cat([a1[b * Ms:(b + 1) * Ms] @ w1b[b].T for b in range(2)]) + b0
-        dlp2 = L.DeferredLN(mode=1, np=npart, xt=xt.data_ptr(), ld_xt=D, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=None, s=None, s_bs=0,
-                            eps=0.0, n_feat=D, rows_bs=Ms)
-        cen_now = cen.cpu().clone()
+        dlp2 = L.DeferredLN(mode=1, np=npart, xt=xt.data_ptr(), ld_xt=D, part=part.data_ptr(), cen_in=cen_b.data_ptr(), cen_out=cen.data_ptr(),
+                            delta=delta.data_ptr(), s=None, s_bs=0, eps=0.0, n_feat=D, rows_bs=Ms)
+        cen_now = (cen_b + delta).cpu().clone()                             # = the row means the consumer measured
         ops.gemm_dln(a1.to(dev, dt), w1b.to(dev, dt)[0], x, L.EPI_RESIDUAL, dlp2, bias=b0.to(dev), M=Ms, batch=2, sA=Ms * K0, sW=D * K0, sC=Ms * D, sBias=0)
         torch.cuda.synchronize()
         assert _rel(x.cpu(), x2_ref) < TOL[dt]
+        assert torch.equal(cen.cpu(), cen_now)
         xc2 = (x.cpu() - cen_now[:, None]).view(M, npart, 128)
         assert torch.allclose(part.cpu()[..., 0], xc2.sum(-1), rtol=1e-4, atol=2e-3)
         assert float((xt[:M].float().cpu() - xc2.view(M, D)).abs().max()) <= float(xc2.abs().max()) * (2 ** -8 if dt == torch.bfloat16 else 2 ** -11) * 1.01
