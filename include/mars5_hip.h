@@ -95,6 +95,8 @@ typedef struct {
     const int32_t* kv_index;    /* optional device int: K base += (*kv_index) * kv_index_stride_k,   */
     int64_t kv_index_stride_k;  /* V^T base += (*kv_index) * kv_index_stride_v (selects the          */
     int64_t kv_index_stride_v;  /* pre-computed cross-attention memory of the current DDPM step)     */
+    const int32_t* q_len;       /* per-batch valid query count (device) or NULL = Sq: query blocks past it are not computed
+                                   (sequences of different lengths in one padded layout; their rows of O stay untouched) */
 } M5AttnArgs;
 M5_API int m5_attention(int dtype, const M5AttnArgs* a, void* stream);
 
@@ -154,10 +156,10 @@ M5_API int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, co
  *     LN(x) W^T + b = r (xt W'^T - d s) + b',   xt = dtype(x - cen),  W' = dtype(W diag gamma),  s[n] = sum_k W'[n][k],
  *     b' = b + W beta,  d = mean(x - cen),  r = 1 / sqrt(var(x) + eps)           (cen: any per-row constant near the mean)
  * so the LayerNorm launch, its read of x and the normalised copy disappear:
- *  - mode 1, the PRODUCER: m5_gemm_dln(M5_EPI_RESIDUAL) updates x in place as m5_gemm does and also writes xt (row stride
+ *  - mode 1, the PRODUCER: m5_gemm_ex(M5_EPI_RESIDUAL) updates x in place as m5_gemm does and also writes xt (row stride
  *    ld_xt) and, per row and 128-column tile tn, part[row][tn] = {sum, sum of squares} of (x_new - cen_in[row]) over the tile
  *    (np = N / 128, even, <= 8).  The row's centre is cen_in[row] + delta[row] (NULL = 0) and is left in cen_out[row].
- *  - mode 2, a CONSUMER: m5_gemm_dln(M5_EPI_QKV / M5_EPI_SWIGLU) and m5_xattn_scores_dln take A = xt and W = W', bias = b',
+ *  - mode 2, a CONSUMER: m5_gemm_ex(M5_EPI_QKV / M5_EPI_SWIGLU) and m5_xattn_scores_ex take A = xt and W = W', bias = b',
  *    derive (d, r) per row from the np partial pairs (n_feat = D, eps) and apply the formula in their epilogues; the column
  *    tile 0 workgroups also write delta[row] = d (centre + d = the row's mean: the next producer's centre; a consumer
  *    never READS a centre, so nothing in it waits on another launch's small stores).
@@ -179,12 +181,24 @@ typedef struct {
     int32_t n_feat;           /* consumer: D                                                      */
     int32_t rows_bs;          /* rows per batch entry                                             */
 } M5DeferredLN;
-M5_API int m5_gemm_dln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
-                int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, const M5DeferredLN* dl, void* stream);
-M5_API int m5_xattn_scores_dln(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
-                        void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
-                        void* stream);
+/* Row-tile lists: a batch of sequences of DIFFERENT lengths in one padded layout (sequence b = rows b * rows_per_seq ..,
+ * its first len_b rows real, rows_per_seq a multiple of 384).  For each tile height BM in {96, 128, 192}, map[i] lists the
+ * row tiles b * (rows_per_seq / BM) + t with t * BM < len_b (device int32, n[i] entries, ascending); a launch that gets the
+ * lists runs only those tiles (the kernel picks the list of its own tile height), so the padding costs nothing and the
+ * XCD-contiguous tile order stays balanced.  Flat launches (batch = 1, M = all rows) and batched ones (batch = sequences,
+ * M = rows_per_seq) use the same lists.  Rows of tiles that are not listed are neither read nor written. */
+typedef struct {
+    const int32_t* map[3];    /* BM = 96, 128, 192                                                */
+    int32_t n[3];
+    int32_t rows_per_seq;
+} M5RowTiles;
+/* m5_gemm / m5_xattn_scores with either or both of the two (NULL = without). */
+M5_API int m5_gemm_ex(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+               void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
+               int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, const M5DeferredLN* dl, const M5RowTiles* rt, void* stream);
+M5_API int m5_xattn_scores_ex(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                       void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
+                       const M5RowTiles* rt, void* stream);
 M5_API int m5_layernorm_mean(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                       void* y, int64_t ldy, int M, int D, float* mean_out, void* stream);
 

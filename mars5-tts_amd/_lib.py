@@ -56,7 +56,7 @@ class AttnArgs(C.Structure):
                 ("o", vp), ("o_bs", i64), ("o_rs", i64),
                 ("B", i32), ("H", i32), ("Sq", i32), ("Sk", i32),
                 ("key_len", vp), ("causal", i32), ("scale", f32),
-                ("kv_index", vp), ("kv_index_stride_k", i64), ("kv_index_stride_v", i64)]
+                ("kv_index", vp), ("kv_index_stride_k", i64), ("kv_index_stride_v", i64), ("q_len", vp)]
 
 
 class Prefetch(C.Structure):
@@ -117,6 +117,11 @@ class NarSampleArgs(C.Structure):
                 ("div_mode", i32), ("q0_override_steps", i32)]
 
 
+class RowTiles(C.Structure):
+    """M5RowTiles (include/mars5_hip.h): the row tiles of a padded batch layout that hold real rows, per tile height 96 / 128 / 192."""
+    _fields_ = [("map", vp * 3), ("n", i32 * 3), ("rows_per_seq", i32)]
+
+
 class DeferredLN(C.Structure):
     """M5DeferredLN (include/mars5_hip.h): a LayerNorm deferred into the GEMM that consumes it."""
     _fields_ = [("mode", i32), ("np", i32), ("xt", vp), ("ld_xt", i64), ("part", vp), ("cen_in", vp), ("cen_out", vp), ("delta", vp),
@@ -134,10 +139,10 @@ PROTOTYPES = {
                                        vp, C.c_int, vp]),
     "m5_xattn_absorb": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
     "m5_xattn_scores": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
-    "m5_gemm_dln": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int,
-                              C.POINTER(QkvScatter), C.c_int, i64, i64, i64, i64, C.POINTER(DeferredLN), vp]),
-    "m5_xattn_scores_dln": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                      C.POINTER(DeferredLN), vp]),
+    "m5_gemm_ex": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.POINTER(QkvScatter), C.c_int, i64, i64, i64, i64, C.POINTER(DeferredLN), C.POINTER(RowTiles), vp]),
+    "m5_xattn_scores_ex": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(DeferredLN), C.POINTER(RowTiles), vp]),
     "m5_layernorm_mean": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, vp, vp]),
     "m5_layernorm": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
     "m5_rmsnorm": (C.c_int, [C.c_int, vp, i64, vp, f32, vp, i64, C.c_int, C.c_int, vp]),

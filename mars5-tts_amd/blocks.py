@@ -200,7 +200,8 @@ class SeqWorkspace:
                           vt=self.vt.data_ptr(), vt_bs=H * 64 * Sp, vt_hs=64 * Sp, vt_ds=Sp,
                           o=self.att.data_ptr(), o_bs=Sr * D, o_rs=D, B=self.B, H=H, Sq=S, Sk=S,
                           key_len=key_len.data_ptr() if key_len is not None else None, causal=1 if causal else 0,
-                          scale=64 ** -0.5, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0)
+                          scale=64 ** -0.5, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0,
+                          q_len=key_len.data_ptr() if key_len is not None else None)     # self-attention: a sequence's queries = its keys
 
 
 def residual_gemm(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Optional[torch.Tensor], ws: SeqWorkspace,
@@ -336,7 +337,7 @@ class AbsorbedCross:
 
 
     def block_dln(self, l: int, x: torch.Tensor, lw: EncLayerW, ws: "SeqWorkspace", dl: DeferredLN, consume: bool, stream=None,
-                  last_segment: bool = True) -> None:
+                  last_segment: bool = True, rt: Optional["RowTiles"] = None) -> None:
         """``block`` inside a deferred-LayerNorm chain: `consume` = ws.xn holds the centred copy of x (the scores GEMM applies
         norm2 in its epilogue; layers >= 1), else ws.xn = LN2(x); the P.B GEMM always leaves the centred copy + partials of
         the updated rows for norm3."""
@@ -344,14 +345,26 @@ class AbsorbedCross:
         r0, rows = self.s0 * ws.Sr, self.n_seq * ws.Sr
         assert N <= ws.FF and self.dln
         P = ws.hff.view(-1)[r0 * N: (r0 + rows) * N].view(rows, N)
+        rc = None
+        if rt is not None:                     # the row tiles of THIS run of sequences (lists are relative to the run's first row)
+            rc = self._rt_c(rt, ws)
         if consume:
             assert l >= 1
             ops.xattn_scores_dln(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq,
-                                 dl.consumer(self.sA[l], r0=r0, rows_bs=ws.Sr, s_bs=N), stream=stream)
+                                 dl.consumer(self.sA[l], r0=r0, rows_bs=ws.Sr, s_bs=N), stream=stream, rt=rc)
+        elif rc is not None:
+            ops.xattn_scores_dln(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq, None, stream=stream, rt=rc)
         else:
             ops.xattn_scores(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq, stream=stream)
         ops.gemm_dln(P, self.Bt[l, 0], x[r0:], L.EPI_RESIDUAL, dl.producer(ws, r0=r0, rows_bs=ws.Sr, advance=last_segment), bias=lw.ca_out_b, M=ws.Sr, batch=self.n_seq,
-                     sA=ws.Sr * N, sW=self.D * N, sC=ws.Sr * self.D, sBias=0, stream=stream)
+                     sA=ws.Sr * N, sW=self.D * N, sC=ws.Sr * self.D, sBias=0, stream=stream, rt=rc)
+
+    def _rt_c(self, rt: "RowTiles", ws: "SeqWorkspace"):
+        """Row-tile lists of this run's sequences [s0, s0 + n_seq), numbered from the run's first sequence (cached)."""
+        if getattr(self, "_rt_src", None) is not rt:
+            self._rt_src = rt
+            self._rt_own = RowTiles(rt.lens[self.s0: self.s0 + self.n_seq], ws.Sr, rt.maps[0].device)
+        return self._rt_own.c
 
 
 def make_cross_plan(layers, mems_per_layer, D: int, dt: torch.dtype, dev, dln: bool = False) -> list:
@@ -453,13 +466,32 @@ def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_p
     return ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream, normed=n, next_ln=next_ln)
 
 
+class RowTiles:
+    """Row-tile lists of a padded batch layout (include/mars5_hip.h, M5RowTiles): sequence b occupies rows b * Sr .. of the
+    workspace, its first lens[b] rows are real; for the tile heights 96 / 128 / 192 the tiles that hold a real row.  GEMMs
+    launched with `.c` run only those, so padding a group of utterances to its longest member costs (almost) nothing."""
+
+    ALIGN = 384                                   # lcm(96, 128, 192): every sequence starts on a tile boundary of every tile height
+
+    def __init__(self, lens, Sr: int, dev):
+        assert Sr % self.ALIGN == 0 and all(0 < n <= Sr for n in lens)
+        self.maps, ns = [], []
+        for bm in (96, 128, 192):
+            tpb = Sr // bm
+            e = [b * tpb + t for b, n in enumerate(lens) for t in range((n + bm - 1) // bm)]
+            self.maps.append(torch.tensor(e, dtype=torch.int32, device="cpu").to(dev))
+            ns.append(len(e))
+        self.n, self.Sr, self.lens = ns, Sr, list(lens)
+        self.c = L.RowTiles(map=(L.vp * 3)(*[m.data_ptr() for m in self.maps]), n=(L.i32 * 3)(*ns), rows_per_seq=Sr)
+
+
 def plan_allows_dln(plan) -> bool:
     return plan is not None and len(plan) > 0 and all(seg[0] == "absorbed" and seg[1].dln for seg in plan)
 
 
 def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr: torch.Tensor, dl: DeferredLN, plan, layer: int,
                       chain_in: bool, chain_out: bool, stream=None, key_len: Optional[torch.Tensor] = None, before_cross=None,
-                      skip_self: bool = False) -> None:
+                      skip_self: bool = False, rt: Optional[RowTiles] = None) -> None:
     """One pre-LN decoder layer with its LayerNorms DEFERRED into the GEMMs that consume them (include/mars5_hip.h,
     M5DeferredLN; reference model.py:179-203, same mathematics): every residual GEMM leaves a centred 16-bit copy of the rows
     it updated (ws.xn) + per-tile row partials, the next projection applies the normalisation in its epilogue -- 3 LayerNorm
@@ -467,31 +499,41 @@ def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr
     is an explicit launch.  Layer 0 keeps explicit norm1 / norm2 launches (its self-attention block runs once for both guidance
     branches; norm2 starts the chain and leaves the row means as the first centres), so the per-row arithmetic is the same
     for a lone utterance and inside any batch.  `chain_out`: linear2 leaves the copy for the next layer's norm1.
-    `skip_self`: the caller already ran the self-attention block (layer 0 of a guided lone utterance)."""
+    `skip_self`: the caller already ran the self-attention block (layer 0 of a guided lone utterance).
+    `rt` (a batch of utterances of different lengths): every GEMM runs over the row tiles that hold real rows only."""
     first = layer == 0
     assert first or chain_in
+    rc = rt.c if rt is not None else None
     if not skip_self:
         if chain_in and not first:
-            ops.gemm_dln(ws.xn, lw.in_w_f, None, L.EPI_QKV, dl.consumer(lw.in_s, M=ws.M), bias=lw.in_b_f, scatter=ws.scatter(), stream=stream)
+            ops.gemm_dln(ws.xn, lw.in_w_f, None, L.EPI_QKV, dl.consumer(lw.in_s, M=ws.M), bias=lw.in_b_f, scatter=ws.scatter(), stream=stream, rt=rc)
         else:
             ops.layernorm(x, lw.n1_w, lw.n1_b, LAYERNORM_EPS, ws.xn, stream=stream)
-            ops.gemm(ws.xn, lw.in_w, None, L.EPI_QKV, bias=lw.in_b, scatter=ws.scatter(), stream=stream)
+            if rc is None:
+                ops.gemm(ws.xn, lw.in_w, None, L.EPI_QKV, bias=lw.in_b, scatter=ws.scatter(), stream=stream)
+            else:
+                ops.gemm_dln(ws.xn, lw.in_w, None, L.EPI_QKV, None, bias=lw.in_b, scatter=ws.scatter(), stream=stream, rt=rc)
         ops.attention(ws.dt, ws.self_attn_args(key_len), stream=stream)
         if first:
-            ops.gemm(ws.att, lw.out_w, x, L.EPI_RESIDUAL, bias=lw.out_b, stream=stream)
+            if rc is None:
+                ops.gemm(ws.att, lw.out_w, x, L.EPI_RESIDUAL, bias=lw.out_b, stream=stream)
+            else:
+                ops.gemm_dln(ws.att, lw.out_w, x, L.EPI_RESIDUAL, None, bias=lw.out_b, stream=stream, rt=rc)
         else:
-            ops.gemm_dln(ws.att, lw.out_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.out_b, stream=stream)
+            ops.gemm_dln(ws.att, lw.out_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.out_b, stream=stream, rt=rc)
     if before_cross is not None:
         before_cross()
     if first:
         ops.layernorm_mean(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, dl.start(), stream=stream)
     for i, seg in enumerate(plan):
-        seg[1].block_dln(layer, x, lw, ws, dl, consume=not first, stream=stream, last_segment=i + 1 == len(plan))
-    ops.gemm_dln(ws.xn, lw.act_w_f, ws.hff, L.EPI_SWIGLU, dl.consumer(lw.act_s, M=ws.M), bias=lw.act_b_f, stream=stream)
+        seg[1].block_dln(layer, x, lw, ws, dl, consume=not first, stream=stream, last_segment=i + 1 == len(plan), rt=rt)
+    ops.gemm_dln(ws.xn, lw.act_w_f, ws.hff, L.EPI_SWIGLU, dl.consumer(lw.act_s, M=ws.M), bias=lw.act_b_f, stream=stream, rt=rc)
     if chain_out:
-        ops.gemm_dln(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.l2_b, stream=stream)
-    else:
+        ops.gemm_dln(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.l2_b, stream=stream, rt=rc)
+    elif rc is None:
         ops.gemm(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, bias=lw.l2_b, stream=stream)
+    else:
+        ops.gemm_dln(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, None, bias=lw.l2_b, stream=stream, rt=rc)
 
 
 class SpeakerEncoder:

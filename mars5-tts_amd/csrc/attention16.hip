@@ -75,6 +75,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
     const int l31 = lane & 31, hh = lane >> 5;
     const int qg = (KH == 1) ? wave : (wave % NQG), kh = (KH == 1) ? 0 : (wave / NQG);      // wave-uniform
     const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
+    if (p.q_len && q0 >= p.q_len[b]) return;        // a query block of padding rows (workgroup-uniform: before any barrier)
     int kl = p.key_len ? p.key_len[b] : p.Sk;
     kl = min(kl, p.Sk);
     int64_t koff = 0, voff = 0;

@@ -225,7 +225,8 @@ int launch_gemm(int epi, const GemmParams& p, dim3 grid, hipStream_t s) {
 
 int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc, const int* sec_kind,
-                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s, const M5DeferredLN* dl = nullptr);   // gemm16.hip
+                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s, const M5DeferredLN* dl = nullptr,
+                       const M5RowTiles* rt = nullptr);   // gemm16.hip
 bool m5_gemm_skinny_fits(int dtype, int M, int N, int K, int epi, int batch, int64_t lda, int64_t ldw);   // gemm_skinny.hip
 int m5_gemm_skinny_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                             void* C, int64_t ldc, int M, int N, int K, int epi, hipStream_t s);
@@ -276,12 +277,13 @@ extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int
     }
 }
 
-// m5_gemm with a deferred LayerNorm (M5DeferredLN in include/mars5_hip.h): 16-bit operands only; mode 1 with
-// M5_EPI_RESIDUAL (the producer of the rows), mode 2 with M5_EPI_QKV / M5_EPI_SWIGLU (a consumer).
-extern "C" int m5_gemm_dln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                           void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
-                           int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, const M5DeferredLN* dl, void* stream) {
-    if (!A || !W || !dl || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return M5_ERR_ARG;
+// m5_gemm with a deferred LayerNorm (M5DeferredLN in include/mars5_hip.h; mode 1 with M5_EPI_RESIDUAL = the producer of the
+// rows, mode 2 with M5_EPI_QKV / M5_EPI_SWIGLU = a consumer) and / or over a row-tile list (M5RowTiles).  16-bit operands only.
+extern "C" int m5_gemm_ex(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                          void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc,
+                          int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, const M5DeferredLN* dl, const M5RowTiles* rt,
+                          void* stream) {
+    if (!A || !W || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return M5_ERR_ARG;
     if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
     if (K % 64 != 0) return M5_ERR_UNSUPPORTED;
     if (lda % 8 || ldw % 8 || ((uintptr_t)A & 15) || ((uintptr_t)W & 15) || (sA % 8) || (sW % 8)) return M5_ERR_ARG;
@@ -299,5 +301,5 @@ extern "C" int m5_gemm_dln(int dtype, const void* A, int64_t lda, const void* W,
         if (n == 0 || N != n * sc->n_heads * sc->head_dim) return M5_ERR_ARG;
     }
     return m5_gemm16_dispatch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, epi == M5_EPI_QKV ? &scv : nullptr, sec_kind,
-                              batch, sA, sW, sC, sBias, (hipStream_t)stream, dl);
+                              batch, sA, sW, sC, sBias, (hipStream_t)stream, dl, rt);
 }

@@ -74,7 +74,28 @@ struct Gemm16Params {
     const float* dl_s; int64_t dl_s_bs;          // consumer: per output column, sum_k W'[n][k] (fp32); batch stride
     float dl_eps, dl_inv_n;                      // consumer: LayerNorm eps, 1 / feature count
     int dl_rows_bs;                              // rows per batch entry in dl_part / dl_cen_* / dl_xt (batched launches)
+    // Row-tile list (M5RowTiles): only the listed BM-row tiles exist in the grid.  A batch of sequences of different lengths
+    // lives in one padded layout (rows_per_seq rows each); the tiles that hold nothing but padding are not launched, and
+    // the XCD-contiguous tile order runs over the compacted list (balanced whatever the lengths are).
+    const int* rt_map; int rt_tpb;               // entry e -> batch e / rt_tpb, row tile e % rt_tpb (rt_tpb = 0: flat, row tile e)
+    const M5RowTiles* rt_host;                   // host side only: the caller's lists (launch16 picks the one of its tile height)
 };
+
+// Row-tile list of tile height BM for this launch (host): false = the caller gave lists but none fits (unsupported)
+template <int BM>
+bool rt_apply(Gemm16Params& p, int batch) {
+    const M5RowTiles* rt = p.rt_host;
+    if (!rt) return true;
+    constexpr int idx = BM == 96 ? 0 : (BM == 128 ? 1 : (BM == 192 ? 2 : -1));
+    if constexpr (idx < 0) return false;
+    else {
+        if (!rt->map[idx] || rt->n[idx] <= 0 || rt->rows_per_seq <= 0 || rt->rows_per_seq % BM) return false;
+        p.rt_map = rt->map[idx];
+        p.tilesM = rt->n[idx];
+        p.rt_tpb = batch > 1 ? rt->rows_per_seq / BM : 0;
+        return true;
+    }
+}
 constexpr int EPI_RESIDUAL_LN = 101;
 constexpr int EPI_Q_CROSS = 102;
 constexpr int EPI_SOFTMAX_HEADS = 103;           // C (16-bit) = per-head softmax over the wave's TN*16 columns of acc + bias (xattn_absorb.hip)
@@ -202,7 +223,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     const int tiles = p.tilesM * p.tilesN;
-    const int bz = t / tiles;
+    int bz = t / tiles;
     t -= bz * tiles;
     int tm, tn;
     {
@@ -212,6 +233,11 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         const int w = t - g * width;
         tm = first + w % gsz;
         tn = w / gsz;
+    }
+    if (p.rt_map) {                                    // row-tile list: tm indexes the compacted list (p.tilesM = its length)
+        const int e = __builtin_amdgcn_readfirstlane(p.rt_map[tm]);
+        if (p.rt_tpb) { bz = e / p.rt_tpb; tm = e - bz * p.rt_tpb; }
+        else tm = e;
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const unsigned char* A = p.A + (int64_t)bz * p.sA * 2;
@@ -1367,7 +1393,8 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = fal
     if (dln) {
         if (!fast) return M5_ERR_UNSUPPORTED;
         p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-        const int64_t nb = (int64_t)p.tilesM * p.tilesN * batch;
+        if (!rt_apply<BM>(p, batch)) return M5_ERR_UNSUPPORTED;
+        const int64_t nb = (int64_t)p.tilesM * p.tilesN * (p.rt_map ? 1 : batch);
         if (nb > 0x7fffffff) return M5_ERR_UNSUPPORTED;
         p.nblk = (int)nb;
         p.group_m = max(1, GROUP_M * 128 / BM);
@@ -1399,7 +1426,8 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = fal
         return M5_ERR_UNSUPPORTED;
     }
     p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
-    const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
+    if (!rt_apply<BM>(p, batch)) return M5_ERR_UNSUPPORTED;
+    const int64_t nblk = (int64_t)p.tilesM * p.tilesN * (p.rt_map ? 1 : batch);
     if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
     p.nblk = (int)nblk;
     p.group_m = max(1, GROUP_M * 128 / BM);
@@ -1438,6 +1466,9 @@ static const CfgInfo kCfg[] = {
     {192, 192, 4, 1, 7.f, 1.40f, -2},             // 6: region 192x192, 6 waves (2x3 of 96x64), 3 stages (sweeps: superseded by 2)
     { 96, 128, 4, 1, 8.f, 0.48f, -1},             // 7: = 3 with the prefetched-fragment K loop (PF); 0.45-0.48 us per K-step measured hot
     { 96, 128, 4, 1, 8.f, 0.48f, -2},             // 8: = 7 with 5 stages (140 KB of LDS: five K-steps of DMA in flight)
+    {192, 384, 6, 1, 8.f, 2.10f, -2},             // 9 (tools build, round-4 probe): = 5 with 32-deep K-steps and 4 stages (same 144 KB: three
+                                                  //    half-steps of DMA in flight instead of one whole step)
+    {192, 192, 4, 1, 7.f, 1.20f, -2},             // 10 (tools build): = 2 with 32-deep K-steps and 6 stages
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -1453,6 +1484,10 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool
         case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s, fast, dln);
         case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true, 1>(epi, p, batch, s, fast, dln);
         case 8: return launch16<T, 2, 2, 3, 4, 128, 5, 1, true>(epi, p, batch, s, fast, dln);
+#ifdef M5_TOOLS
+        case 9: return launch16<T, 4, 4, 3, 6, 64, 4, 1>(epi, p, batch, s, fast, dln);
+        case 10: return launch16<T, 4, 3, 3, 4, 64, 6, 1>(epi, p, batch, s, fast, dln);
+#endif
         default: return M5_ERR_ARG;
     }
 }
@@ -1548,7 +1583,8 @@ extern "C" int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const
 // Scores + per-head softmax of the absorbed cross-attention (include/mars5_hip.h, xattn_absorb.hip): P[b] = softmax_heads(
 // X[b] A[b]^T + c[b]) for `batch` sequences, head blocks of Lp = 48 or 64 columns (one per wave), 96-row tiles.
 static int xattn_scores_impl(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
-                             void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl, void* stream) {
+                             void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
+                             const M5RowTiles* rt, void* stream) {
     if (!X || !A || !c || !P || M <= 0 || n_heads <= 0 || K <= 0 || batch <= 0) return M5_ERR_ARG;
     if (dtype != M5_F16 && dtype != M5_BF16) return M5_ERR_UNSUPPORTED;
     if ((Lp != 48 && Lp != 64) || (n_heads % 2) || (K % 64)) return M5_ERR_UNSUPPORTED;
@@ -1573,7 +1609,9 @@ static int xattn_scores_impl(int dtype, const void* X, int64_t ldx, int64_t sX, 
     const bool off32 = true;
     const int BM = cfg == 1 ? 64 : (cfg == 2 ? 128 : 96);
     p.tilesM = (M + BM - 1) / BM; p.tilesN = p.N / BN;
-    const int64_t nblk = (int64_t)p.tilesM * p.tilesN * batch;
+    p.rt_host = rt;
+    if (rt && (BM != 96 || !rt_apply<96>(p, batch))) return M5_ERR_UNSUPPORTED;
+    const int64_t nblk = (int64_t)p.tilesM * p.tilesN * (p.rt_map ? 1 : batch);
     if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
     p.nblk = (int)nblk; p.group_m = max(1, GROUP_M * 128 / BM);
     const dim3 grid(p.nblk);
@@ -1605,16 +1643,15 @@ static int xattn_scores_impl(int dtype, const void* X, int64_t ldx, int64_t sX, 
 
 extern "C" int m5_xattn_scores(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
                                void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, void* stream) {
-    return xattn_scores_impl(dtype, X, ldx, sX, A, sA_tab, c, sc_tab, P, ldp, sP, M, n_heads, Lp, K, batch, nullptr, stream);
+    return xattn_scores_impl(dtype, X, ldx, sX, A, sA_tab, c, sc_tab, P, ldp, sP, M, n_heads, Lp, K, batch, nullptr, nullptr, stream);
 }
 
-// ... with the LayerNorm that produced X deferred into the epilogue (M5DeferredLN, mode 2): X is the centred copy, A the
-// operands built from the gamma-folded query weights.
-extern "C" int m5_xattn_scores_dln(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
-                                   void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
-                                   void* stream) {
-    if (!dl) return M5_ERR_ARG;
-    return xattn_scores_impl(dtype, X, ldx, sX, A, sA_tab, c, sc_tab, P, ldp, sP, M, n_heads, Lp, K, batch, dl, stream);
+// ... optionally with the LayerNorm that produced X deferred into the epilogue (M5DeferredLN, mode 2: X is the centred copy, A
+// the operands built from the gamma-folded query weights) and / or over a row-tile list (M5RowTiles).
+extern "C" int m5_xattn_scores_ex(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
+                                  void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
+                                  const M5RowTiles* rt, void* stream) {
+    return xattn_scores_impl(dtype, X, ldx, sX, A, sA_tab, c, sc_tab, P, ldp, sP, M, n_heads, Lp, K, batch, dl, rt, stream);
 }
 
 // Residual GEMM with the following LayerNorm fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
@@ -1666,8 +1703,10 @@ extern "C" int m5_debug_gemm_clock(unsigned long long* buf) {   // diagnostics (
 // Called by m5_gemm (gemm.hip) for F16 / BF16 operands after argument validation.
 int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                        void* C, int64_t ldc, int M, int N, int K, int epi, const M5QkvScatter* sc, const int* sec_kind,
-                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s, const M5DeferredLN* dl) {
+                       int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, hipStream_t s, const M5DeferredLN* dl,
+                       const M5RowTiles* rt) {
     Gemm16Params p{};
+    p.rt_host = rt;
     p.A = (const unsigned char*)A; p.W = (const unsigned char*)W; p.bias = bias; p.C = (unsigned char*)C;
     p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.sA = sA; p.sW = sW; p.sC = sC; p.sBias = sBias;
     int dln = 0;

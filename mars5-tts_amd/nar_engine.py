@@ -30,7 +30,7 @@ import torch
 
 from . import _lib as L
 from . import ops
-from .blocks import (LAYERNORM_EPS, AbsorbedCross, CrossMemory, DeferredLN, SeqWorkspace, SpeakerEncoder, cross_attn_block,
+from .blocks import (LAYERNORM_EPS, AbsorbedCross, CrossMemory, DeferredLN, RowTiles, SeqWorkspace, SpeakerEncoder, cross_attn_block,
                      cross_memory_table, decoder_layer, decoder_layer_dln, encoder_layer, ff_block, make_cross_plan, pack_layer,
                      plan_allows_dln, residual_gemm, round_up, self_attn_block)
 from .synth import NARShape
@@ -600,8 +600,15 @@ class NARBatchSession:
         S_max = max(sub.S for sub in self.subs)
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):
-            self.ws = SeqWorkspace(U * nb, S_max, D, FF, dt, dev, row_pad=64)
+            # Deferred LayerNorms + row-tile lists (every utterance on the absorbed cross-attention path): sequences start on
+            # 384-row boundaries and the GEMMs / attention skip the tiles that hold only padding -- a group no longer pays for
+            # being padded to its longest member.  M5_NAR_ROWTILES=0: A/B knob (tools/nar_batch_bench.py).
+            want_dln = DeferredLN.eligible(D, dt) and os.environ.get("M5_NAR_DLN", "1") != "0"
+            all_abs = all(AbsorbedCross.lp_of(sub.mems[0].Le, D // 64) > 0 and sub.mems[0].v_rows is not None for sub in self.subs)
+            use_rt = want_dln and all_abs and os.environ.get("M5_NAR_ROWTILES", "1") != "0"
+            self.ws = SeqWorkspace(U * nb, S_max, D, FF, dt, dev, row_pad=RowTiles.ALIGN if use_rt else 64)
             self.Sr = Sr = self.ws.Sr
+            self.rt = RowTiles([sub.S for sub in self.subs for _ in range(nb)], Sr, dev) if use_rt else None
             self.key_len = torch.tensor([sub.S for sub in self.subs for _ in range(nb)], dtype=torch.int32, device=dev)
             self.h = torch.zeros(U * nb, Sr, D, dtype=torch.float32, device=dev)
             self.hf = torch.zeros(U * nb * Sr, D, dtype=torch.float32, device=dev)
@@ -616,9 +623,10 @@ class NARBatchSession:
             self.logits = torch.empty(self.R, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
-            want_dln = DeferredLN.eligible(D, dt) and os.environ.get("M5_NAR_DLN", "1") != "0"
             self.plan = make_cross_plan(mdl.dec, [[sub.mems[l] for sub in self.subs] for l in range(len(mdl.dec))], D, dt, dev, dln=want_dln)
             self.dl = DeferredLN(self.ws, dev) if (want_dln and plan_allows_dln(self.plan)) else None
+            if self.dl is None:
+                assert self.rt is None, "row-tile lists need the deferred-LayerNorm path"
         self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
         self._ring = None
         self.graph = None
@@ -636,7 +644,7 @@ class NARBatchSession:
         for l, lw in enumerate(mdl.dec):
             if self.dl is not None:
                 decoder_layer_dln(hx, lw, self.ws, self.step_ptr, self.dl, self.plan, l, chain_in=l > 0, chain_out=l + 1 < nl, stream=st,
-                                  key_len=self.key_len, before_cross=join if l == 0 else None)
+                                  key_len=self.key_len, before_cross=join if l == 0 else None, rt=self.rt)
                 continue
             decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l,
                           before_cross=join if l == 0 else None)

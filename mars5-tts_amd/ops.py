@@ -49,11 +49,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int
                       C.byref(scatter) if scatter is not None else None, batch, sA, sW, sC, sBias, _s(stream)), "m5_gemm")
 
 
-def gemm_dln(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int, dl: L.DeferredLN, bias: Optional[torch.Tensor] = None,
+def gemm_dln(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int, dl: Optional[L.DeferredLN], bias: Optional[torch.Tensor] = None,
              scatter: Optional[L.QkvScatter] = None, M: Optional[int] = None, ldc: Optional[int] = None,
-             batch: int = 1, sA: int = 0, sW: int = 0, sC: int = 0, sBias: int = 0, stream: Optional[int] = None) -> None:
+             batch: int = 1, sA: int = 0, sW: int = 0, sC: int = 0, sBias: int = 0, stream: Optional[int] = None,
+             rt: Optional[L.RowTiles] = None) -> None:
     """``gemm`` with a deferred LayerNorm (include/mars5_hip.h, M5DeferredLN): epi RESIDUAL = the producer (also writes the
-    centred copy + row partials), QKV / SWIGLU = a consumer (applies the normalisation in its epilogue)."""
+    centred copy + row partials), QKV / SWIGLU = a consumer (applies the normalisation in its epilogue); and / or over a
+    row-tile list `rt` (M5RowTiles: only the tiles that hold real rows of a padded batch are launched)."""
     assert a.dtype == w.dtype and a.stride(-1) == 1 and w.stride(-1) == 1
     Mv = a.shape[-2] if M is None else M
     N, K = w.shape[-2], w.shape[-1]
@@ -61,16 +63,18 @@ def gemm_dln(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi:
     if bias is not None:
         assert bias.dtype == torch.float32
     ld = ldc if ldc is not None else (out.stride(-2) if out is not None else 0)
-    check(lib.m5_gemm_dln(DT_CODE[a.dtype], _p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(out), ld, Mv, N, K, epi,
-                          C.byref(scatter) if scatter is not None else None, batch, sA, sW, sC, sBias, C.byref(dl), _s(stream)), "m5_gemm_dln")
+    check(lib.m5_gemm_ex(DT_CODE[a.dtype], _p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(out), ld, Mv, N, K, epi,
+                         C.byref(scatter) if scatter is not None else None, batch, sA, sW, sC, sBias, C.byref(dl) if dl is not None else None,
+                         C.byref(rt) if rt is not None else None, _s(stream)), "m5_gemm_ex")
 
 
 def xattn_scores_dln(x: torch.Tensor, sX: int, a_tab: torch.Tensor, c_tab: torch.Tensor, p_out: torch.Tensor, sP: int, M: int, n_heads: int,
-                     Lp: int, batch: int, dl: L.DeferredLN, stream: Optional[int] = None) -> None:
-    """``xattn_scores`` on the centred copy x with the LayerNorm applied in the epilogue (dl.mode = 2)."""
+                     Lp: int, batch: int, dl: Optional[L.DeferredLN], stream: Optional[int] = None, rt: Optional[L.RowTiles] = None) -> None:
+    """``xattn_scores`` on the centred copy x with the LayerNorm applied in the epilogue (dl.mode = 2) and / or over a row-tile list."""
     N, K = n_heads * Lp, x.shape[-1]
-    check(lib.m5_xattn_scores_dln(DT_CODE[x.dtype], _p(x), x.stride(-2), sX, _p(a_tab), N * K, _p(c_tab), N, _p(p_out), p_out.stride(-2), sP,
-                                  M, n_heads, Lp, K, batch, C.byref(dl), _s(stream)), "m5_xattn_scores_dln")
+    check(lib.m5_xattn_scores_ex(DT_CODE[x.dtype], _p(x), x.stride(-2), sX, _p(a_tab), N * K, _p(c_tab), N, _p(p_out), p_out.stride(-2), sP,
+                                 M, n_heads, Lp, K, batch, C.byref(dl) if dl is not None else None, C.byref(rt) if rt is not None else None,
+                                 _s(stream)), "m5_xattn_scores_ex")
 
 
 def layernorm_mean(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, out: torch.Tensor, mean_out: torch.Tensor,

@@ -178,3 +178,23 @@ def test_host_tables_ignore_the_ambient_default_device():
         c = st.expansion_csr()
     for x_, y_ in zip(a[:2], c[:2]):
         assert y_.device.type == "cpu" and torch.equal(x_, y_)
+
+
+def test_row_tile_lists_cover_exactly_the_real_rows():
+    """blocks.RowTiles: for each tile height the listed tiles are exactly those that contain a real row of some sequence of the
+    padded layout, ascending, numbered b * (Sr / BM) + t; the ctypes mirror carries the same counts."""
+    from mars5_tts_amd.blocks import RowTiles
+    lens, Sr = [835, 1, 384, 385, 2237, 2304], 2304
+    rt = RowTiles(lens, Sr, torch.device("cpu"))
+    for i, bm in enumerate((96, 128, 192)):
+        tpb = Sr // bm
+        got = rt.maps[i].tolist()
+        want = [b * tpb + t for b in range(len(lens)) for t in range(tpb) if t * bm < lens[b]]
+        assert got == want == sorted(got) and rt.n[i] == len(want) == int(rt.c.n[i])
+        real_rows = {b * Sr + r for b, n in enumerate(lens) for r in range(n)}
+        covered = {e * bm + r for e in got for r in range(bm)}
+        assert real_rows <= covered and len(covered) - len(real_rows) < len(lens) * bm       # at most one partial tile per sequence
+    assert int(rt.c.rows_per_seq) == Sr
+    import pytest
+    with pytest.raises(AssertionError):
+        RowTiles([10], 320, torch.device("cpu"))                                              # not a multiple of 384
