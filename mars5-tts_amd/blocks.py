@@ -90,8 +90,8 @@ def fold_layer_dln(sd: Dict[str, torch.Tensor], p: str, lw: EncLayerW, act: torc
     lw.in_w_f, lw.in_b_f, lw.in_s = fold(f(f"{p}.self_attn.in_proj_weight"), f(f"{p}.self_attn.in_proj_bias"), f(f"{p}.norm1.weight"), f(f"{p}.norm1.bias"))
     lw.act_w_f, lw.act_b_f, lw.act_s = fold(act, None, f(f"{p}.norm3.weight"), f(f"{p}.norm3.bias"))
     cw, cb = f(f"{p}.multihead_attn.in_proj_weight")[:D], f(f"{p}.multihead_attn.in_proj_bias")[:D]
-    wq_f, lw.ca_q_b_f, lw.ca_q_rs = fold(cw, cb, f(f"{p}.norm2.weight"), f(f"{p}.norm2.bias"))
-    lw.ca_q_wT_f = wq_f.view(H, 64, D).permute(0, 2, 1).contiguous()
+    lw.ca_q_w_f, lw.ca_q_b_f, lw.ca_q_rs = fold(cw, cb, f(f"{p}.norm2.weight"), f(f"{p}.norm2.bias"))
+    lw.ca_q_wT_f = lw.ca_q_w_f.view(H, 64, D).permute(0, 2, 1).contiguous()
 
 
 class DeferredLN:
@@ -345,9 +345,7 @@ class AbsorbedCross:
         r0, rows = self.s0 * ws.Sr, self.n_seq * ws.Sr
         assert N <= ws.FF and self.dln
         P = ws.hff.view(-1)[r0 * N: (r0 + rows) * N].view(rows, N)
-        rc = None
-        if rt is not None:                     # the row tiles of THIS run of sequences (lists are relative to the run's first row)
-            rc = self._rt_c(rt, ws)
+        rc = _rt_sub(rt, self.s0, self.n_seq)      # the row tiles of THIS run of sequences (numbered from the run's first row)
         if consume:
             assert l >= 1
             ops.xattn_scores_dln(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq,
@@ -358,13 +356,6 @@ class AbsorbedCross:
             ops.xattn_scores(ws.xn[r0:], ws.Sr * self.D, self.A[l], self.c[l], P, ws.Sr * N, ws.Sr, self.H, self.Lp, self.n_seq, stream=stream)
         ops.gemm_dln(P, self.Bt[l, 0], x[r0:], L.EPI_RESIDUAL, dl.producer(ws, r0=r0, rows_bs=ws.Sr, advance=last_segment), bias=lw.ca_out_b, M=ws.Sr, batch=self.n_seq,
                      sA=ws.Sr * N, sW=self.D * N, sC=ws.Sr * self.D, sBias=0, stream=stream, rt=rc)
-
-    def _rt_c(self, rt: "RowTiles", ws: "SeqWorkspace"):
-        """Row-tile lists of this run's sequences [s0, s0 + n_seq), numbered from the run's first sequence (cached)."""
-        if getattr(self, "_rt_src", None) is not rt:
-            self._rt_src = rt
-            self._rt_own = RowTiles(rt.lens[self.s0: self.s0 + self.n_seq], ws.Sr, rt.maps[0].device)
-        return self._rt_own.c
 
 
 def make_cross_plan(layers, mems_per_layer, D: int, dt: torch.dtype, dev, dln: bool = False) -> list:
@@ -482,16 +473,63 @@ class RowTiles:
             self.maps.append(torch.tensor(e, dtype=torch.int32, device="cpu").to(dev))
             ns.append(len(e))
         self.n, self.Sr, self.lens = ns, Sr, list(lens)
+        self._subs = {}
         self.c = L.RowTiles(map=(L.vp * 3)(*[m.data_ptr() for m in self.maps]), n=(L.i32 * 3)(*ns), rows_per_seq=Sr)
 
 
+def _rt_sub(rt: Optional[RowTiles], s0: int, n: int):
+    """The ctypes lists of the sequences [s0, s0 + n) of `rt`, numbered from s0 (a launch over that run of the workspace)."""
+    if rt is None:
+        return None
+    if s0 == 0 and n == len(rt.lens):
+        return rt.c
+    key = (s0, n)
+    if key not in rt._subs:
+        rt._subs[key] = RowTiles(rt.lens[s0: s0 + n], rt.Sr, rt.maps[0].device)
+    return rt._subs[key].c
+
+
 def plan_allows_dln(plan) -> bool:
-    return plan is not None and len(plan) > 0 and all(seg[0] == "absorbed" and seg[1].dln for seg in plan)
+    """Every run of utterances can take part in a deferred-LayerNorm chain: absorbed runs built with the folded operands,
+    plain runs (memories of more than 64 rows) through the folded query projection (blocks._plain_cross_dln)."""
+    return plan is not None and len(plan) > 0 and all((seg[0] == "absorbed" and seg[1].dln) or seg[0] == "plain" for seg in plan)
+
+
+def _plain_cross_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, s0: int, s1: int, step_ptr: torch.Tensor, dl: DeferredLN,
+                     consume: bool, last_segment: bool, rt: Optional[RowTiles], stream=None) -> None:
+    """``_plain_cross`` inside a deferred-LayerNorm chain: the query projection is the consumer of norm2 (gamma-folded weights;
+    layer 0: ws.xn = LN2(x) and the plain weights), the out-projection the producer for norm3."""
+    H, S, Sr, D = ws.H, ws.S, ws.Sr, ws.D
+    esz = ws.q.element_size()
+    r0, rows = s0 * Sr, (s1 - s0) * Sr
+    rc = _rt_sub(rt, s0, s1 - s0)
+    sc = ws.scatter(True, False, False)
+    sc.q = ws.q.data_ptr() + s0 * H * Sr * 64 * esz
+    if consume:
+        ops.gemm_dln(ws.xn[r0:r0 + rows], lw.ca_q_w_f, None, L.EPI_QKV, dl.consumer(lw.ca_q_rs, r0=r0, M=rows), bias=lw.ca_q_b_f, scatter=sc,
+                     stream=stream, rt=rc)
+    elif rc is not None:
+        ops.gemm_dln(ws.xn[r0:r0 + rows], lw.ca_q_w, None, L.EPI_QKV, None, bias=lw.ca_q_b, scatter=sc, stream=stream, rt=rc)
+    else:
+        ops.gemm(ws.xn[r0:r0 + rows], lw.ca_q_w, None, L.EPI_QKV, bias=lw.ca_q_b, scatter=sc, stream=stream)
+    b0 = s0
+    for mem in mems:
+        a = L.AttnArgs(q=ws.q.data_ptr() + b0 * H * Sr * 64 * esz, q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64,
+                       k=mem.k.data_ptr(), k_bs=H * mem.Le * 64, k_hs=mem.Le * 64, k_rs=64,
+                       vt=mem.vt.data_ptr(), vt_bs=H * 64 * mem.Lep, vt_hs=64 * mem.Lep, vt_ds=mem.Lep,
+                       o=ws.att.data_ptr() + b0 * Sr * D * esz, o_bs=Sr * D, o_rs=D, B=mem.Bm, H=H, Sq=(rt.lens[b0] if rt is not None else S),
+                       Sk=mem.Le, key_len=None, causal=0, scale=64 ** -0.5, kv_index=step_ptr.data_ptr(),
+                       kv_index_stride_k=mem.Bm * H * mem.Le * 64, kv_index_stride_v=mem.Bm * H * 64 * mem.Lep)
+        ops.attention(ws.dt, a, stream=stream)
+        b0 += mem.Bm
+    assert b0 == s1
+    ops.gemm_dln(ws.att[r0:r0 + rows], lw.ca_out_w, x[r0:r0 + rows], L.EPI_RESIDUAL, dl.producer(ws, r0=r0, rows_bs=rows, advance=last_segment),
+                 bias=lw.ca_out_b, stream=stream, rt=rc)
 
 
 def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr: torch.Tensor, dl: DeferredLN, plan, layer: int,
                       chain_in: bool, chain_out: bool, stream=None, key_len: Optional[torch.Tensor] = None, before_cross=None,
-                      skip_self: bool = False, rt: Optional[RowTiles] = None) -> None:
+                      skip_self: bool = False, rt: Optional[RowTiles] = None, mems=None) -> None:
     """One pre-LN decoder layer with its LayerNorms DEFERRED into the GEMMs that consume them (include/mars5_hip.h,
     M5DeferredLN; reference model.py:179-203, same mathematics): every residual GEMM leaves a centred 16-bit copy of the rows
     it updated (ws.xn) + per-tile row partials, the next projection applies the normalisation in its epilogue -- 3 LayerNorm
@@ -526,7 +564,11 @@ def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr
     if first:
         ops.layernorm_mean(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, dl.start(), stream=stream)
     for i, seg in enumerate(plan):
-        seg[1].block_dln(layer, x, lw, ws, dl, consume=not first, stream=stream, last_segment=i + 1 == len(plan), rt=rt)
+        if seg[0] == "absorbed":
+            seg[1].block_dln(layer, x, lw, ws, dl, consume=not first, stream=stream, last_segment=i + 1 == len(plan), rt=rt)
+        else:
+            _plain_cross_dln(x, lw, ws, [mems[u] for u in seg[3]], seg[1], seg[2], step_ptr, dl, consume=not first,
+                             last_segment=i + 1 == len(plan), rt=rt, stream=stream)
     ops.gemm_dln(ws.xn, lw.act_w_f, ws.hff, L.EPI_SWIGLU, dl.consumer(lw.act_s, M=ws.M), bias=lw.act_b_f, stream=stream, rt=rc)
     if chain_out:
         ops.gemm_dln(ws.hff, lw.l2_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.l2_b, stream=stream, rt=rc)

@@ -410,7 +410,7 @@ class NARSession:
                               rows=S, stream=st)
         for l, lw in enumerate(mdl.dec):
             decoder_layer_dln(hx, lw, self.ws, self.step_ptr, self.dl, self.plan, l, chain_in=l > 0, chain_out=l + 1 < nl, stream=st,
-                              before_cross=join if l == 0 else None, skip_self=(skip0 and l == 0))
+                              before_cross=join if l == 0 else None, skip_self=(skip0 and l == 0), mems=[self.mems[l]])
         join()
 
     def enqueue_forward(self, st: int) -> None:
@@ -604,8 +604,7 @@ class NARBatchSession:
             # 384-row boundaries and the GEMMs / attention skip the tiles that hold only padding -- a group no longer pays for
             # being padded to its longest member.  M5_NAR_ROWTILES=0: A/B knob (tools/nar_batch_bench.py).
             want_dln = DeferredLN.eligible(D, dt) and os.environ.get("M5_NAR_DLN", "1") != "0"
-            all_abs = all(AbsorbedCross.lp_of(sub.mems[0].Le, D // 64) > 0 and sub.mems[0].v_rows is not None for sub in self.subs)
-            use_rt = want_dln and all_abs and os.environ.get("M5_NAR_ROWTILES", "1") != "0"
+            use_rt = want_dln and os.environ.get("M5_NAR_ROWTILES", "1") != "0"
             self.ws = SeqWorkspace(U * nb, S_max, D, FF, dt, dev, row_pad=RowTiles.ALIGN if use_rt else 64)
             self.Sr = Sr = self.ws.Sr
             self.rt = RowTiles([sub.S for sub in self.subs for _ in range(nb)], Sr, dev) if use_rt else None
@@ -644,7 +643,7 @@ class NARBatchSession:
         for l, lw in enumerate(mdl.dec):
             if self.dl is not None:
                 decoder_layer_dln(hx, lw, self.ws, self.step_ptr, self.dl, self.plan, l, chain_in=l > 0, chain_out=l + 1 < nl, stream=st,
-                                  key_len=self.key_len, before_cross=join if l == 0 else None, rt=self.rt)
+                                  key_len=self.key_len, before_cross=join if l == 0 else None, rt=self.rt, mems=[sub.mems[l] for sub in self.subs])
                 continue
             decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l,
                           before_cross=join if l == 0 else None)
