@@ -118,11 +118,14 @@ def parse():
                          "per step (60 s = 4500 generated frames: the AR context passes the 3000-slot rotating KV window)")
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--ar-batch", type=int, default=32)
-    ap.add_argument("--nar-batch", type=int, default=8)
+    ap.add_argument("--nar-batch", type=int, default=16, help="c3: utterances refined together per NAR group (16 since round 4: the row-tile "
+                    "lists make padding a group to its longest member free; 8 before)")
     ap.add_argument("--nar-in-flight", type=int, default=2, help="c3: NAR groups refined at once, each on its own stream")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + rank census only, then exit (no model, no GPU work): with --backend gloo this is how the "
                          "CPU tests check that `--gpus N` really starts N ranks")
+    ap.add_argument("--check-bundle", action="store_true", help="with --launch-check: also build the (tiny) synthetic checkpoint on rank 0 and "
+                    "map it on the other ranks, as the N-rank runs do with the full one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on the GPU box)")
     return ap.parse_args()
 
@@ -158,12 +161,20 @@ def launch_check(args, world: int, rank: int) -> None:
         dist.init_process_group(backend=args.backend)
         census = sh.rank_census()
         seen = sh.LAST_STATS["ranks_seen"]
+        shared = None
+        if args.check_bundle:
+            # the synthetic checkpoint as the N-rank runs get it: built on rank 0, mapped by the others; every rank reports a checksum
+            b = shared_bundle(world, rank, size="tiny")
+            cs = float(sum(float(v.double().sum()) for v in b.ar_ckpt["model"].values()) + sum(float(v.double().sum()) for v in b.nar_ckpt["model"].values()))
+            allcs = [None] * world
+            dist.all_gather_object(allcs, cs)
+            shared = {"checksums_equal": len(set(allcs)) == 1, "ranks": world, "leftover_file": os.path.exists(f"/dev/shm/m5_bench_bundle_{os.environ.get('MASTER_PORT', '0')}.pt")}
         dist.barrier()
         dist.destroy_process_group()
     else:
-        census, seen = [dict(rank=0)], 1
+        census, seen, shared = [dict(rank=0)], 1, None
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": seen, "requested": args.gpus, "world_size_env": world,
+        print(json.dumps({"launch_check": True, "n_gpus": seen, "requested": args.gpus, "world_size_env": world, "shared_bundle": shared,
                           "collective": {"backend": args.backend if world > 1 else None, "ranks_seen": seen, "census": census}}), flush=True)
 
 
@@ -383,11 +394,35 @@ def main_c4(args, m, dev, world, rank, barrier):
     print(json.dumps(out), flush=True)
 
 
-def build_model(dtype_name: str, dev):
-    from inference import Mars5TTS
+def shared_bundle(world: int, rank: int, size: str = "full"):
+    """The seeded synthetic checkpoint of the real geometry (1.2 B parameters, ~11 s of host time to synthesise).  With N ranks
+    on one node rank 0 builds it ONCE and the others map it from /dev/shm (eight concurrent builds would fight over the host
+    cores inside the driver's timeout); the file is keyed by MASTER_PORT (one per job) and removed by rank 0 afterwards."""
     from mars5_tts_amd import synth
+    if world <= 1:
+        return synth.make_bundle(size, seed=0)
+    import torch.distributed as dist
+    path = f"/dev/shm/m5_bench_bundle_{os.environ.get('MASTER_PORT', '0')}.pt"
+    if rank == 0:
+        b = synth.make_bundle(size, seed=0)
+        torch.save(b, path + ".tmp")
+        os.replace(path + ".tmp", path)
+    dist.barrier()
+    if rank != 0:
+        b = torch.load(path, map_location="cpu", weights_only=False, mmap=True)
+    dist.barrier()
+    if rank == 0:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return b
+
+
+def build_model(dtype_name: str, dev, world: int = 1, rank: int = 0):
+    from inference import Mars5TTS
     from mars5_tts_amd.ops import DT_NAME
-    bundle = synth.make_bundle("full", seed=0)
+    bundle = shared_bundle(world, rank)
     m = Mars5TTS(bundle.ar_ckpt, bundle.nar_ckpt, device=str(dev), codec=False, vocos=False)
     m.codeclm.set_engine_dtype(DT_NAME[dtype_name])
     m.codecnar.set_engine_dtype(DT_NAME[dtype_name])
@@ -855,7 +890,7 @@ def main():
         workload_name = ("BASELINE configs[4]: long-form single utterance deep-clone, 60 s target (4500 generated frames, ~150-word "
                          "text), 6 s / 450-frame synthetic reference, temperature=0.7 top_k=100, hipGraph AR decode step over the "
                          "3000-slot rotating KV window, 200 DDPM steps x CFG at S = 5399, seeded random weights of the real geometry")
-    m, bundle = build_model(args.dtype, dev)
+    m, bundle = build_model(args.dtype, dev, world, rank)
     ref_codes = synth.make_ref_codes(args.ref_frames, seed=7).to(dev)
     p_len, n_text_tok = prompt_len(m, ref_codes)
     cfg = make_cfg(n_text_tok, p_len, args.n_gen)

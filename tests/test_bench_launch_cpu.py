@@ -39,3 +39,12 @@ def test_gpus_more_than_visible_devices_fails_loudly():
 def test_world_size_mismatch_is_an_error():
     r = _run(["--gpus", "4", "--launch-check", "--backend", "gloo"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_synthetic_checkpoint_is_built_once_and_shared():
+    """N ranks on one node: rank 0 synthesises the checkpoint, the others map it from /dev/shm (bench.shared_bundle) -- same
+    weights on every rank, no file left behind."""
+    r = _run(["--gpus", "2", "--launch-check", "--check-bundle", "--backend", "gloo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["shared_bundle"] == {"checksums_equal": True, "ranks": 2, "leftover_file": False}
