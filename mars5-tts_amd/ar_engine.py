@@ -299,6 +299,16 @@ class ARSession:
         self.enqueue_head_and_sample(st)
         self.graph = ops.Graph().end(st)
 
+    def _launch_steps(self, n: int, use_graph: bool, st: int) -> None:
+        """Enqueue n decode steps (persistent launches under the per-device exclusive lock)."""
+        with (_mega_exclusive(self.stream, self.m.dev) if self.mega else contextlib.nullcontext()):
+            for _ in range(n):
+                if use_graph:
+                    self.graph.launch(st)
+                else:
+                    self.enqueue_layers(st)
+                    self.enqueue_head_and_sample(st)
+
     def decode(self, use_graph: bool = True, poll: int = 32, noise_fill=None) -> torch.Tensor:
         """Run sampler for the prefill logits, then decode steps until EOS / max_len.
         Returns the token sequence (prompt + generated) like ``ar_generate`` (EOS not appended).
@@ -330,28 +340,26 @@ class ARSession:
         # runs on a stale residual stream; the host then restores this point, switches the session to the per-launch form
         # (bit-identical arithmetic, tests/test_gpu_parity16.py) and replays from there -- the request is never lost.
         snap = None
+        kv_snap = None            # past the wrap of the rotating cache: the rows the next batch overwrites (see below)
         self.mega_recovered = 0
+        pos_host = self.P         # the host's copy of state[ST_POS] at the last poll (the cache row the next launch writes, or the one before)
         if self.mega:
             with torch.cuda.stream(self.stream):
                 snap = (0, self.state.clone(), self.xdec.clone())
         while done < budget:
             n = min(poll, budget - done)
             need(done + n + 1)                                 # the n steps below read rows done+1 .. done+n
-            with (_mega_exclusive(self.stream, self.m.dev) if self.mega else contextlib.nullcontext()):
-                for _ in range(n):
-                    if use_graph:
-                        self.graph.launch(st)
-                    else:
-                        self.enqueue_layers(st)
-                        self.enqueue_head_and_sample(st)
-            done += n
-            inject = getattr(self, "_inject_mega_err_at", None)         # tests only: the kernel's sticky error word, set from outside
-            if self.mega and inject is not None and done >= inject:
-                self._inject_mega_err_at = None
+            if self.mega and self.w_alloc == self.window and pos_host + n + 1 > self.window:
+                # The cache has wrapped (or wraps inside this batch): the batch overwrites rows that still hold positions
+                # pos - window .., which a replay from the recovery point attends to.  Keep those rows (<= poll per layer and
+                # head, a few MB) so that a recovery restores the cache too, not only the state words and the residual stream.
                 with torch.cuda.stream(self.stream):
-                    self.mega_err.fill_(1)
-                    self.xdec.mul_(0.5)                                # ... and what it leaves behind: a residual stream that is not the step's
-                    self.state[L.ST_POS] += 3
+                    slots = torch.tensor(sorted({(pos_host + i) % self.window for i in range(n + 2)}), dtype=torch.long, device="cpu").to(self.m.dev)
+                    kv_snap = (slots, self.kc.index_select(2, slots), self.vc.index_select(2, slots))
+            else:
+                kv_snap = None
+            self._launch_steps(n, use_graph, st)
+            done += n
             with torch.cuda.stream(self.stream):
                 flag = self.state.cpu()                        # syncs this stream only
                 bad = bool(int(self.mega_err.cpu()[0])) if self.mega else False
@@ -361,12 +369,16 @@ class ARSession:
                     self.state.copy_(st0)
                     self.xdec.copy_(x0)
                     self.mega_err.zero_()
+                    if kv_snap is not None:
+                        self.kc.index_copy_(2, kv_snap[0], kv_snap[1])
+                        self.vc.index_copy_(2, kv_snap[0], kv_snap[2])
                 self.mega = False
                 self.mega_recovered += 1
                 if use_graph:
                     self.capture()                             # the per-launch form of the step
                 done = done0
                 continue
+            pos_host = int(flag[L.ST_POS])
             if self.mega:
                 with torch.cuda.stream(self.stream):
                     snap = (done, self.state.clone(), self.xdec.clone())

@@ -152,8 +152,12 @@ class SeqWorkspace:
     of 64).  Each sequence occupies Sr = round_up(S, row_pad) rows of the row-major [B*Sr, D]
     activation buffers: with row_pad = 64 every sequence starts on a tile boundary, so the GEMM
     epilogues and the V^T scatter (4 consecutive s per 8-byte store) stay vector-aligned for
-    B > 1.  The pad rows are ordinary finite rows (zero-initialised, never attended to: keys >= S
-    are masked and never loaded); V^T rows are padded to whole 64-key tiles."""
+    B > 1.  The pad rows are ordinary FINITE rows (zero-initialised in a workspace that owns its buffers; a workspace laid
+    `inside` another one inherits whatever finite values the larger one last wrote there), never attended to: keys >= S are
+    masked by index; V^T rows are padded to whole 64-key tiles, and pad key columns of the last tile are multiplied by
+    p = 0 -- which is why every buffer must stay free of Inf / NaN (16-bit engines: an overflow anywhere would leak into
+    real rows of a later sub-problem).  No buffer of a workspace is live across a launch sequence that runs on a workspace
+    laid inside it (tests/test_host_cpu.py::test_workspace_laid_over_a_larger_one_shares_its_front)."""
 
     def __init__(self, B: int, S: int, D: int, FF: int, dt: torch.dtype, dev, row_pad: int = 1, fuse_ln: bool = False,
                  inside: Optional["SeqWorkspace"] = None):

@@ -285,7 +285,7 @@ def clock_stamp(slots: torch.Tensor, i: int, stream: Optional[int] = None) -> No
     check(lib.m5_clock_stamp(slots.data_ptr() + 8 * i, _s(stream)), "m5_clock_stamp")
 
 
-_SESSION_STREAMS: dict = {}
+_SESSION_TLS = threading.local()      # per host thread: {(device index, role): stream}; the entries die with their thread
 
 
 def session_stream(dev, role: str) -> torch.cuda.Stream:
@@ -294,13 +294,20 @@ def session_stream(dev, role: str) -> torch.cuda.Stream:
     allocator keeps freed blocks PER STREAM, so the ~1.2 GB of per-utterance state (hoisted conditioning, workspaces, KV cache)
     was hipMalloc'ed again for every utterance until the pool wrapped around -- 50 ms of host time per utterance in front of the
     decode (tools/host_profile.py).  With one stream per role the blocks of the previous utterance are reused.  Roles keep the
-    concurrency that exists (AR decode beside NAR conditioning; two batch groups in flight); host threads keep their own streams."""
+    concurrency that exists (AR decode beside NAR conditioning; two batch groups in flight); host threads keep their own streams.
+    Consequence to know about: two sessions of the SAME role made on one host thread without an explicit `stream=` share this
+    stream and therefore run one after the other -- pass each its own ``torch.cuda.Stream`` (as ``tts_batch_from_codes`` does
+    for its groups in flight) to overlap them.  The table is thread-local (no lock, no growth in thread-per-request servers:
+    a dead thread's entries go with it); every stream that stays alive keeps its own pool of cached allocator blocks
+    (``torch.cuda.empty_cache()`` returns them)."""
     d = torch.device(dev)
     idx = d.index if d.index is not None else torch.cuda.current_device()
-    key = (idx, role, threading.get_ident())
-    st = _SESSION_STREAMS.get(key)
+    tab = getattr(_SESSION_TLS, "streams", None)
+    if tab is None:
+        tab = _SESSION_TLS.streams = {}
+    st = tab.get((idx, role))
     if st is None:
-        st = _SESSION_STREAMS[key] = torch.cuda.Stream(device=idx)
+        st = tab[(idx, role)] = torch.cuda.Stream(device=idx)
     return st
 
 
