@@ -59,8 +59,18 @@ def run_case(name, M, N, K, epi, bias=True, rpb=None, check=True, pad=0):
     else:
         out = torch.zeros(M, N, dtype=dt, device=dev)
     c0 = out.clone().float() if out is not None else None
+    call = lambda: ops.gemm(a, w, out, epi, bias=b, scatter=sc, stream=st)          # noqa: E731
+    if os.environ.get("DLN") == "1" and epi == L.EPI_RESIDUAL and N % 128 == 0 and N // 128 <= 8:
+        # the deferred-LayerNorm producer form of the residual GEMM (also writes the centred 16-bit copy + row partials)
+        xt = torch.zeros(M, N, dtype=dt, device=dev)
+        part = torch.zeros(M, N // 128, 2, device=dev)
+        cen, cen2 = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+        dl = L.DeferredLN(mode=1, np=N // 128, xt=xt.data_ptr(), ld_xt=N, part=part.data_ptr(), cen_in=cen.data_ptr(), cen_out=cen2.data_ptr(),
+                          delta=None, s=None, s_bs=0, eps=0.0, n_feat=N, rows_bs=M)
+        call = lambda: ops.gemm_dln(a, w, out, epi, dl, bias=b, stream=st)         # noqa: E731
+        name = name + " +dln-producer"
     with torch.cuda.stream(stream):
-        ops.gemm(a, w, out, epi, bias=b, scatter=sc, stream=st)
+        call()
     stream.synchronize()
     err = None
     if check:
@@ -87,7 +97,7 @@ def run_case(name, M, N, K, epi, bias=True, rpb=None, check=True, pad=0):
         stream.synchronize()
         ops.Graph.begin(st)
         for _ in range(REP):
-            ops.gemm(a, w, out, epi, bias=b, scatter=sc, stream=st)
+            call()
         gr = ops.Graph().end(st)
         gr.launch(st)
         stream.synchronize()
