@@ -124,6 +124,8 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous + rank census only, then exit (no model, no GPU work): with --backend gloo this is how the "
                          "CPU tests check that `--gpus N` really starts N ranks")
+    ap.add_argument("--c4-per-request", action="store_true", help="c4: every rank runs its shard request by request (round 1-3 behaviour) instead of "
+                    "refining it in NAR groups (tts_batch_from_ids; identical results)")
     ap.add_argument("--check-bundle", action="store_true", help="with --launch-check: also build the (tiny) synthetic checkpoint on rank 0 and "
                     "map it on the other ranks, as the N-rank runs do with the full one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on the GPU box)")
@@ -311,6 +313,19 @@ def request_worker(m, base_cfg):
     return work
 
 
+def request_batch_worker(m, base_cfg, nar_batch: int, nar_in_flight: int):
+    """A rank's whole shard through ``Mars5TTS.tts_batch_from_ids``: AR request by request (bit-exact batch-1 decode), NAR in
+    groups -- result i is bit-identical to ``request_worker`` on request i (bench.verify_remote checks exactly that)."""
+    def work(shard):
+        if not shard:
+            return []
+        outs = m.tts_batch_from_ids([r.text_ids for r in shard], [r.ref_codes.T.contiguous()[None].to(m.device) for r in shard],
+                                    [int(r.n_phones_gen) for r in shard], base_cfg, seeds=[int(r.seed) for r in shard], nar_batch=nar_batch,
+                                    ar_batch=1, max_lens=[int(r.max_len) for r in shard], nar_in_flight=nar_in_flight)
+        return [final.cpu() for _, final in outs]
+    return work
+
+
 def c4_requests(m, n: int, n_gen: int, factor: float, seed: int = 11):
     """SURVEY 8(d) config 4 = config 3's request generator, in the wire format of ``sharding.Request``."""
     from mars5_tts_amd.sharding import Request
@@ -351,10 +366,13 @@ def main_c4(args, m, dev, world, rank, barrier):
     n_total = args.batch * world
     reqs = c4_requests(m, n_total, args.n_gen, cfg.eos_estimated_gen_length_factor, seed=11)      # every rank can rebuild them (verification)
     work = request_worker(m, cfg)
+    bwork = None if args.c4_per_request else request_batch_worker(m, cfg, args.nar_batch, args.nar_in_flight)
 
     def step():
         if world > 1:
-            return sh.run_sharded(reqs if rank == 0 else None, n_total, work, src=0)
+            return sh.run_sharded(reqs if rank == 0 else None, n_total, work, src=0, batch_worker=bwork)
+        if bwork is not None:
+            return bwork(reqs)
         return [work(r) for r in reqs]
 
     if args.warmup:
@@ -368,6 +386,9 @@ def main_c4(args, m, dev, world, rank, barrier):
     elapsed = time.perf_counter() - t0
     frames = float(sum(int(o.shape[0]) for o in outs)) * args.steps if rank == 0 else 0.0
     collective = None
+    checked_local = None
+    if world == 1 and bwork is not None:          # one rank: the group results against lone seeded calls of two requests
+        checked_local = verify_remote(m, cfg, reqs, set(), outs, k=2)
     if world > 1:
         elapsed, frames = sh.reduce_timing(elapsed, frames)
         census = sh.rank_census()
@@ -385,11 +406,13 @@ def main_c4(args, m, dev, world, rank, barrier):
         "n_gpus": (collective["ranks_seen"] if collective else world), "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"BASELINE configs[3]: {n_total} mixed-length deep-clone requests ({args.batch} per GPU) built on rank 0, "
-                               f"scattered over {world} rank(s) by estimated cost, batch-1 hot path per request, results gathered on rank 0; "
+                               f"scattered over {world} rank(s) by estimated cost, "
+                               + ("batch-1 hot path per request" if args.c4_per_request else f"each rank: batch-1 AR decode per request, NAR in groups of {args.nar_batch} (tts_batch_from_ids)")
+                               + ", results gathered on rank 0; "
                                f"reference 150-900 frames, {args.n_gen} generated frames each, temperature=0.7 top_k=100, 200 DDPM steps x CFG",
                    "requests_per_step": n_total, "reference_frames_min_mean_max": [min(ref_frames), round(sum(ref_frames) / len(ref_frames), 1), max(ref_frames)],
                    "parallelism": f"replicas x{world}, request scatter + result gather over {'RCCL' if world > 1 else 'nothing (single rank)'}"},
-        "collective": collective,
+        "collective": collective, "group_results_rechecked_against_lone_calls": checked_local,
     }
     print(json.dumps(out), flush=True)
 

@@ -224,7 +224,10 @@ class Mars5TTS:
                   ar_noise: Optional[Tensor] = None, generator: Optional[torch.Generator] = None):
         """Prompt construction + AR decode + BPE expansion (reference inference.py:222-285).
         Returns (L0 frames (G,), the ``perform_simple_inference`` batch tuple, frames to skip in front)."""
-        pr = self._prompt(text, prompt_codec, ref_transcript, cfg)
+        return self._ar_stage_pr(self._prompt(text, prompt_codec, ref_transcript, cfg), cfg, ar_noise, generator)
+
+    def _ar_stage_pr(self, pr: dict, cfg: InferenceConfig, ar_noise: Optional[Tensor] = None, generator: Optional[torch.Generator] = None):
+        """``_ar_stage`` for a prompt that is already built (``_prompt`` / ``_prompt_from_ids``)."""
         ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
                                fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
                                n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,
@@ -333,7 +336,7 @@ class Mars5TTS:
     def tts_batch_from_codes(self, texts: List[str], prompt_codecs: List[Tensor], ref_transcripts: List[Optional[str]],
                              cfg: InferenceConfig = InferenceConfig(), seeds: Optional[List[int]] = None,
                              nar_batch: int = 8, ar_batch: int = 1, max_lens: Optional[List[int]] = None,
-                             nar_in_flight: int = 2) -> List[Tuple[Tensor, Tensor]]:
+                             nar_in_flight: int = 2, prompts: Optional[List[dict]] = None) -> List[Tuple[Tensor, Tensor]]:
         """Several independent requests on one GPU (BASELINE config 3).  Request i gets a private
         device generator seeded ``seeds[i]`` and consumes it as a lone call would.
         NAR: up to `nar_batch` requests of similar length are refined per decoder pass
@@ -345,9 +348,12 @@ class Mars5TTS:
         order, like any batch-size change does in the reference).
         `nar_in_flight`: how many NAR groups are refined at once, each on its own stream (a group's 200 dependent step
         graphs leave per-launch bubbles that another group's launches fill, and the host prepares the next group while the
-        previous ones run; results do not depend on it)."""
-        n = len(texts)
-        assert len(prompt_codecs) == n and len(ref_transcripts) == n
+        previous ones run; results do not depend on it).
+        `prompts`: prompts that are already built (``_prompt_from_ids``: requests that arrive tokenised, ``tts_batch_from_ids``);
+        texts / prompt_codecs / ref_transcripts are then unused."""
+        n = len(prompts) if prompts is not None else len(texts)
+        assert prompts is not None or (len(prompt_codecs) == n and len(ref_transcripts) == n)
+        pr_of = (lambda i: prompts[i]) if prompts is not None else (lambda i: self._prompt(texts[i], prompt_codecs[i], ref_transcripts[i], cfg))
         gens = []
         for i in range(n):
             g = torch.Generator(device=self.device)
@@ -359,10 +365,10 @@ class Mars5TTS:
             return cfg if max_lens is None else dataclasses.replace(cfg, generate_max_len_override=int(max_lens[i]))
 
         if ar_batch <= 1:
-            staged = [self._ar_stage(texts[i], prompt_codecs[i], ref_transcripts[i], cfg_of(i), None, gens[i]) for i in range(n)]
+            staged = [self._ar_stage_pr(pr_of(i), cfg_of(i), None, gens[i]) for i in range(n)]
         else:
             assert cfg.beam_width == 1, "Only beam size of 1 is currently supported."
-            prs = [self._prompt(texts[i], prompt_codecs[i], ref_transcripts[i], cfg) for i in range(n)]
+            prs = [pr_of(i) for i in range(n)]
             staged = [None] * n
             order = sorted(range(n), key=lambda i: prs[i]["prompt"].shape[0])
             for g0 in range(0, n, min(ar_batch, 32)):
@@ -398,6 +404,16 @@ class Mars5TTS:
         while flying:
             land()
         return [(staged[i][0], finals[i]) for i in range(n)]
+
+    @torch.inference_mode()
+    def tts_batch_from_ids(self, text_ids: List, prompt_codecs: List[Tensor], n_phones_gens: List[int],
+                           cfg: InferenceConfig = InferenceConfig(), **kw) -> List[Tuple[Tensor, Tensor]]:
+        """``tts_batch_from_codes`` for requests that arrive already tokenised (the wire format of the multi-GPU request scatter,
+        ``mars5_tts_amd.sharding.Request``; see ``tts_from_ids``): a rank refines its whole shard in NAR groups instead of request
+        by request.  With ``ar_batch=1`` (the default) result i is bit-identical to ``torch.manual_seed(seeds[i]); tts_from_ids(...)``."""
+        prompts = [self._prompt_from_ids(t.tolist() if isinstance(t, Tensor) else list(t), prompt_codecs[i], int(n_phones_gens[i]), cfg)
+                   for i, t in enumerate(text_ids)]
+        return self.tts_batch_from_codes(None, None, None, cfg, prompts=prompts, **kw)
 
     @torch.inference_mode()
     def tts(self, text: str, ref_audio: Tensor, ref_transcript: Optional[str] = None,

@@ -178,11 +178,16 @@ def rank_census(group=None) -> List[dict]:
     return census
 
 
-def run_sharded(requests: Optional[List[Request]], n_total: int, worker: Callable[[Request], torch.Tensor],
-                src: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+def run_sharded(requests: Optional[List[Request]], n_total: int, worker: Optional[Callable[[Request], torch.Tensor]],
+                src: int = 0, group=None, batch_worker: Optional[Callable[[List[Request]], List[torch.Tensor]]] = None) -> Optional[List[torch.Tensor]]:
     """scatter -> each rank runs `worker(request) -> (G, 8) codes` on its shard (seeded per utterance)
-    -> gather on `src`."""
+    -> gather on `src`.  `batch_worker(shard) -> [codes]` instead hands a rank its whole shard at once (it seeds per request
+    itself: ``Mars5TTS.tts_batch_from_ids``), so that the rank can refine its requests in groups."""
     shard = scatter_requests(requests, src=src, group=group)
+    if batch_worker is not None:
+        outs = batch_worker(shard) if shard else []
+        assert len(outs) == len(shard)
+        return gather_results([(r.idx, o) for r, o in zip(shard, outs)], n_total, dst=src, group=group)
     done = []
     for r in shard:
         torch.manual_seed(r.seed)

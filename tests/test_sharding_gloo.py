@@ -90,19 +90,23 @@ def _cpu_tts(tiny_vocab):
     def fake_begin(model, c_text, c_codes, T, dsh=None, div_mode=0, diff=None, **kw):
         return None
 
-    def fake_ar(texttok, speechtok, codeclm, xx, ss_gen, first_codex_idx, max_len=1500, **kw):
+    def fake_ar(texttok, speechtok, codeclm, xx, ss_gen, first_codex_idx, max_len=1500, generator=None, **kw):
         n = min(int(max_len) - int(xx.shape[0]), 9 + int(ss_gen.shape[0]) % 5)
         n_text = len(texttok.vocab)
-        new = torch.randint(n_text, n_text + 1024, (max(n, 0),))           # global generator: seeded per request by run_sharded
+        new = torch.randint(n_text, n_text + 1024, (max(n, 0),), generator=generator)   # global generator (seeded per request by run_sharded) or the request's own
         return torch.cat([xx.cpu(), new])
 
     def fake_nar(model, batch, diff, T, dtype=None, retain_quant0=True, dsh=None, generator=None, session=None, **kw):
         c_codes, x = batch[1], batch[4]
         out = x.clone()
-        out[..., 1:] = torch.randint(0, 1024, out[..., 1:].shape)
+        out[..., 1:] = torch.randint(0, 1024, out[..., 1:].shape, generator=generator)
         if dsh.deep_clone:
             out = torch.cat([c_codes.to(out.dtype), out], dim=1)
         return out
+
+    def fake_nar_batch(model, batches, diff, T, dsh=None, generators=None, wait=True, stream=None, **kw):
+        outs = [fake_nar(model, b, diff, T, dsh=dsh, generator=g) for b, g in zip(batches, generators)]     # request i draws from ITS generator
+        return outs if wait else (lambda: outs)
 
     def fake_expand(tokens, n_text, off, vals, max_run, stream=None):       # CPU stand-in of m5_expand_tokens (same CSR table)
         out = []
@@ -111,6 +115,7 @@ def _cpu_tts(tiny_vocab):
         return torch.tensor(out, dtype=torch.long)
 
     inf.begin_inference, inf.ar_generate, inf.perform_simple_inference = fake_begin, fake_ar, fake_nar
+    inf.perform_batch_inference = fake_nar_batch
     inf.ops.expand_tokens = fake_expand
     m = inf.Mars5TTS.__new__(inf.Mars5TTS)
     m.device = torch.device("cpu")
@@ -162,9 +167,16 @@ def _host_worker(rank: int, world: int, port: int, ok):
             parts = sh.lpt_partition([sh.estimate_cost(r) for r in reqs], world)
             assert bench.verify_remote(m, cfg, reqs, set(parts[0]), out, k=2) == 2
             for r in reqs:                                        # and the whole batch equals a single-process run
+                torch.manual_seed(r.seed)
                 assert torch.equal(out[r.idx], work(r)), r.idx
                 assert out[r.idx].shape[1] == 8 and out[r.idx].shape[0] >= 1
             assert sh.LAST_STATS["gather_bytes"] == sum(8 * (2 + o.numel()) for o in out) + 8 * world
+        # the same shard handed to the rank AT ONCE (bench.py --workload c4 since round 4: Mars5TTS.tts_batch_from_ids refines a
+        # rank's requests in NAR groups): identical codes, request by request
+        bwork = bench.request_batch_worker(m, cfg, nar_batch=4, nar_in_flight=2)
+        out_b = sh.run_sharded(reqs if rank == 0 else None, len(reqs), None, src=0, batch_worker=bwork)
+        if rank == 0:
+            assert all(torch.equal(a, b) for a, b in zip(out, out_b))
             ok.value = 1
     finally:
         dist.destroy_process_group()
