@@ -512,7 +512,7 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     st = sess.stream.cuda_stream
     es = 2 if dtype_name != "f32" else 4
     names_epi = {L.EPI_F32: "F32", L.EPI_RESIDUAL: "RESIDUAL", L.EPI_SWIGLU: "SWIGLU", L.EPI_QKV: "QKV", L.EPI_DT: "DT", L.EPI_SILU_DT: "SILU"}
-    orig = {k: getattr(ops, k) for k in ("gemm", "gemm_dln", "attention", "layernorm", "layernorm_mean", "xattn_scores", "xattn_scores_dln",
+    orig = {k: getattr(ops, k) for k in ("gemm", "gemm_dln", "attention", "layernorm", "layernorm_mean", "layernorm_twice", "xattn_scores", "xattn_scores_dln",
                                          "xattn_absorb", "chunked_embed")}
 
     slots = torch.zeros(2048, dtype=torch.int64, device=m.device)
@@ -548,6 +548,9 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     ops.layernorm_mean = timed(orig["layernorm_mean"], lambda x_, g_, b_, eps, out, mo, **kw: f"layernorm_vec_kernel D={x_.shape[-1]} affine=1 +mean",
                                lambda *a, **kw: 0.0,
                                lambda x_, g_, b_, eps, out, mo, **kw: float((kw.get("M") or x_.shape[0]) * x_.shape[-1] * (4 + out.element_size())))
+    ops.layernorm_twice = timed(orig["layernorm_twice"], lambda x_, g_, b_, eps, eps2, out, rps, **kw: f"layernorm_twice_vec_kernel D={x_.shape[-1]}",
+                                lambda *a, **kw: 0.0,
+                                lambda x_, g_, b_, eps, eps2, out, rps, **kw: float(rps * kw.get("n_seq", 1) * x_.shape[-1] * (4 + out.element_size())))
     ops.xattn_scores_dln = timed(orig["xattn_scores_dln"], lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: f"gemm16_kernel<EPI_SOFTMAX_HEADS> M={M * batch} N={H * Lp} K={x_.shape[-1]} +dln-consumer",
                                  lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: 2.0 * M * batch * H * Lp * x_.shape[-1],
                                  lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: float(M * batch * (x_.shape[-1] + H * Lp) * es + batch * H * Lp * x_.shape[-1] * es))

@@ -199,6 +199,12 @@ M5_API int m5_gemm_ex(int dtype, const void* A, int64_t lda, const void* W, int6
 M5_API int m5_xattn_scores_ex(int dtype, const void* X, int64_t ldx, int64_t sX, const void* A, int64_t sA_tab, const float* c, int64_t sc_tab,
                        void* P, int64_t ldp, int64_t sP, int M, int n_heads, int Lp, int K, int batch, const M5DeferredLN* dl,
                        const M5RowTiles* rt, void* stream);
+/* y = normalise(LayerNorm(x; gamma, beta, eps); eps2) without a second affine, one pass: the NAR output heads' LayerNorm on top of
+ * the decoder's final LayerNorm (model.py:236-242,342) -- the seven heads share the statistics, their gamma / beta are folded
+ * into the head weights, so one normalised copy serves all heads.  Rows: n_seq runs of rows_per_seq rows; run s of x starts
+ * x_seq_stride rows after run s - 1, y is packed.  Vector rows only (D % 256 == 0, 16-byte aligned). */
+M5_API int m5_layernorm_twice(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float eps2,
+                       void* y, int64_t ldy, int rows_per_seq, int n_seq, int64_t x_seq_stride, int D, void* stream);
 M5_API int m5_layernorm_mean(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                       void* y, int64_t ldy, int M, int D, float* mean_out, void* stream);
 

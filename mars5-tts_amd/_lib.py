@@ -143,6 +143,7 @@ PROTOTYPES = {
                              C.POINTER(QkvScatter), C.c_int, i64, i64, i64, i64, C.POINTER(DeferredLN), C.POINTER(RowTiles), vp]),
     "m5_xattn_scores_ex": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(DeferredLN), C.POINTER(RowTiles), vp]),
+    "m5_layernorm_twice": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, f32, vp, i64, C.c_int, C.c_int, i64, C.c_int, vp]),
     "m5_layernorm_mean": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, vp, vp]),
     "m5_layernorm": (C.c_int, [C.c_int, vp, i64, vp, vp, f32, vp, i64, C.c_int, C.c_int, C.c_int, i64, i64, vp]),
     "m5_rmsnorm": (C.c_int, [C.c_int, vp, i64, vp, f32, vp, i64, C.c_int, C.c_int, vp]),

@@ -101,6 +101,91 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* x, int6
     }
 }
 
+// LayerNorm (gamma, beta, eps) followed by a second, affine-free normalisation (eps2) of its fp32 result, in one pass over the
+// row: the NAR output heads (reference model.py:236-242,342) apply their own LayerNorm to the decoder's final LayerNorm output;
+// the seven heads' statistics are the same, so ONE normalised copy serves all of them once their gamma / beta are folded into
+// the head weights (nar_engine.NARModel).  Rows come in n_seq runs of rows_per_seq (x: run s starts x_seq_stride rows
+// after run s - 1; y: packed).
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_twice_vec_kernel(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                                                  float eps2, typename T::storage* y, int64_t ldy, int rows_per_seq, int n_seq,
+                                                                  int64_t x_seq_stride) {
+    using st = typename T::storage;
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows_per_seq * n_seq) return;
+    const int sq = row / rows_per_seq, r = row - sq * rows_per_seq;
+    const float* xr = x + ((int64_t)sq * x_seq_stride + r) * ldx;
+    float4 v[NV], g0[NV], b0[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + (lane + 64 * i) * 4);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g0[i] = *reinterpret_cast<const float4*>(gamma + (lane + 64 * i) * 4);
+        b0[i] = *reinterpret_cast<const float4*>(beta + (lane + 64 * i) * 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+        q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {          // the first LayerNorm's output, exactly as layernorm_vec_kernel computes it (fp32)
+        v[i].x = v[i].x * rstd * g0[i].x + b0[i].x; v[i].y = v[i].y * rstd * g0[i].y + b0[i].y;
+        v[i].z = v[i].z * rstd * g0[i].z + b0[i].z; v[i].w = v[i].w * rstd * g0[i].w + b0[i].w;
+        s2 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean2 = wave_sum(s2) / (float)D;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i].x -= mean2; v[i].y -= mean2; v[i].z -= mean2; v[i].w -= mean2;
+        q2 += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+    }
+    const float rstd2 = 1.0f / sqrtf(wave_sum(q2) / (float)D + eps2);
+    st* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        const float o[4] = {v[i].x * rstd2, v[i].y * rstd2, v[i].z * rstd2, v[i].w * rstd2};
+        if constexpr (sizeof(st) == 4) {
+            *reinterpret_cast<float4*>(yr + c) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            st t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = T::from_f32(o[e]);
+            *reinterpret_cast<uint2*>(yr + c) = *reinterpret_cast<const uint2*>(t);
+        }
+    }
+}
+
+template <typename T>
+bool launch_ln_twice(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float eps2, void* y, int64_t ldy,
+                     int rows_per_seq, int n_seq, int64_t x_seq_stride, int D, hipStream_t s) {
+    using st = typename T::storage;
+    const int es = sizeof(st);
+    if (D % 256 || (ldx % 4) || (ldy * es % (es == 4 ? 16 : 8)) || (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y) & 15)) return false;
+    dim3 grid((rows_per_seq * n_seq + 3) / 4);
+#define M5_LN2(NV) hipLaunchKernelGGL((layernorm_twice_vec_kernel<T, NV>), grid, dim3(256), 0, s, x, ldx, gamma, beta, eps, eps2, (st*)y, ldy, rows_per_seq, n_seq, x_seq_stride)
+    switch (D / 256) {
+        case 1: M5_LN2(1); break;
+        case 2: M5_LN2(2); break;
+        case 4: M5_LN2(4); break;
+        case 6: M5_LN2(6); break;
+        case 8: M5_LN2(8); break;
+        default: return false;
+    }
+#undef M5_LN2
+    return true;
+}
+
 template <typename T>
 bool launch_ln_vec(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* y, int64_t ldy, int M,
                    int D, int n_affine, int64_t affine_stride, int64_t y_affine_stride, hipStream_t s, float* mean_out = nullptr) {
@@ -398,6 +483,20 @@ extern "C" int m5_layernorm_mean(int out_dtype, const float* x, int64_t ldx, con
     if (out_dtype == M5_F32) done = launch_ln_vec<F32T>(x, ldx, gamma, beta, eps, y, ldy, M, D, 1, 0, 0, s, mean_out);
     else if (out_dtype == M5_F16) done = launch_ln_vec<F16T>(x, ldx, gamma, beta, eps, y, ldy, M, D, 1, 0, 0, s, mean_out);
     else if (out_dtype == M5_BF16) done = launch_ln_vec<BF16T>(x, ldx, gamma, beta, eps, y, ldy, M, D, 1, 0, 0, s, mean_out);
+    else return M5_ERR_ARG;
+    if (!done) return M5_ERR_UNSUPPORTED;
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
+
+extern "C" int m5_layernorm_twice(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float eps2,
+                                  void* y, int64_t ldy, int rows_per_seq, int n_seq, int64_t x_seq_stride, int D, void* stream) {
+    if (!x || !gamma || !beta || !y || rows_per_seq <= 0 || n_seq <= 0 || D <= 0 || x_seq_stride < 0) return M5_ERR_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    bool done = false;
+    if (out_dtype == M5_F32) done = launch_ln_twice<F32T>(x, ldx, gamma, beta, eps, eps2, y, ldy, rows_per_seq, n_seq, x_seq_stride, D, s);
+    else if (out_dtype == M5_F16) done = launch_ln_twice<F16T>(x, ldx, gamma, beta, eps, eps2, y, ldy, rows_per_seq, n_seq, x_seq_stride, D, s);
+    else if (out_dtype == M5_BF16) done = launch_ln_twice<BF16T>(x, ldx, gamma, beta, eps, eps2, y, ldy, rows_per_seq, n_seq, x_seq_stride, D, s);
     else return M5_ERR_ARG;
     if (!done) return M5_ERR_UNSUPPORTED;
     M5_CHECK_LAUNCH();

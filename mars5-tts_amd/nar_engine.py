@@ -61,6 +61,21 @@ class NARModel:
         self.head_b = torch.stack([sd[f"residual_decoder.{q}.0.bias"].float() for q in range(1, Q)]).to(dev).contiguous()
         self.head_w = torch.stack([sd[f"residual_decoder.{q}.1.weight"].float() for q in range(1, Q)]).to(device=dev, dtype=dt).contiguous()
         self.head_bias = torch.stack([sd[f"residual_decoder.{q}.1.bias"].float() for q in range(1, Q)]).to(dev).contiguous()
+        # 16-bit engines: the heads' own LayerNorm (gamma_q, beta_q) folded into their Linear -- all seven heads normalise the same
+        # rows with the same statistics, so ONE affine-free normalised copy (m5_layernorm_twice) feeds ONE GEMM of N = 7 x Kp
+        # columns (Kp = K rounded up to 4: zero rows, so a head's logits start on a 16-byte boundary as before):
+        # W'_q = dtype(W_q diag gamma_q), b'_q = b_q + W_q beta_q.  The fp32 parity engine keeps the reference's order.
+        self.head_wf = self.head_bf = None
+        if dt != torch.float32:
+            Kp = round_up(K, 4)
+            wf = torch.zeros(Q - 1, Kp, D, dtype=dt)
+            bf = torch.zeros(Q - 1, Kp, dtype=torch.float32)
+            for q in range(1, Q):
+                W, b = sd[f"residual_decoder.{q}.1.weight"].float(), sd[f"residual_decoder.{q}.1.bias"].float()
+                g, be = sd[f"residual_decoder.{q}.0.weight"].float(), sd[f"residual_decoder.{q}.0.bias"].float()
+                wf[q - 1, :K] = (W * g[None, :]).to(dt)
+                bf[q - 1, :K] = b + W @ be
+            self.head_wf, self.head_bf = wf.view((Q - 1) * Kp, D).to(dev).contiguous(), bf.view(-1).to(dev).contiguous()
         self.spk = SpeakerEncoder(sd, "ref_embedder", "ref_pos_embedding.alpha", shape.n_spk_layers, dt, dev)
         self.pe = sine_pe(max_frames, D).to(dev)
         self.spk_uncond: Optional[torch.Tensor] = None      # model constant, computed on first use
@@ -333,7 +348,7 @@ class NARSession:
             self.ws0 = SeqWorkspace(1, S, D, FF, dt, dev, row_pad=64, inside=over) if (nb == 2 and share0) else None
             self.h = torch.zeros(nb, Sr, D, dtype=torch.float32, device=dev)
             self.hf = torch.zeros(nb * Sr, D, dtype=torch.float32, device=dev)
-            self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
+            self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)       # (folded heads use the first slab only)
             self.Kp = round_up(K, 4)
             self.logits = torch.empty(nb * self.s_out, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -461,6 +476,12 @@ class NARSession:
         mdl, s = self.m, self.m.shape
         Sr, nb, D, Q = self.Sr, self.nb, s.dim, s.n_codebooks
         so = self.s_out
+        if mdl.head_wf is not None and not compact and os.environ.get("M5_NAR_HEADFOLD", "1") != "0":      # A/B knob (tools/nar_step_bench.py)
+            # final LayerNorm + the heads' (folded) LayerNorm of the generated rows of both branches in one launch, then ONE GEMM
+            ops.layernorm_twice(hx[self.row_offset:], mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, 1e-5, self.hn[0], so, n_seq=nb, x_seq_stride=Sr,
+                                stream=st)
+            ops.gemm(self.hn[0], mdl.head_wf, self.logits.view(nb * so, (Q - 1) * self.Kp), L.EPI_F32, bias=mdl.head_bf, stream=st)
+            return
         if compact:
             hf, hrow = self.hf_l, [b * self.ws_l.Sr for b in range(nb)]
         else:
@@ -648,6 +669,12 @@ class NARBatchSession:
             decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l,
                           before_cross=join if l == 0 else None)
         join()
+        if mdl.head_wf is not None and os.environ.get("M5_NAR_HEADFOLD", "1") != "0":
+            for u, sub in enumerate(self.subs):
+                ops.layernorm_twice(hx[u * nb * Sr + sub.row_offset:], mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, 1e-5, self.hn[0, self.row0[u]:],
+                                    sub.s_out, n_seq=nb, x_seq_stride=Sr, stream=st)
+            ops.gemm(self.hn[0], mdl.head_wf, self.logits.view(self.R, (Q - 1) * self.Kp), L.EPI_F32, bias=mdl.head_bf, stream=st)
+            return
         ops.layernorm(hx, mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, self.hf, stream=st)
         for u, sub in enumerate(self.subs):
             so = sub.s_out

@@ -87,6 +87,15 @@ def layernorm_mean(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps
                                 _p(mean_out), _s(stream)), "m5_layernorm_mean")
 
 
+def layernorm_twice(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, eps2: float, out: torch.Tensor, rows_per_seq: int,
+                    n_seq: int = 1, x_seq_stride: int = 0, stream: Optional[int] = None) -> None:
+    """out (n_seq * rows_per_seq, D) = normalise(LayerNorm(x; gamma, beta, eps); eps2), no second affine; run s of x starts
+    x_seq_stride rows after run s - 1 (include/mars5_hip.h)."""
+    assert x.dtype == torch.float32 and x.stride(-1) == 1 and out.stride(-1) == 1
+    check(lib.m5_layernorm_twice(DT_CODE[out.dtype], _p(x), x.stride(0), _p(gamma), _p(beta), eps, eps2, _p(out), out.stride(-2), rows_per_seq, n_seq,
+                                 x_seq_stride, x.shape[1], _s(stream)), "m5_layernorm_twice")
+
+
 def gemm_q_cross_attn(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], n_heads: int, mem_table: torch.Tensor, max_le: int,
                       rows_per_seq: int, step: torch.Tensor, scale: float, out: torch.Tensor, stream: Optional[int] = None) -> bool:
     """out = cross-attention of the projected queries a @ w^T + bias against short pre-projected memories, one launch.

@@ -220,8 +220,8 @@ def test_batch_entry_point_groups_by_length_and_restores_order(monkeypatch):
     calls, seeds_seen = [], {}
     open_groups, peak = [], [0]
 
-    def fake_ar_stage(text, prompt_codec, ref_transcript, cfg, ar_noise, generator):
-        i = int(text)
+    def fake_ar_stage(pr, cfg, ar_noise, generator):
+        i = pr["i"]
         seeds_seen[i] = generator.initial_seed()
         x = torch.full((1, lens[i], 8), i, dtype=torch.long)
         return torch.arange(lens[i]), (None, None, None, None, x, None), 2      # frames, batch tuple (x at [4]), skip_front
@@ -240,7 +240,8 @@ def test_batch_entry_point_groups_by_length_and_restores_order(monkeypatch):
             return [torch.full((1, lens[i] + 2, 8), i, dtype=torch.long) for i in ids]
         return land
 
-    monkeypatch.setattr(Mars5TTS, "_ar_stage", lambda self, *a: fake_ar_stage(*a))
+    monkeypatch.setattr(Mars5TTS, "_prompt", lambda self, text, prompt_codec, ref_transcript, cfg, ref_handle=None: {"i": int(text)})
+    monkeypatch.setattr(Mars5TTS, "_ar_stage_pr", lambda self, *a: fake_ar_stage(*a))
     monkeypatch.setattr(inference, "perform_batch_inference", fake_batch)
     n = len(lens)
     out = m.tts_batch_from_codes([str(i) for i in range(n)], [None] * n, [""] * n, InferenceConfig(), seeds=[1000 + i for i in range(n)], nar_batch=3)

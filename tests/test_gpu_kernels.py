@@ -376,6 +376,23 @@ def _ref_attention(q, k, v, key_len, causal):
 
 
 @pytest.mark.parametrize("dt", DTS)
+def test_layernorm_twice(dev, dt):
+    """m5_layernorm_twice: normalise(LayerNorm(x; gamma, beta, eps); eps2) in one pass, rows gathered from runs with a stride
+    (the generated rows of the two guidance branches), against two torch LayerNorms in fp32."""
+    from mars5_tts_amd import ops
+    D, rps, n_seq, stride = 1024, 45, 2, 70
+    x = _rand((n_seq * stride + 5, D), 1, 3.0) + 2.0 * _rand((n_seq * stride + 5, 1), 2)
+    g, b = 1.0 + 0.3 * _rand((D,), 3), 0.2 * _rand((D,), 4)
+    out = torch.zeros(n_seq * rps + 1, D, device=dev, dtype=dt)
+    ops.layernorm_twice(x.to(dev)[3:], g.to(dev), b.to(dev), 4e-5, 1e-5, out[:n_seq * rps], rps, n_seq=n_seq, x_seq_stride=stride)
+    torch.cuda.synchronize()
+    rows = torch.cat([x[3 + s_ * stride: 3 + s_ * stride + rps] for s_ in range(n_seq)])
+    ref = torch.nn.functional.layer_norm(torch.nn.functional.layer_norm(rows, (D,), g, b, 4e-5), (D,), None, None, 1e-5)
+    assert _rel(out[:n_seq * rps].float().cpu(), ref) < max(TOL[dt] / 3, 5e-6), _rel(out[:n_seq * rps].float().cpu(), ref)
+    assert float(out[n_seq * rps].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dt", DTS)
 @pytest.mark.parametrize("B,H,Sq,Sk,kls,causal", [(2, 3, 150, 150, [150, 77], False), (1, 2, 130, 130, [130], True),
                                                    (2, 2, 100, 41, [41, 41], False), (1, 1, 70, 300, [300], False),
                                                    # long key ranges (22 / 10 key tiles), ragged query blocks, a key limit inside the first tile
