@@ -66,7 +66,7 @@ class NARModel:
         # columns (Kp = K rounded up to 4: zero rows, so a head's logits start on a 16-byte boundary as before):
         # W'_q = dtype(W_q diag gamma_q), b'_q = b_q + W_q beta_q.  The fp32 parity engine keeps the reference's order.
         self.head_wf = self.head_bf = None
-        if dt != torch.float32:
+        if dt != torch.float32 and D % 256 == 0:                # (m5_layernorm_twice has the vector form only)
             Kp = round_up(K, 4)
             wf = torch.zeros(Q - 1, Kp, D, dtype=dt)
             bf = torch.zeros(Q - 1, Kp, dtype=torch.float32)
