@@ -519,9 +519,12 @@ class NARSession:
                 self._ring = _UniformRing(self.stream, [shape], self.m.dev)
             ring = self._ring
             (u1, u2), = ring.draw([uniform], t > 0)
-        if use_graph:
+        if use_graph and self.graph is None and self.step_i == 0 and len(self.times) > 1:
+            # The first step goes out launch by launch, and the step graph is captured (a few ms of host time) while the GPU works on
+            # it: with the capture in front of the first step the GPU sat idle for its duration (round 4).
+            self.enqueue_forward(st)
+        elif use_graph:
             if self.graph is None:
-                self.stream.synchronize()
                 ops.Graph.begin(st)
                 self.enqueue_forward(st)
                 self.graph = ops.Graph().end(st)
@@ -698,9 +701,10 @@ class NARBatchSession:
                 self._ring = _UniformRing(self.stream, shapes, self.m.dev)
             ring = self._ring
             drawn = ring.draw(draws, t > 0)
-        if use_graph:
+        if use_graph and self.graph is None and self.step_i == 0 and len(self.times) > 1:
+            self.enqueue_forward(st)                # first step eager, the graph is captured behind it (NARSession.step)
+        elif use_graph:
             if self.graph is None:
-                self.stream.synchronize()
                 ops.Graph.begin(st)
                 self.enqueue_forward(st)
                 self.graph = ops.Graph().end(st)
