@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
     constexpr int CH = (PRO == M5_PRO_DT) ? 8 : 4;             // elements per 16-byte prologue chunk
     constexpr int NCH = K / CH, JN = (NCH + NT - 1) / NT;       // chunk c = tid + j * NT, j < JN
     static_assert(PRO != M5_PRO_ATTN || NT * 8 == K, "attention combine: 8 outputs per thread");
-    __shared__ __attribute__((aligned(16))) float xs[K];
+    __shared__ __attribute__((aligned(16))) st xs[K];            // the activation vector in the operand type (common.h: dot8)
     __shared__ float red[NW];
     __shared__ float wsm[24 * 8 + 24];           // PRO_ATTN: split weights [h][s], then l_tot[h]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -292,21 +292,15 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
         for (int j = 0; j < JN; ++j) {
             const int c = tid + j * NT;
             if (c < NCH) {
-                float4 o;
-                o.x = round_dt<T>((xin[j].x * rstd) * nwv[j].x); o.y = round_dt<T>((xin[j].y * rstd) * nwv[j].y);
-                o.z = round_dt<T>((xin[j].z * rstd) * nwv[j].z); o.w = round_dt<T>((xin[j].w * rstd) * nwv[j].w);
-                *reinterpret_cast<float4*>(xs + c * 4) = o;
+                *reinterpret_cast<uint2*>(xs + c * 4) = m5_pack4<T>((xin[j].x * rstd) * nwv[j].x, (xin[j].y * rstd) * nwv[j].y,
+                                                                    (xin[j].z * rstd) * nwv[j].z, (xin[j].w * rstd) * nwv[j].w);
             }
         }
     } else if constexpr (PRO == M5_PRO_DT) {
 #pragma unroll
         for (int j = 0; j < JN; ++j) {
             const int c = tid + j * NT;
-            if (c < NCH) {
-                const st* xe = reinterpret_cast<const st*>(&xraw[j]);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) xs[c * 8 + e] = T::to_f32(xe[e]);
-            }
+            if (c < NCH) *reinterpret_cast<uint4*>(xs + c * 8) = xraw[j];       // already in the operand type
         }
     } else {
         constexpr int PER = 8;
@@ -345,8 +339,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
             }
         }
         const float l = wsm[H * 8 + h];
-#pragma unroll
-        for (int e = 0; e < PER; ++e) xs[i0 + e] = round_dt<T>(o[e] / l);
+        {
+            const uint2 lo = m5_pack4<T>(o[0] / l, o[1] / l, o[2] / l, o[3] / l), hi = m5_pack4<T>(o[4] / l, o[5] / l, o[6] / l, o[7] / l);
+            *reinterpret_cast<uint4*>(xs + i0) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
     }
     __syncthreads();
     ar_stamp(dbg, 2);
@@ -358,14 +354,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_stream_kernel(M5GemvArgs a) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int k0 = (it * 64 + lane) * EPL;
-        const float4 x0 = *reinterpret_cast<const float4*>(xs + k0);
-        const float4 x1 = *reinterpret_cast<const float4*>(xs + k0 + 4);
-        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + k0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const st* we = reinterpret_cast<const st*>(&wv[r][it]);
-#pragma unroll
-            for (int e = 0; e < EPL; ++e) acc[r] = fmaf(T::to_f32(we[e]), xv[e], acc[r]);
+            const uint4 wr = make_uint4(wv[r][it][0], wv[r][it][1], wv[r][it][2], wv[r][it][3]);
+            acc[r] = dot8<T>(wr, xv, acc[r]);
         }
     }
 #pragma unroll

@@ -98,7 +98,8 @@ __device__ inline float half_to_f32(unsigned bits) {
 // fp32 to dst[2 (j nl + lane)], [.. + 1]; else one fp32 value to dst[j nl + lane].  false: gave up.
 // Addresses: wave-uniform base (SGPRs) + one shared 32-bit lane offset; the buffer is readable up to (PER - 1) sj + 64 words.
 template <typename T, int PER, bool PACK>
-__device__ inline bool gather(const u64* g, int sj, int nl, unsigned tag, float* dst, int lane, int n_total = PER * 64) {
+__device__ inline bool gather(const u64* g, int sj, int nl, unsigned tag, void* dst_, int lane, int n_total = PER * 64) {
+    float* dst = reinterpret_cast<float*>(dst_);                // PACK: granule i = elements 2i, 2i + 1 of an operand-type vector
     const unsigned lane8 = (unsigned)lane * 8u;
     unsigned pend = 0;                                          // granule (j, lane) is wanted iff lane < nl and j nl + lane < n_total
 #pragma unroll
@@ -115,7 +116,7 @@ __device__ inline bool gather(const u64* g, int sj, int nl, unsigned tag, float*
             if (((pend >> j) & 1u) && (unsigned)(w[j] >> 32) == tag) {
                 const unsigned pay = (unsigned)w[j];
                 if (PACK) {
-                    *reinterpret_cast<float2*>(dst + 2 * (j * nl + lane)) = make_float2(half_to_f32<T>(pay & 0xffffu), half_to_f32<T>(pay >> 16));
+                    reinterpret_cast<unsigned*>(dst_)[j * nl + lane] = pay;      // the pair as it travelled: the products' operand (dot8)
                 } else {
                     dst[j * nl + lane] = __uint_as_float(pay);
                 }
@@ -156,22 +157,17 @@ __device__ inline void wait_dma() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N)
 // acc[r] = row r . xs with gemv_stream_kernel's summation order (per lane: k chunks it = 0..NIT-1, 8 elements each, one
 // fmaf chain per row; then the xor-shuffle tree); the rows come from the wave's LDS slice
 template <typename T, int R, int NIT>
-__device__ inline void dot_rows(float (&acc)[R], const unsigned char* slice, const float* xs, int lane) {
-    using st = typename T::storage;
+__device__ inline void dot_rows(float (&acc)[R], const unsigned char* slice, const typename T::storage* xs, int lane) {
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int k0 = (it * 64 + lane) * 8;
-        const float4 x0 = *reinterpret_cast<const float4*>(xs + k0);
-        const float4 x1 = *reinterpret_cast<const float4*>(xs + k0 + 4);
-        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        const uint4 xv = *reinterpret_cast<const uint4*>(xs + k0);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const uint4 wv = *reinterpret_cast<const uint4*>(slice + (r * NIT + it) * 1024 + lane * 16);
-            const st* we = reinterpret_cast<const st*>(&wv);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[r] = fmaf(T::to_f32(we[e]), xv[e], acc[r]);
+            acc[r] = dot8<T>(wv, xv, acc[r]);
         }
     }
 #pragma unroll
@@ -182,7 +178,7 @@ __device__ inline void dot_rows(float (&acc)[R], const unsigned char* slice, con
 // (chunk c = tid + j * NWP * 64 of MD / 4 float4 chunks; block sum = wave trees, then the waves in order).  All 512
 // threads call it (one workgroup barrier inside).
 template <typename T, int NWP>
-__device__ inline void rms_to_xs(const float* graw, const float* nws, float eps, float* xs, float* red, int tid, int lane, int wave) {
+__device__ inline void rms_to_xs(const float* graw, const float* nws, float eps, typename T::storage* xs, float* red, int tid, int lane, int wave) {
     constexpr int NT = NWP * 64, NCH = MD / 4, JN = (NCH + NT - 1) / NT;
     float4 xin[JN], nwv[JN];
     float ss = 0.f;
@@ -209,10 +205,8 @@ __device__ inline void rms_to_xs(const float* graw, const float* nws, float eps,
         for (int j = 0; j < JN; ++j) {
             const int c = tid + j * NT;
             if (c < NCH) {
-                float4 o;
-                o.x = round_dt<T>((xin[j].x * rstd) * nwv[j].x); o.y = round_dt<T>((xin[j].y * rstd) * nwv[j].y);
-                o.z = round_dt<T>((xin[j].z * rstd) * nwv[j].z); o.w = round_dt<T>((xin[j].w * rstd) * nwv[j].w);
-                *reinterpret_cast<float4*>(xs + c * 4) = o;
+                *reinterpret_cast<uint2*>(xs + c * 4) = m5_pack4<T>((xin[j].x * rstd) * nwv[j].x, (xin[j].y * rstd) * nwv[j].y,
+                                                                    (xin[j].z * rstd) * nwv[j].z, (xin[j].w * rstd) * nwv[j].w);
             }
         }
     }
@@ -226,7 +220,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
     constexpr int OFF_A = 2 * MF * 4, OFF_B = OFF_A + 7 * 12 * 1024, OFF_END = OFF_B + 6 * 7 * 1024;
     __shared__ __attribute__((aligned(16))) unsigned char lds[OFF_END];
     float* graw = reinterpret_cast<float*>(lds);                // the gatherers' target (raw granule values)
-    float* xs = reinterpret_cast<float*>(lds) + MF;             // the phase's activation vector as the dot products read it
+    st* xs = reinterpret_cast<st*>(lds + MF * 4);               // the phase's activation vector as the dot products read it (operand type)
     float* nws = graw + 2048;                                   // RMSNorm weights of the phase (P1 / P4 gather 1536 values only)
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     __shared__ float red[2][8];

@@ -60,6 +60,39 @@ struct Vec16 {
     }
 };
 
+// ---- eight 16-bit products into one fp32 accumulator ---------------------------------------------------------------------
+// acc += sum_e w[e] x[e] over the 8 element pairs of two 16-byte operands, as FOUR v_dot2c_f32_{bf16,f16}
+// (acc = w.lo x.lo + w.hi x.hi + acc), pairs in memory order.  Both forms of the AR decode step (ar_decode.hip's
+// gemv_stream_kernel and ar_mega.hip's dot_rows) call this on the same operands in the same order: that is what keeps them
+// bit-identical.  Before round 4 this was 8 unpack + 8 fmaf per 16 bytes and operand; the activation vector now lives in LDS
+// in the operand type (it always held operand-rounded values), one ds_read_b128 per 8 elements instead of two.
+typedef __attribute__((ext_vector_type(2))) __bf16 m5_bf2_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 m5_h2_t;
+template <typename T>
+__device__ inline float dot8(const uint4& w, const uint4& x, float acc);
+template <>
+__device__ inline float dot8<BF16T>(const uint4& w, const uint4& x, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const m5_bf2_t*>(&w.x), *reinterpret_cast<const m5_bf2_t*>(&x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const m5_bf2_t*>(&w.y), *reinterpret_cast<const m5_bf2_t*>(&x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const m5_bf2_t*>(&w.z), *reinterpret_cast<const m5_bf2_t*>(&x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const m5_bf2_t*>(&w.w), *reinterpret_cast<const m5_bf2_t*>(&x.w), acc, false);
+    return acc;
+}
+template <>
+__device__ inline float dot8<F16T>(const uint4& w, const uint4& x, float acc) {
+    acc = __builtin_amdgcn_fdot2(*reinterpret_cast<const m5_h2_t*>(&w.x), *reinterpret_cast<const m5_h2_t*>(&x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2(*reinterpret_cast<const m5_h2_t*>(&w.y), *reinterpret_cast<const m5_h2_t*>(&x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2(*reinterpret_cast<const m5_h2_t*>(&w.z), *reinterpret_cast<const m5_h2_t*>(&x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2(*reinterpret_cast<const m5_h2_t*>(&w.w), *reinterpret_cast<const m5_h2_t*>(&x.w), acc, false);
+    return acc;
+}
+// four fp32 values -> four operand-type values (8 bytes)
+template <typename T>
+__device__ inline uint2 m5_pack4(float a, float b, float c, float d) {
+    typename T::storage t[4] = {T::from_f32(a), T::from_f32(b), T::from_f32(c), T::from_f32(d)};
+    return *reinterpret_cast<const uint2*>(t);
+}
+
 // ---- wave / block reductions ---------------------------------------------------------
 // Cross-lane exchanges without the LDS crossbar.  `__shfl_xor` compiles to ds_bpermute_b32 (address arithmetic + an
 // LDS-pipe round trip + a wait, ~100 cycles per step; a reduction is a chain of 6 dependent steps).  The same partners are
