@@ -97,7 +97,9 @@ __device__ inline float half_to_f32(unsigned bits) {
 // a lane in flight; a granule is accepted once its tag matches.  PACK: a granule carries two 16-bit values, written as
 // fp32 to dst[2 (j nl + lane)], [.. + 1]; else one fp32 value to dst[j nl + lane].  false: gave up.
 // Addresses: wave-uniform base (SGPRs) + one shared 32-bit lane offset; the buffer is readable up to (PER - 1) sj + 64 words.
-template <typename T, int PER, bool PACK>
+// PACK: 0 = granules carry one fp32 value each; 1 = two operand-type values, unpacked to fp32 (the head's q | k | v for the cache
+// scan); 2 = two operand-type values stored as they travelled (the products' operand vector, common.h dot8)
+template <typename T, int PER, int PACK>
 __device__ inline bool gather(const u64* g, int sj, int nl, unsigned tag, void* dst_, int lane, int n_total = PER * 64) {
     float* dst = reinterpret_cast<float*>(dst_);                // PACK: granule i = elements 2i, 2i + 1 of an operand-type vector
     const unsigned lane8 = (unsigned)lane * 8u;
@@ -115,8 +117,10 @@ __device__ inline bool gather(const u64* g, int sj, int nl, unsigned tag, void* 
         for (int j = 0; j < PER; ++j)
             if (((pend >> j) & 1u) && (unsigned)(w[j] >> 32) == tag) {
                 const unsigned pay = (unsigned)w[j];
-                if (PACK) {
+                if (PACK == 2) {
                     reinterpret_cast<unsigned*>(dst_)[j * nl + lane] = pay;      // the pair as it travelled: the products' operand (dot8)
+                } else if (PACK == 1) {
+                    *reinterpret_cast<float2*>(dst + 2 * (j * nl + lane)) = make_float2(half_to_f32<T>(pay & 0xffffu), half_to_f32<T>(pay >> 16));
                 } else {
                     dst[j * nl + lane] = __uint_as_float(pay);
                 }
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
             if (l == a.layer0) {
 #pragma unroll
                 for (int j = 0; j < MD / 384; ++j) graw[q0 + j * 64 + lane] = a.xres[q0 + j * 64 + lane];
-            } else if (!gather<T, MD / 384, false>(g + G_X2 + q0, 64, 64, tl - 8u + E_X2, graw + q0, lane)) {
+            } else if (!gather<T, MD / 384, 0>(g + G_X2 + q0, 64, 64, tl - 8u + E_X2, graw + q0, lane)) {
                 fail = 1;
             }
         }
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
                     }
                 }
             }
-            if (wave == 4 && !gather<T, 3, true>(g + G_QKV + ah * 32, MD / 2, 32, tl + E_QKV, graw, lane)) fail = 1;
+            if (wave == 4 && !gather<T, 3, 1>(g + G_QKV + ah * 32, MD / 2, 32, tl + E_QKV, graw, lane)) fail = 1;
             bar();
             if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
             if (loader) dma_flat(lds_base + OFF_A, W13, 42, lane);            // drains under the scan's arithmetic
@@ -459,7 +463,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         } else if (b < MH * MNS + MH) {
             const int hh = b - MH * MNS;
             // one sweep over the head's 8 x 66 words (the region is padded to 9 x 64 granules)
-            if (wave == 4 && !gather<T, 9, false>(g + G_PART + hh * PART_H, 64, 64, tl + E_PART, graw, lane, MNS * M5_ATTN_PART)) fail = 1;
+            if (wave == 4 && !gather<T, 9, 0>(g + G_PART + hh * PART_H, 64, 64, tl + E_PART, graw, lane, MNS * M5_ATTN_PART)) fail = 1;
             bar();
             if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
             if (wave == 0) {                                  // lane = d; the merge of gemv_stream_kernel's PRO_ATTN prologue
@@ -485,7 +489,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         // ------------------------------------------------------------------ P3: Wo rows -> x += .
         // The gathered values ARE the products' operand (already rounded): they go straight to xs (its last readers, P1's
         // products, are behind the post-P1 barrier), and the loader's wait sits in front of the one barrier of this phase.
-        if (wave < 6 && !gather<T, 2, true>(g + G_O + wave * 128, 64, 64, tl + E_O, xs + wave * 256, lane)) fail = 1;
+        if (wave < 6 && !gather<T, 2, 2>(g + G_O + wave * 128, 64, 64, tl + E_O, xs + wave * 256, lane)) fail = 1;
         if (loader) wait_dma<63>();                           // 18 Wo + 84 W1|W3 pieces issued since: <= 63 outstanding => the Wo rows landed
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
@@ -507,7 +511,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
             const int q0 = wave * (MD / 6);
 #pragma unroll
             for (int j = 0; j < MD / 384; ++j) nws[q0 + j * 64 + lane] = a.ffn_norm[(int64_t)l * MD + q0 + j * 64 + lane];
-            if (!gather<T, MD / 384, false>(g + G_X1 + q0, 64, 64, tl + E_X1, graw + q0, lane)) fail = 1;
+            if (!gather<T, MD / 384, 0>(g + G_X1 + q0, 64, 64, tl + E_X1, graw + q0, lane)) fail = 1;
         }
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
 
         mstamp(a.dbg, l, 8);
         // ------------------------------------------------------------------ P5: W2 rows -> x += .
-        if (wave < 7 && !gather<T, 4, true>(g + G_H + wave * 256, 64, 64, tl + E_H, xs + wave * 512, lane)) fail = 1;   // (straight to xs, as in P3)
+        if (wave < 7 && !gather<T, 4, 2>(g + G_H + wave * 256, 64, 64, tl + E_H, xs + wave * 512, lane)) fail = 1;   // (straight to xs, as in P3)
         if (loader) wait_dma<0>();                            // the W2 rows have landed
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
