@@ -335,11 +335,13 @@ class Mars5TTS:
     @torch.inference_mode()
     def tts_batch_from_codes(self, texts: List[str], prompt_codecs: List[Tensor], ref_transcripts: List[Optional[str]],
                              cfg: InferenceConfig = InferenceConfig(), seeds: Optional[List[int]] = None,
-                             nar_batch: int = 8, ar_batch: int = 1, max_lens: Optional[List[int]] = None,
+                             nar_batch: int = 32, ar_batch: int = 1, max_lens: Optional[List[int]] = None,
                              nar_in_flight: int = 2, prompts: Optional[List[dict]] = None) -> List[Tuple[Tensor, Tensor]]:
         """Several independent requests on one GPU (BASELINE config 3).  Request i gets a private
         device generator seeded ``seeds[i]`` and consumes it as a lone call would.
-        NAR: up to `nar_batch` requests of similar length are refined per decoder pass
+        NAR: up to `nar_batch` requests of similar length (default 32 since round 4: a group is laid out padded to its longest
+        member but only the row tiles that hold real rows are launched, so large groups are the efficient ones; each request
+        holds ~1 GB of hoisted conditioning while its group runs) are refined per decoder pass
         (``perform_batch_inference``) - exact: result i equals ``torch.manual_seed(seeds[i]);
         tts_from_codes(...)`` whatever else is in the batch.
         AR: `ar_batch` = 1 decodes request by request (the batch-1 weight-streaming GEMV path, bit-equal to
