@@ -131,6 +131,11 @@ CASES = [
     ("big linear2", 35840, 1024, 3072, L.EPI_RESIDUAL, True, None),
     ("big swiglu", 35840, 6144, 1024, L.EPI_SWIGLU, False, None),
     ("big qkv", 35840, 3072, 1024, L.EPI_QKV, True, 2240),
+    # one NAR group of 32 utterances (round 4: ~98 k real rows of 147 k padded ones are launched)
+    ("huge out_proj", 98304, 1024, 1024, L.EPI_RESIDUAL, True, None),
+    ("huge linear2", 98304, 1024, 3072, L.EPI_RESIDUAL, True, None),
+    ("huge swiglu", 98304, 6144, 1024, L.EPI_SWIGLU, False, None),
+    ("huge qkv", 98304, 3072, 1024, L.EPI_QKV, True, 2304),
 ]
 
 def run_heads(name="nar heads x7"):
