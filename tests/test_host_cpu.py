@@ -198,3 +198,53 @@ def test_row_tile_lists_cover_exactly_the_real_rows():
     import pytest
     with pytest.raises(AssertionError):
         RowTiles([10], 320, torch.device("cpu"))                                              # not a multiple of 384
+
+
+def test_deferred_layernorm_fold_is_the_same_linear_map():
+    """blocks.fold_layer_dln + the identity the kernels implement (include/mars5_hip.h, M5DeferredLN), in fp32 on the host:
+    LN(x; gamma, beta) W^T + b == r (xt W'^T - d s) + b' with xt = x - c for ANY per-row centre c, for the three folded
+    projections of a decoder layer (in_proj behind norm1, cross-attention query behind norm2, the interleaved SwiGLU pair behind
+    norm3); and the chain's centre bookkeeping (blocks.DeferredLN: producers alternate between two centre buffers, the first one
+    after a chain start takes the LayerNorm's means without a delta)."""
+    from mars5_tts_amd import _lib as L
+    from mars5_tts_amd.blocks import DeferredLN, EncLayerW, SeqWorkspace, fold_layer_dln, interleave_rows, LAYERNORM_EPS
+    torch.manual_seed(0)
+    D, FF, M = 256, 384, 37
+    p = "tfm.decoder.layers.0"
+    sd = {f"{p}.self_attn.in_proj_weight": torch.randn(3 * D, D) / 16, f"{p}.self_attn.in_proj_bias": torch.randn(3 * D),
+          f"{p}.multihead_attn.in_proj_weight": torch.randn(3 * D, D) / 16, f"{p}.multihead_attn.in_proj_bias": torch.randn(3 * D),
+          f"{p}.activation.W.weight": torch.randn(FF, D) / 16, f"{p}.activation.V.weight": torch.randn(FF, D) / 16}
+    for n in (1, 2, 3):
+        sd[f"{p}.norm{n}.weight"], sd[f"{p}.norm{n}.bias"] = 1 + 0.3 * torch.randn(D), 0.2 * torch.randn(D)
+    lw = EncLayerW(in_w=None, in_b=None, out_w=torch.zeros(D, D), out_b=None, act_w=None, l2_w=None, l2_b=None, n1_w=None, n1_b=None, n2_w=None, n2_b=None)
+    act = interleave_rows(sd[f"{p}.activation.W.weight"], sd[f"{p}.activation.V.weight"])
+    fold_layer_dln(sd, p, lw, act, torch.float32, "cpu")
+    x = 2.0 * torch.randn(M, D) + 5.0 * torch.randn(M, 1)
+    c = x.mean(dim=1, keepdim=True) + 0.5 * torch.randn(M, 1)             # a centre near, not at, the mean
+    xt = x - c
+    d = xt.mean(dim=1, keepdim=True)
+    r = 1.0 / torch.sqrt(x.var(dim=1, unbiased=False, keepdim=True) + LAYERNORM_EPS)
+    cases = [(sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"], 1, lw.in_w_f, lw.in_b_f, lw.in_s),
+             (sd[f"{p}.multihead_attn.in_proj_weight"][:D], sd[f"{p}.multihead_attn.in_proj_bias"][:D], 2, lw.ca_q_w_f, lw.ca_q_b_f, lw.ca_q_rs),
+             (act, None, 3, lw.act_w_f, lw.act_b_f, lw.act_s)]
+    for W, b, n, Wf, bf, s in cases:
+        ln = torch.nn.functional.layer_norm(x, (D,), sd[f"{p}.norm{n}.weight"], sd[f"{p}.norm{n}.bias"], LAYERNORM_EPS)
+        want = ln @ W.T + (b if b is not None else 0.0)
+        got = r * (xt @ Wf.T - d * s[None, :]) + bf[None, :]
+        assert float((got - want).abs().max()) < 2e-4 * float(want.abs().max()), n
+    assert torch.equal(lw.ca_q_wT_f, lw.ca_q_w_f.view(D // 64, 64, D).permute(0, 2, 1).contiguous())
+    # centre bookkeeping of a chain
+    ws = SeqWorkspace(1, M, D, FF, torch.bfloat16, torch.device("cpu"))
+    dl = DeferredLN(ws, torch.device("cpu"))
+    start = dl.start()
+    assert start.data_ptr() == dl.cen[0].data_ptr()
+    p1 = dl.producer(ws)                                   # first producer after the start: the LayerNorm's means, no delta
+    assert (p1.cen_in, p1.cen_out, p1.delta) == (dl.cen[0].data_ptr(), dl.cen[1].data_ptr(), None) and p1.mode == 1 and p1.np == D // 128
+    cns = dl.consumer(lw.in_s, M=M)
+    assert cns.mode == 2 and cns.delta == dl.delta.data_ptr() and cns.cen_in is None and cns.n_feat == D
+    p2a = dl.producer(ws, r0=8, rows_bs=16, advance=False)     # a step split over two launches reads / writes the same pair of buffers
+    p2b = dl.producer(ws, r0=24, rows_bs=16)
+    assert (p2a.cen_in - 8 * 4, p2a.cen_out - 8 * 4) == (dl.cen[1].data_ptr(), dl.cen[0].data_ptr()) == (p2b.cen_in - 24 * 4, p2b.cen_out - 24 * 4)
+    assert p2a.delta == dl.delta.data_ptr() + 8 * 4 and p2a.xt == ws.xn.data_ptr() + 8 * D * 2 and p2a.part == dl.part.data_ptr() + 8 * (D // 128) * 8
+    p3 = dl.producer(ws)
+    assert (p3.cen_in, p3.cen_out) == (dl.cen[0].data_ptr(), dl.cen[1].data_ptr())
