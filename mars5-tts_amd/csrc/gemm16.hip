@@ -1514,7 +1514,7 @@ int pick_config(int M, int N, int K, int batch, int span_div, int epi, int dln =
         // fixed cost hides under its successor / co-resident workgroup (measured at M = 35840, profiles/r2t_gemm_configs.txt)
         if (wg >= 4 * slots) t = (float)wg / (float)slots * ((f.occ == 1 ? 0.2f : 0.7f) * f.t_fix_us + (float)(K / 64) * f.t_iter_us);
         if (epi == M5_EPI_QKV && (c == 3 || c == 7)) t += 2.5f * (float)rounds;     // measured: its 4-wave scatter epilogue is the slowest
-        if (epi == M5_EPI_QKV && c == 0 && wg >= 4 * slots) t *= 1.06f;             // measured at M = 35,840 / 98,304 (profiles/r4q_large_m_gemm_config_sweep.txt):
+        if (epi == M5_EPI_QKV && c == 0 && wg >= 4 * slots) t *= 1.12f;             // measured at M = 35,840 / 98,304 (profiles/r4q_large_m_gemm_config_sweep.txt):
                                                                                     // 128x128 is 4-5 % behind the 192x192 region for the scatter epilogue
         if (t < best_t) { best_t = t; best = c; }
     }
