@@ -171,12 +171,38 @@ def launch_check(args, world: int, rank: int) -> None:
             allcs = [None] * world
             dist.all_gather_object(allcs, cs)
             shared = {"checksums_equal": len(set(allcs)) == 1, "ranks": world, "leftover_file": os.path.exists(f"/dev/shm/m5_bench_bundle_{os.environ.get('MASTER_PORT', '0')}.pt")}
+        c4 = None
+        if args.workload == "c4":
+            # BASELINE configs[3] end to end THROUGH THIS FILE with CPU stand-ins for the three device stages (oracle/fakes.py:
+            # test infrastructure; the product's host logic -- prompt assembly from wire ids, hand-off, grouping, prompt skipping --
+            # is the real one): requests built on rank 0 -> scatter -> every rank refines its shard in groups -> gather -> rank 0
+            # re-computes requests that ANOTHER rank ran and requires identical codes.
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            from fakes import cpu_standin_tts
+            from mars5_tts_amd import synth
+            m, inf = cpu_standin_tts(synth.make_vocab(30, 63))
+            cfg = inf.InferenceConfig(deep_clone=True, temperature=0.7, top_k=100)
+            n_total = 3 * world
+            reqs = []
+            for i in range(n_total):
+                text, tr = f"Request number {i} says hello.", "A transcript " * (1 + i % 3)
+                ids = m.texttok.encode("<|startoftext|>" + tr + ' ' + text.strip() + "<|endoftext|>", allowed_special='all')
+                ref = synth.make_ref_codes(20 + 7 * i, seed=50 + i, merge_friendly=True)
+                reqs.append(sh.Request(i, torch.tensor(ids, dtype=torch.long), ref[0].T.contiguous(), seed=500 + i, n_gen_est=12,
+                                       n_phones_gen=len(text), max_len=len(ids) + ref.shape[-1] + 12))
+            outs = sh.run_sharded(reqs if rank == 0 else None, n_total, None, src=0, batch_worker=request_batch_worker(m, cfg, 2, 2))
+            parts = sh.lpt_partition([sh.estimate_cost(r) for r in reqs], world)
+            if rank == 0:
+                checked = verify_remote(m, cfg, reqs, set(parts[0]), outs, k=2)
+                c4 = {"requests": n_total, "requests_per_rank": [len(p) for p in parts], "scatter_bytes": sh.LAST_STATS.get("scatter_bytes"),
+                      "gather_bytes": sh.LAST_STATS.get("gather_bytes"), "remote_results_rechecked_equal": checked,
+                      "frames": [int(o.shape[0]) for o in outs], "stages": "CPU stand-ins (oracle/fakes.cpu_standin_tts)"}
         dist.barrier()
         dist.destroy_process_group()
     else:
-        census, seen, shared = [dict(rank=0)], 1, None
+        census, seen, shared, c4 = [dict(rank=0)], 1, None, None
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": seen, "requested": args.gpus, "world_size_env": world, "shared_bundle": shared,
+        print(json.dumps({"launch_check": True, "n_gpus": seen, "requested": args.gpus, "world_size_env": world, "shared_bundle": shared, "c4": c4,
                           "collective": {"backend": args.backend if world > 1 else None, "ranks_seen": seen, "census": census}}), flush=True)
 
 

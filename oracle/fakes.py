@@ -72,3 +72,58 @@ class CpuStreamHooks:
 
     def uniform(self, shape):
         return torch.rand(shape, generator=self.g).to(self.dev)
+
+
+def cpu_standin_tts(tiny_vocab):
+    """(Moved here from tests/test_sharding_gloo.py in round 4 so that ``bench.py --launch-check --workload c4`` can use it.)
+    A Mars5TTS whose host logic is the product's (prompt assembly from wire-format ids, BPE hand-off, prompt skipping)
+    and whose device stages (AR decode, token expansion kernel, NAR refinement) are deterministic CPU stand-ins driven by
+    the global RNG (what run_sharded seeds)."""
+    import io
+    import inference as inf
+    from mars5_tts_amd import minbpe
+
+    def fake_begin(model, c_text, c_codes, T, dsh=None, div_mode=0, diff=None, **kw):
+        return None
+
+    def fake_ar(texttok, speechtok, codeclm, xx, ss_gen, first_codex_idx, max_len=1500, generator=None, **kw):
+        n = min(int(max_len) - int(xx.shape[0]), 9 + int(ss_gen.shape[0]) % 5)
+        n_text = len(texttok.vocab)
+        new = torch.randint(n_text, n_text + 1024, (max(n, 0),), generator=generator)   # global generator (seeded per request by run_sharded) or the request's own
+        return torch.cat([xx.cpu(), new])
+
+    def fake_nar(model, batch, diff, T, dtype=None, retain_quant0=True, dsh=None, generator=None, session=None, **kw):
+        c_codes, x = batch[1], batch[4]
+        out = x.clone()
+        out[..., 1:] = torch.randint(0, 1024, out[..., 1:].shape, generator=generator)
+        if dsh.deep_clone:
+            out = torch.cat([c_codes.to(out.dtype), out], dim=1)
+        return out
+
+    def fake_nar_batch(model, batches, diff, T, dsh=None, generators=None, wait=True, stream=None, **kw):
+        outs = [fake_nar(model, b, diff, T, dsh=dsh, generator=g) for b, g in zip(batches, generators)]     # request i draws from ITS generator
+        return outs if wait else (lambda: outs)
+
+    def fake_expand(tokens, n_text, off, vals, max_run, stream=None):       # CPU stand-in of m5_expand_tokens (same CSR table)
+        out = []
+        for t in (tokens - n_text).clamp(min=0).tolist():
+            out.extend(vals[int(off[t]):int(off[t + 1])].tolist())
+        return torch.tensor(out, dtype=torch.long)
+
+    inf.begin_inference, inf.ar_generate, inf.perform_simple_inference = fake_begin, fake_ar, fake_nar
+    inf.perform_batch_inference = fake_nar_batch
+    inf.ops.expand_tokens = fake_expand
+    m = inf.Mars5TTS.__new__(inf.Mars5TTS)
+    m.device = torch.device("cpu")
+    m.codec = m.vocos = False
+    m.texttok = minbpe.RegexTokenizer()
+    m.texttok.load(io.BytesIO(tiny_vocab["texttok.model"].encode()))
+    m.speechtok = minbpe.CodebookTokenizer()
+    m.speechtok.load(io.BytesIO(tiny_vocab["speechtok.model"].encode()))
+    m.n_vocab = len(m.texttok.vocab) + len(m.speechtok.vocab)
+    m.n_text_vocab = len(m.texttok.vocab) + 1
+    m.diffusion_n_classes = 1025
+    m.codeclm = m.codecnar = None
+    m.default_T, m.sr, m.latent_sr = 4, 24000, 75
+    m._expansion = m.speechtok.expansion_table()
+    return m, inf

@@ -48,3 +48,16 @@ def test_synthetic_checkpoint_is_built_once_and_shared():
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert j["shared_bundle"] == {"checksums_equal": True, "ranks": 2, "leftover_file": False}
+
+
+def test_c4_scatter_run_gather_recheck_through_bench_py():
+    """`bench.py --gpus 2 --workload c4 --launch-check --backend gloo`: BASELINE configs[3]'s flow through bench.py itself --
+    requests on rank 0, scatter, every rank refines its shard in groups (the product's host logic; CPU stand-ins for the device
+    stages), gather, and rank 0 re-computes two requests that the OTHER rank ran and finds identical codes."""
+    r = _run(["--gpus", "2", "--workload", "c4", "--launch-check", "--backend", "gloo"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    c4 = j["c4"]
+    assert c4["requests"] == 6 and sum(c4["requests_per_rank"]) == 6 and min(c4["requests_per_rank"]) >= 1
+    assert c4["remote_results_rechecked_equal"] == 2 and c4["scatter_bytes"] > 0 and c4["gather_bytes"] > 0
+    assert len(c4["frames"]) == 6 and all(f >= 1 for f in c4["frames"])
