@@ -452,13 +452,18 @@ def shared_bundle(world: int, rank: int, size: str = "full"):
         return synth.make_bundle(size, seed=0)
     import torch.distributed as dist
     path = f"/dev/shm/m5_bench_bundle_{os.environ.get('MASTER_PORT', '0')}.pt"
+    ok = [True]
     if rank == 0:
         b = synth.make_bundle(size, seed=0)
-        torch.save(b, path + ".tmp")
-        os.replace(path + ".tmp", path)
-    dist.barrier()
+        try:
+            torch.save(b, path + ".tmp")
+            os.replace(path + ".tmp", path)
+        except Exception as e:          # noqa: BLE001 -- e.g. a container with a 64-MB /dev/shm: every rank then builds its own copy
+            print(f"bench.py: could not share the synthetic checkpoint through {path} ({type(e).__name__}: {e}); every rank builds its own", file=sys.stderr, flush=True)
+            ok[0] = False
+    dist.broadcast_object_list(ok, src=0)
     if rank != 0:
-        b = torch.load(path, map_location="cpu", weights_only=False, mmap=True)
+        b = torch.load(path, map_location="cpu", weights_only=False, mmap=True) if ok[0] else synth.make_bundle(size, seed=0)
     dist.barrier()
     if rank == 0:
         try:
