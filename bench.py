@@ -86,6 +86,29 @@ def preflight(local: int, timeout_s: float = 240.0) -> dict:
     return res
 
 
+def run_leg(out: dict, name: str, fn, sync=None) -> bool:
+    """One optional leg of the line: `fn()` fills `out`; an exception is recorded as out["<name>_error"] (and printed to stderr)
+    instead of propagating, the enriched line is re-printed either way.  Returns whether the leg completed."""
+    t_leg = time.perf_counter()
+    done = False
+    try:
+        fn()
+        out.setdefault("legs_done", []).append(name)
+        done = True
+    except Exception as e:          # noqa: BLE001 -- a diagnostic leg must never cost the headline
+        import traceback
+        out[f"{name}_error"] = f"{type(e).__name__}: {e}"[:600]
+        traceback.print_exc(file=sys.stderr)
+        if sync is not None:
+            try:
+                sync()
+            except Exception as e2:     # noqa: BLE001
+                out[f"{name}_error"] += f" | device unusable afterwards: {e2}"[:200]
+    out.setdefault("leg_seconds", {})[name] = round(time.perf_counter() - t_leg, 1)
+    emit(out)
+    return done
+
+
 def emit(out: dict) -> None:
     """One JSON line on stdout, flushed.  Called after the timed loop and again after every leg: the LAST line is the
     complete record, every earlier one is a valid (smaller) record of the same run."""
@@ -1053,20 +1076,7 @@ def main():
     emit(out)
 
     def leg(name, fn):
-        t_leg = time.perf_counter()
-        try:
-            fn()
-            out["legs_done"].append(name)
-        except Exception as e:          # noqa: BLE001 -- a diagnostic leg must never cost the headline
-            import traceback
-            out[f"{name}_error"] = f"{type(e).__name__}: {e}"[:600]
-            traceback.print_exc(file=sys.stderr)
-            try:
-                torch.cuda.synchronize()
-            except Exception as e2:     # noqa: BLE001
-                out[f"{name}_error"] += f" | device unusable afterwards: {e2}"[:200]
-        out.setdefault("leg_seconds", {})[name] = round(time.perf_counter() - t_leg, 1)
-        emit(out)
+        run_leg(out, name, fn, torch.cuda.synchronize)
 
     single = world == 1
     if not args.no_roofline:

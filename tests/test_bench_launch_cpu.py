@@ -61,3 +61,28 @@ def test_c4_scatter_run_gather_recheck_through_bench_py():
     assert c4["requests"] == 6 and sum(c4["requests_per_rank"]) == 6 and min(c4["requests_per_rank"]) >= 1
     assert c4["remote_results_rechecked_equal"] == 2 and c4["scatter_bytes"] > 0 and c4["gather_bytes"] > 0
     assert len(c4["frames"]) == 6 and all(f >= 1 for f in c4["frames"])
+
+
+def test_a_failing_leg_cannot_take_the_headline_with_it(capsys):
+    """Round 3 lost its driver record to an exception in a diagnostic leg that ran two minutes after the timed loop.  bench.run_leg:
+    the exception becomes "<leg>_error", the line printed so far stays valid, the next leg still runs, and every call re-prints the
+    enriched line (the last line is the complete record)."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    out = {"metric": "m", "value": 1.0, "legs_done": []}
+    bench.emit(out)
+    synced = []
+
+    def boom():
+        out["half"] = 1
+        raise RuntimeError("indices should be either on cpu or on the same device")
+
+    assert bench.run_leg(out, "parity", boom, lambda: synced.append(1)) is False
+    assert bench.run_leg(out, "cpu_baseline", lambda: out.__setitem__("cpu_baseline", {"value": 0.007})) is True
+    lines = [json.loads(ln) for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 3 and lines[0] == {"metric": "m", "value": 1.0, "legs_done": []}
+    last = lines[-1]
+    assert last["value"] == 1.0 and last["legs_done"] == ["cpu_baseline"] and "RuntimeError" in last["parity_error"]
+    assert last["cpu_baseline"] == {"value": 0.007} and set(last["leg_seconds"]) == {"parity", "cpu_baseline"} and synced == [1]
