@@ -15,6 +15,7 @@ One JSON line on rank 0; ``value`` = generated audio seconds per wall second ove
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import statistics
@@ -254,6 +255,60 @@ def c3_requests(m, n: int, n_gen: int, seed: int = 11):
     return texts, trs, refs, max_lens
 
 
+class NarGroupSpy:
+    """Re-check of a batched NAR refinement against LONE calls (the configs[2] legs ran a path -- row-tile lists +
+    deferred LayerNorms at the real geometry -- whose equality with the lone path only tests/ asserted).  Wrapped around
+    ``inference.perform_batch_inference`` for ONE batch step it remembers, per group, the staged inputs, the (seed, offset) of
+    every request's private device generator right before the group consumed it, and the group's results; ``recheck`` then
+    refines up to k requests of a group ALONE (``perform_simple_inference``, a generator put back to that seed and offset)
+    and requires identical codes.  Outside every timed region."""
+
+    def __init__(self):
+        import inference as inf
+        self.inf, self.orig, self.groups = inf, inf.perform_batch_inference, []
+
+    def __enter__(self):
+        def wrapped(model, batches, diff, T, dsh=None, generators=None, **kw):
+            rec = dict(model=model, batches=list(batches), diff=diff, T=T, dsh=dsh, out=None,
+                       snap=[(int(g.initial_seed()), int(g.get_offset())) for g in generators])
+            self.groups.append(rec)
+            r = self.orig(model, batches, diff, T, dsh=dsh, generators=generators, **kw)
+            if not callable(r):
+                rec["out"] = r
+                return r
+
+            def land():
+                rec["out"] = r()
+                return rec["out"]
+            return land
+        self.inf.perform_batch_inference = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.inf.perform_batch_inference = self.orig
+        return False
+
+    def recheck(self, dev, k: int = 2) -> dict:
+        from mars5_tts_amd.diffuser import perform_simple_inference
+        checked, rows = 0, []
+        grp = max(self.groups, key=lambda g: len(g["batches"]))          # the largest group: the one the row-tile lists matter for
+        n = len(grp["batches"])
+        lens = [int(b[4].shape[1]) + int(b[1].shape[1]) for b in grp["batches"]]
+        order = sorted(range(n), key=lambda i: lens[i])
+        pick = [order[0], order[n // 2]][:k] if n > 1 else [0]          # the shortest member (most padding around it) and a middle one
+        for i in dict.fromkeys(pick):
+            g = torch.Generator(device=dev)
+            g.manual_seed(grp["snap"][i][0])
+            g.set_offset(grp["snap"][i][1])
+            lone = perform_simple_inference(grp["model"], grp["batches"][i], grp["diff"], grp["T"], dsh=grp["dsh"], generator=g)
+            same = bool(torch.equal(lone.cpu(), grp["out"][i].cpu()))
+            assert same, f"request {i} of a group of {n}: the batched NAR refinement differs from the lone call in {int((lone.cpu() != grp['out'][i].cpu()).sum())} codes"
+            checked += 1
+            rows.append(lens[i])
+        return {"group_results_rechecked_against_lone_calls": True, "requests_rechecked": checked, "group_size": n, "rechecked_total_rows": rows,
+                "groups_in_step": len(self.groups)}
+
+
 def main_c3(args, m, dev, world, rank, barrier):
     """One step = `--batch` mixed-length requests: AR decoded --ar-batch at a time (weights read once per step for
     all of them), NAR refined --nar-batch at a time.  value = generated audio seconds / wall second."""
@@ -331,6 +386,13 @@ def main_c3(args, m, dev, world, rank, barrier):
         ranks_seen = sh.LAST_STATS["ranks_seen"]
     if rank != 0:
         return
+    # one more (untimed) step under the spy: two of its group results against lone seeded calls
+    inf.ar_generate_batch, inf.perform_batch_inference = _ar, _nar
+    with NarGroupSpy() as spy:
+        m.tts_batch_from_codes(texts, refs, trs, cfg, seeds=[77000 + j for j in range(args.batch)], nar_batch=args.nar_batch, ar_batch=args.ar_batch,
+                               max_lens=max_lens, nar_in_flight=args.nar_in_flight)
+        torch.cuda.synchronize()
+    recheck = spy.recheck(dev, k=2)
     ref_frames = [int(r.shape[-1]) for r in refs]
     out = {
         "metric": "generated audio seconds/sec (RTF), deep-clone", "value": round(frames / 75.0 / elapsed, 4), "unit": "audio_s/s",
@@ -347,6 +409,7 @@ def main_c3(args, m, dev, world, rank, barrier):
         "last_ar_batch": {k: ar_engine.LAST_STATS.get(k) for k in ("decode_ms", "decode_steps_launched", "batch")},
         "last_nar_batch": {k: nar_engine.LAST_STATS.get(k) for k in ("loop_ms", "steps", "batch", "rows")},
     }
+    out.update(recheck)
     print(json.dumps(out), flush=True)
 
 
@@ -596,16 +659,16 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     ops.gemm = timed(orig["gemm"], gemm_label, gemm_flops, gemm_bytes)
     # deferred-LayerNorm forms (same kernel names as rocprofv3 prints them: the DLN template argument is part of the instantiation, the
     # epilogue class is what groups them here)
-    ops.gemm_dln = timed(orig["gemm_dln"], lambda a, w_, out, epi, dl, **kw: gemm_label(a, w_, out, epi, **kw) + (" +dln-producer" if dl.mode == 1 else " +dln-consumer"),
+    ops.gemm_dln = timed(orig["gemm_dln"], lambda a, w_, out, epi, dl, **kw: gemm_label(a, w_, out, epi, **kw) + ((" +dln-producer" if dl.mode == 1 else " +dln-consumer") if dl is not None else " +row-tiles"),
                          lambda a, w_, out, epi, dl, **kw: gemm_flops(a, w_, out, epi, **kw),
-                         lambda a, w_, out, epi, dl, **kw: gemm_bytes(a, w_, out, epi, **kw) + (float((kw.get("M") or a.shape[-2]) * kw.get("batch", 1) * w_.shape[-2] * es) if dl.mode == 1 else 0.0))
+                         lambda a, w_, out, epi, dl, **kw: gemm_bytes(a, w_, out, epi, **kw) + (float((kw.get("M") or a.shape[-2]) * kw.get("batch", 1) * w_.shape[-2] * es) if (dl is not None and dl.mode == 1) else 0.0))
     ops.layernorm_mean = timed(orig["layernorm_mean"], lambda x_, g_, b_, eps, out, mo, **kw: f"layernorm_vec_kernel D={x_.shape[-1]} affine=1 +mean",
                                lambda *a, **kw: 0.0,
                                lambda x_, g_, b_, eps, out, mo, **kw: float((kw.get("M") or x_.shape[0]) * x_.shape[-1] * (4 + out.element_size())))
     ops.layernorm_twice = timed(orig["layernorm_twice"], lambda x_, g_, b_, eps, eps2, out, rps, **kw: f"layernorm_twice_vec_kernel D={x_.shape[-1]}",
                                 lambda *a, **kw: 0.0,
                                 lambda x_, g_, b_, eps, eps2, out, rps, **kw: float(rps * kw.get("n_seq", 1) * x_.shape[-1] * (4 + out.element_size())))
-    ops.xattn_scores_dln = timed(orig["xattn_scores_dln"], lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: f"gemm16_kernel<EPI_SOFTMAX_HEADS> M={M * batch} N={H * Lp} K={x_.shape[-1]} +dln-consumer",
+    ops.xattn_scores_dln = timed(orig["xattn_scores_dln"], lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: f"gemm16_kernel<EPI_SOFTMAX_HEADS> M={M * batch} N={H * Lp} K={x_.shape[-1]}" + (" +dln-consumer" if dl is not None else " +row-tiles"),
                                  lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: 2.0 * M * batch * H * Lp * x_.shape[-1],
                                  lambda x_, sX, a_tab, c_tab, p_out, sP, M, H, Lp, batch, dl, **kw: float(M * batch * (x_.shape[-1] + H * Lp) * es + batch * H * Lp * x_.shape[-1] * es))
     ops.attention = timed(orig["attention"], lambda dt, a_, **kw: f"attn16_kernel Sq={a_.Sq} Sk={a_.Sk}",
@@ -633,9 +696,8 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     # included.  (HIP events cannot be read back when recorded during a capture on this stack, and an eager event pair times
     # the launch on an otherwise idle GPU at higher clocks: 12 % rosier than rocprofv3 of the graph, round 2.)
     n_rep = 8
-    side, sess.side = sess.side, None        # the stamped capture is one serial chain (the product graph runs the cross-attention
     capturing = False
-    try:                                     # operand build as a parallel branch beside layer 0's self-attention block)
+    try:
         ops.Graph.begin(st)
         capturing = True
         sess.enqueue_forward(st)
@@ -643,7 +705,6 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
         capturing = False
         g_fwd = ops.Graph().end(st)
     finally:
-        sess.side = side
         for k, v in orig.items():
             setattr(ops, k, v)
         if capturing:                        # an enqueue raised mid-capture: close the capture, or the stream stays unusable for
@@ -686,9 +747,8 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     sess.stream.synchronize()
     fwd_plain_us = 1e3 * e0.elapsed_ms(e1) / n_rep
     per = [(lab, fl, by, 1e-3 * acc_us[i] / n_rep) for i, (lab, fl, by) in enumerate(labels)]
-    timing = (f"in-graph: clock-stamp launches between the launches of the captured step (one serial chain; the product graph, "
-              f"forward_graph_replay_us, runs absorb_kernel as a parallel branch), {n_rep} replays; stamp-to-stamp overhead "
-              f"{stamp_us:.2f} us subtracted per interval")
+    timing = (f"in-graph: clock-stamp launches between the launches of the captured step (one serial chain, like the product graph "
+              f"forward_graph_replay_us), {n_rep} replays; stamp-to-stamp overhead {stamp_us:.2f} us subtracted per interval")
     agg, cls = {}, {}
     for lab, fl, by, ms in per:
         for d, key in ((agg, lab), (cls, lab.split(" M=")[0].split(" Sq=")[0].split(" D=")[0].split(" layers=")[0])):
@@ -1105,27 +1165,36 @@ def main():
         bcfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100,
                                eos_estimated_gen_length_factor=100.0, eos_penalty_factor=50.0, eos_penalty_decay=0.5)
 
-        def batch_leg(n_req, ar_b, nar_b, passes=2):
+        def batch_leg(n_req, ar_b, nar_b, passes=2, recheck=0):
             texts, trs, refs, max_lens = c3_requests(m, n_req, args.n_gen, seed=11)
             refs = [r.to(dev) for r in refs]
-            dtb, res = None, None
+            dtb, res, chk = None, None, {}
             for ps in range(passes):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                res = m.tts_batch_from_codes(texts, refs, trs, bcfg, seeds=[1000 + j for j in range(n_req)], nar_batch=nar_b, ar_batch=ar_b,
-                                             max_lens=max_lens)
-                torch.cuda.synchronize()
-                dtb = time.perf_counter() - t0
-            return {"value": round(sum(int(f.shape[0]) for _, f in res) / 75.0 / dtb, 4), "unit": "audio_s/s", "requests": n_req,
-                    "s_per_batch": round(dtb, 3), "reference_frames": [int(r.shape[-1]) for r in refs],
-                    "note": f"tts_batch_from_codes(ar_batch={ar_b}, nar_batch={nar_b}), pass {passes} of {passes} timed (pass 1 captures the graphs)"}
+                # the warm-up pass runs under the spy (it only reads generator states and keeps references): its group
+                # results are re-checked against lone calls after the timed pass
+                with (NarGroupSpy() if (recheck and ps == 0) else contextlib.nullcontext()) as spy:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    res = m.tts_batch_from_codes(texts, refs, trs, bcfg, seeds=[1000 + j for j in range(n_req)], nar_batch=nar_b, ar_batch=ar_b,
+                                                 max_lens=max_lens)
+                    torch.cuda.synchronize()
+                    dtb = time.perf_counter() - t0
+                if spy is not None:
+                    keep = spy
+            if recheck:
+                chk = keep.recheck(dev, k=recheck)
+            r = {"value": round(sum(int(f.shape[0]) for _, f in res) / 75.0 / dtb, 4), "unit": "audio_s/s", "requests": n_req,
+                 "s_per_batch": round(dtb, 3), "reference_frames": [int(r.shape[-1]) for r in refs],
+                 "note": f"tts_batch_from_codes(ar_batch={ar_b}, nar_batch={nar_b}), pass {passes} of {passes} timed (pass 1 captures the graphs)"}
+            r.update(chk)
+            return r
 
         leg("batch8_mixed_lengths", lambda: out.__setitem__("batch8_mixed_lengths", batch_leg(8, 8, 8)))
         if not args.no_extra_legs:
             # BASELINE configs[2] in full (32 mixed-length requests per step) and configs[4] (60 s long-form utterance): one
             # timed step each after one warm-up step, so that the driver's record carries them (`--workload c3 / c5` are the
             # stand-alone forms with their own time splits)
-            leg("c3_batch32", lambda: out.__setitem__("c3_batch32", batch_leg(32, args.ar_batch, args.nar_batch)))
+            leg("c3_batch32", lambda: out.__setitem__("c3_batch32", batch_leg(32, args.ar_batch, args.nar_batch, recheck=2)))
 
             def _c5():
                 global TEXT
@@ -1144,6 +1213,33 @@ def main():
                                       "nar_ms_per_step": round(_ne.LAST_STATS["loop_ms"] / _ne.LAST_STATS["steps"], 3), "nar_S": _ne.LAST_STATS["S"],
                                       "note": "BASELINE configs[4]: 60 s target, AR context past the 3000-slot rotating KV window; second utterance timed"}
             leg("c5_longform", _c5)
+
+            def _refprec():
+                # The headline runs in BASELINE's dtype (bf16 operands in both stages).  The reference itself computes the AR stage
+                # under fp16 autocast (ar_generate.py:59,67) and calls the NAR model in fp32 (diffuser.py:358-364, no autocast): the
+                # same utterance at THAT arithmetic -- f16 AR engine + the exact-fp32 NAR engine (the parity instrument of
+                # tests/test_gpu_e2e.py::test_full_size_goldens_f32: v_mfma_f32_16x16x4_f32 kernels, correct, not tuned) -- so the
+                # line states what the reference's own precision costs here.  One utterance, engines built before the clock starts.
+                from mars5_tts_amd import ar_engine as _ae, nar_engine as _ne
+                from mars5_tts_amd.ops import DT_NAME
+                try:
+                    m.codeclm.set_engine_dtype(torch.float16)
+                    m.codecnar.set_engine_dtype(torch.float32)
+                    m.codeclm.engine()
+                    m.codecnar.engine()
+                    torch.cuda.synchronize()
+                    dtr, nr, _ = run_utterance(m, ref_codes, cfg, 901)
+                    out["reference_precision"] = {
+                        "value": round(nr / 75.0 / dtr, 4), "unit": "audio_s/s", "s_per_utterance": round(dtr, 3), "generated_frames": nr,
+                        "ar_dtype": "f16", "nar_dtype": "f32", "ar_us_per_token": round(1e3 * _ae.LAST_STATS["decode_ms"] / max(_ae.LAST_STATS["n_generated"] - 1, 1), 1),
+                        "nar_ms_per_step": round(_ne.LAST_STATS["loop_ms"] / _ne.LAST_STATS["steps"], 3),
+                        "note": "the same configs[1] utterance at the reference's own arithmetic (fp16-autocast AR, fp32 NAR); one utterance, first of its "
+                                "engines (step-graph captures inside); the fp32 NAR engine is the bit-exact parity mode, not a tuned path"}
+                finally:
+                    m.codeclm.set_engine_dtype(DT_NAME[args.dtype])
+                    m.codecnar.set_engine_dtype(DT_NAME[args.dtype])
+                    STEP_LOG.pop() if STEP_LOG else None
+            leg("reference_precision", _refprec)
     if single and args.workload == "c2" and args.pipeline:
         # serving mode, reported beside (never as) the headline: the same utterances as a pipelined stream -- request i+1's AR
         # decode overlaps request i's NAR steps (Mars5TTS.tts_stream_from_codes); throughput up, per-request latency not

@@ -122,17 +122,6 @@ M5_API int m5_rope_cache(int dtype, const void* qkv, int M, int n_heads, int pos
                   void* q_out, void* kcache, void* vcache, int64_t cache_hs, int window,
                   void* vt_out, int64_t vt_hs, int64_t vt_ds, void* stream);
 
-/* Cross-attention query projection with the attention fused into its epilogue (nn.MultiheadAttention of the NAR
- * decoder against the text memory, model.py:179-203): out[M][H*64] = softmax(scale (A W^T + bias)_h K_h^T) V_h per head,
- * for memories of at most 64 keys whose K / V^T were projected beforehand.  Rows are grouped in sequences of
- * `rows_per_seq` (a multiple of 16); sequence s attends to the memory described by mem_table[s][6] (device int64):
- * {K base address, V^T base address, Le, Lep, step stride of K, step stride of V^T (elements)} with K [H][Le][64] and
- * V^T [H][64][Lep] inside the block selected by the device index *step (the DDPM step).  Returns M5_ERR_UNSUPPORTED
- * (nothing launched; use m5_gemm(EPI_QKV) + m5_attention) unless 16-bit operands, max_le <= 64, even n_heads. */
-M5_API int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                         int M, int n_heads, int K, const int64_t* mem_table, int max_le, int rows_per_seq,
-                         const int32_t* step, float scale, void* out, int64_t ld_out, void* stream);
-
 /* Cross-attention against a short memory with the projections absorbed into the memory (16-bit engines; NAR decoder,
  * model.py:179-203).  Per head h: scores = x (K_h Wq_h / 8)^T + K_h bq_h / 8 =: x A_h^T + c_h and
  * out = sum_h softmax(scores_h) (V_h Wo_h^T) + bo =: P B + bo, so a layer needs two GEMMs of width n_heads * Lp instead of
@@ -186,11 +175,17 @@ typedef struct {
  * row tiles b * (rows_per_seq / BM) + t with t * BM < len_b (device int32, n[i] entries, ascending); a launch that gets the
  * lists runs only those tiles (the kernel picks the list of its own tile height), so the padding costs nothing and the
  * XCD-contiguous tile order stays balanced.  Flat launches (batch = 1, M = all rows) and batched ones (batch = sequences,
- * M = rows_per_seq) use the same lists.  Rows of tiles that are not listed are neither read nor written. */
+ * M = rows_per_seq) use the same lists.  Rows of tiles that are not listed are neither read nor written.
+ * The three lists cover DIFFERENT pad rows of a sequence (ceil(len / BM) * BM differs per height), so a pad row may be read by a
+ * consumer of one height after only a producer of another height -- or none -- wrote it: every buffer of the layout must
+ * start out finite (the host zero-fills), and with seq_len given a deferred-LayerNorm consumer treats the rows >= len_b of
+ * its tiles as d = r = 0 (output = b' alone: finite whatever partials the row holds), so nothing a pad row carries can grow
+ * through the 1 / sqrt(eps) of a stale statistic into an Inf that p = 0 would turn into NaN inside a real row's attention. */
 typedef struct {
     const int32_t* map[3];    /* BM = 96, 128, 192                                                */
     int32_t n[3];
     int32_t rows_per_seq;
+    const int32_t* seq_len;   /* [sequences] device int32: len_b (may be NULL: no pad-row treatment) */
 } M5RowTiles;
 /* m5_gemm / m5_xattn_scores with either or both of the two (NULL = without). */
 M5_API int m5_gemm_ex(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
@@ -207,22 +202,6 @@ M5_API int m5_layernorm_twice(int out_dtype, const float* x, int64_t ldx, const 
                        void* y, int64_t ldy, int rows_per_seq, int n_seq, int64_t x_seq_stride, int D, void* stream);
 M5_API int m5_layernorm_mean(int out_dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                       void* y, int64_t ldy, int M, int D, float* mean_out, void* stream);
-
-/* x[M][N] += A . W^T + bias (the RESIDUAL epilogue of m5_gemm) with the LayerNorm that follows it in every pre-LN
- * block (model.py:179-203: norm2 / norm3 / the next layer's norm1) fused into the same launch:
- * xn = LayerNorm(x_new; gamma, beta, eps) in the operand type.  The workgroups of a row tile exchange per-tile
- * (mean, M2) words through `scratch` (M2 carries an 8-bit launch tag in its low mantissa bits), so the WHOLE grid
- * must be co-resident: returns M5_ERR_UNSUPPORTED (caller falls back to m5_gemm + m5_layernorm) unless 16-bit
- * operands, N % 128 == 0, N <= 2048 and ceil(M/96) * N/128 <= number of CUs.
- * scratch: zero-initialised once by the caller, >= 256 + 768 ceil(M/96) N/128 bytes, reusable by later calls on the
- * same stream PROVIDED consecutive calls carry different launch tags: tag = 1 + (*tag_step * 64 + tag) % 255 with
- * tag_step a device int32 (or NULL = 0) -- under hipGraph replay the kernel arguments are frozen, so the varying part
- * must live in device memory (the DDPM step counter).  scratch[0] (uint32) counts wait timeouts (0 in a healthy run;
- * waits are bounded, a launch never hangs). */
-M5_API int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
-                        float* C, int64_t ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
-                        float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes,
-                        const int32_t* tag_step, int tag, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * AR decode step (one token, batch 1): weight-streaming GEMV with fused prologue/epilogue.
@@ -402,6 +381,35 @@ M5_API int m5_clock_stamp(uint64_t* slot, void* stream);
 #ifdef M5_TOOLS
 /* ---- tools library only (libmars5_hip_tools.so, built with -DM5_TOOLS; the scripts under tools/ load it with M5_HIP_TOOLS=1).  The
  * product library libmars5_hip.so exports none of these, reads no environment variable and contains no ablation kernel. */
+
+/* ---- Two fusions that were built, tested and measured SLOWER inside the NAR step on MI355X: they are kept as
+ * A/B instruments of the tools library (tools/nar_step_bench.py "M5_GEMM_XATTN=1" / "M5_GEMM_LN=1"), not shipped. */
+/* Cross-attention query projection with the attention fused into its epilogue (nn.MultiheadAttention of the NAR
+ * decoder against the text memory, model.py:179-203): out[M][H*64] = softmax(scale (A W^T + bias)_h K_h^T) V_h per head,
+ * for memories of at most 64 keys whose K / V^T were projected beforehand.  Rows are grouped in sequences of
+ * `rows_per_seq` (a multiple of 16); sequence s attends to the memory described by mem_table[s][6] (device int64):
+ * {K base address, V^T base address, Le, Lep, step stride of K, step stride of V^T (elements)} with K [H][Le][64] and
+ * V^T [H][64][Lep] inside the block selected by the device index *step (the DDPM step).  Returns M5_ERR_UNSUPPORTED
+ * (nothing launched; use m5_gemm(EPI_QKV) + m5_attention) unless 16-bit operands, max_le <= 64, even n_heads. */
+M5_API int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                         int M, int n_heads, int K, const int64_t* mem_table, int max_le, int rows_per_seq,
+                         const int32_t* step, float scale, void* out, int64_t ld_out, void* stream);
+
+/* x[M][N] += A . W^T + bias (the RESIDUAL epilogue of m5_gemm) with the LayerNorm that follows it in every pre-LN
+ * block (model.py:179-203: norm2 / norm3 / the next layer's norm1) fused into the same launch:
+ * xn = LayerNorm(x_new; gamma, beta, eps) in the operand type.  The workgroups of a row tile exchange per-tile
+ * (mean, M2) words through `scratch` (M2 carries an 8-bit launch tag in its low mantissa bits), so the WHOLE grid
+ * must be co-resident: returns M5_ERR_UNSUPPORTED (caller falls back to m5_gemm + m5_layernorm) unless 16-bit
+ * operands, N % 128 == 0, N <= 2048 and ceil(M/96) * N/128 <= number of CUs.
+ * scratch: zero-initialised once by the caller, >= 256 + 768 ceil(M/96) N/128 bytes, reusable by later calls on the
+ * same stream PROVIDED consecutive calls carry different launch tags: tag = 1 + (*tag_step * 64 + tag) % 255 with
+ * tag_step a device int32 (or NULL = 0) -- under hipGraph replay the kernel arguments are frozen, so the varying part
+ * must live in device memory (the DDPM step counter).  scratch[0] (uint32) counts wait timeouts (0 in a healthy run;
+ * waits are bounded, a launch never hangs). */
+M5_API int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                        float* C, int64_t ldc, int M, int N, int K, const float* ln_gamma, const float* ln_beta,
+                        float ln_eps, void* xn, int64_t ld_xn, void* scratch, int64_t scratch_bytes,
+                        const int32_t* tag_step, int tag, void* stream);
 
 /* Diagnostics: placement census of a grid (nblocks x threads, lds_bytes of LDS per workgroup);
  * out[6 * block] = {XCC_ID, HW_ID, start clock lo/hi, end clock lo/hi}.  tools/census.py. */

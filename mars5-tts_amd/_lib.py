@@ -18,6 +18,16 @@ LIB_PATH = os.path.join(_HERE, "libmars5_hip_tools.so" if TOOLS else "libmars5_h
 if TOOLS and os.environ.get("M5_HIP_TOOLS_LIB"):          # same-box A/B of two tools builds (tools/*.py only)
     LIB_PATH = os.environ["M5_HIP_TOOLS_LIB"]
 
+
+
+def tool_knob(name: str, default: str) -> str:
+    """A/B knob of the host engines (tools/nar_step_bench.py, tools/ar_step_bench.py: "KNOB=0" "KNOB=1" in one process).  Knobs exist
+    in the TOOLS configuration only (M5_HIP_TOOLS=1, which tools/*.py set before importing the package): the product reads no
+    environment variable besides M5_HIP_TOOLS here and MARS5_DTYPE in model.py (tests/test_host_cpu.py checks the sources), so
+    no untested configuration can be selected in a deployment."""
+    return os.environ.get(name, default) if TOOLS else default
+
+
 M5_OK, M5_ERR_ARG, M5_ERR_LAUNCH, M5_ERR_UNSUPPORTED = 0, -1, -2, -3
 F32, F16, BF16 = 0, 1, 2
 EPI_F32, EPI_DT, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV, EPI_SILU_DT = 0, 1, 2, 3, 4, 5
@@ -119,7 +129,7 @@ class NarSampleArgs(C.Structure):
 
 class RowTiles(C.Structure):
     """M5RowTiles (include/mars5_hip.h): the row tiles of a padded batch layout that hold real rows, per tile height 96 / 128 / 192."""
-    _fields_ = [("map", vp * 3), ("n", i32 * 3), ("rows_per_seq", i32)]
+    _fields_ = [("map", vp * 3), ("n", i32 * 3), ("rows_per_seq", i32), ("seq_len", vp)]
 
 
 class DeferredLN(C.Structure):
@@ -134,9 +144,6 @@ PROTOTYPES = {
     "m5_build_info": (C.c_char_p, []),
     "m5_gemm": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int,
                           C.POINTER(QkvScatter), C.c_int, i64, i64, i64, i64, vp]),
-    "m5_gemm_q_cross_attn": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, f32, vp, i64, vp]),
-    "m5_gemm_residual_ln": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, f32, vp, i64, vp, i64,
-                                       vp, C.c_int, vp]),
     "m5_xattn_absorb": (C.c_int, [C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, f32, vp]),
     "m5_xattn_scores": (C.c_int, [C.c_int, vp, i64, i64, vp, i64, vp, i64, vp, i64, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "m5_gemm_ex": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -175,6 +182,9 @@ PROTOTYPES = {
 }
 # exported by libmars5_hip_tools.so only (header: #ifdef M5_TOOLS)
 TOOLS_PROTOTYPES = {
+    "m5_gemm_q_cross_attn": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, f32, vp, i64, vp]),
+    "m5_gemm_residual_ln": (C.c_int, [C.c_int, vp, i64, vp, i64, vp, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp, f32, vp, i64, vp, i64,
+                                       vp, C.c_int, vp]),
     "m5_debug_census": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "m5_debug_gemm_clock": (C.c_int, [vp]),
     "m5_debug_feed_probe": (C.c_int, [vp, i64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),

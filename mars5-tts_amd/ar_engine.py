@@ -16,7 +16,6 @@ What is different from the reference by design (all exact):
 from __future__ import annotations
 
 import contextlib
-import os
 import threading
 from dataclasses import dataclass
 from typing import Dict, List, Optional
@@ -79,7 +78,7 @@ def _mega_default() -> bool:
     """Persistent-layers form of the batch-1 decode step (csrc/ar_mega.hip): on unless M5_AR_MEGA=0.  It computes the same
     bits as the per-launch form (tests/test_gpu_parity16.py) and applies to the 16-bit CodecLM geometry on a device with
     at least 256 CUs; anything else runs the per-launch form."""
-    return os.environ.get("M5_AR_MEGA", "1") != "0"
+    return L.tool_knob("M5_AR_MEGA", "1") != "0"
 
 
 class ARModel:
@@ -248,8 +247,8 @@ class ARSession:
             self.mega = False                                  # geometry / device not eligible: per-launch form from here on
         # same-stream prefetch plan (M5Prefetch): 0 off; 1 every launch pulls the NEXT launch's weights; 2 only the two
         # bandwidth-idle launches (cache scan, Wo) pull the two halves of W1|W3.  16-bit streaming geometry only.
-        plan = int(os.environ.get("M5_AR_PREFETCH", "0")) if (m.dt != torch.float32 and D == 1536 and F == 3584) else 0
-        npf = int(os.environ.get("M5_AR_PREFETCH_WGS", "64"))
+        plan = int(L.tool_knob("M5_AR_PREFETCH", "0")) if (m.dt != torch.float32 and D == 1536 and F == 3584) else 0
+        npf = int(L.tool_knob("M5_AR_PREFETCH_WGS", "64"))
         for l in range(s.n_layers):
             nxt = m.wqkv[l + 1] if l + 1 < s.n_layers else m.w_out
             a = self._gemv_args(W=m.wqkv[l], ldw=D, N=3 * D, K=D, x_f32=self.xdec, norm_w=m.attn_norm[l], eps=s.norm_eps,

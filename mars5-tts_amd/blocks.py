@@ -448,15 +448,11 @@ def cross_attn_block(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, ste
 
 
 def decoder_layer(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, step_ptr: torch.Tensor, stream=None,
-                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None, xa=None, plan=None, layer: int = 0,
-                  before_cross=None) -> bool:
+                  key_len: Optional[torch.Tensor] = None, normed: bool = False, next_ln=None, xa=None, plan=None, layer: int = 0) -> bool:
     """One pre-LN decoder layer.  Each residual GEMM tries to leave the NEXT LayerNorm's output in ws.xn (fused
     epilogue); `normed` says the caller (previous layer) already did that for norm1, the return value says whether
-    `next_ln` (the following layer's norm1) has been applied on exit.  `before_cross()` runs between the self- and the
-    cross-attention block (the join of the side stream that builds the step's cross-attention operands)."""
+    `next_ln` (the following layer's norm1) has been applied on exit."""
     n = self_attn_block(x, lw, ws, key_len, stream, normed=normed, next_ln=(lw.n2_w, lw.n2_b))
-    if before_cross is not None:
-        before_cross()
     n = cross_attn_block(x, lw, ws, mems, step_ptr, stream, normed=n, next_ln=(lw.n3_w, lw.n3_b), xa=xa, plan=plan, layer=layer)
     return ff_block(x, lw, ws, lw.n3_w, lw.n3_b, stream, normed=n, next_ln=next_ln)
 
@@ -478,7 +474,17 @@ class RowTiles:
             ns.append(len(e))
         self.n, self.Sr, self.lens = ns, Sr, list(lens)
         self._subs = {}
-        self.c = L.RowTiles(map=(L.vp * 3)(*[m.data_ptr() for m in self.maps]), n=(L.i32 * 3)(*ns), rows_per_seq=Sr)
+        # the sequences' own lengths: the three lists cover different pad rows (ceil(len / BM) * BM), so the deferred-LayerNorm
+        # consumers give the pad rows of their tiles d = r = 0 (include/mars5_hip.h, M5RowTiles.seq_len)
+        self.len_dev = torch.tensor(self.lens, dtype=torch.int32, device="cpu").to(dev)
+        self.c = L.RowTiles(map=(L.vp * 3)(*[m.data_ptr() for m in self.maps]), n=(L.i32 * 3)(*ns), rows_per_seq=Sr,
+                            seq_len=self.len_dev.data_ptr())
+
+    def prebuild(self, runs) -> None:
+        """Make the sub-lists of the runs [(s0, n), ...] of sequences now (a small host -> device copy each), so that the launch
+        sequence itself -- which may be under stream capture -- allocates and copies nothing."""
+        for s0, n in runs:
+            _rt_sub(self, s0, n)
 
 
 def _rt_sub(rt: Optional[RowTiles], s0: int, n: int):
@@ -532,7 +538,7 @@ def _plain_cross_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, mems, s0:
 
 
 def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr: torch.Tensor, dl: DeferredLN, plan, layer: int,
-                      chain_in: bool, chain_out: bool, stream=None, key_len: Optional[torch.Tensor] = None, before_cross=None,
+                      chain_in: bool, chain_out: bool, stream=None, key_len: Optional[torch.Tensor] = None,
                       skip_self: bool = False, rt: Optional[RowTiles] = None, mems=None) -> None:
     """One pre-LN decoder layer with its LayerNorms DEFERRED into the GEMMs that consume them (include/mars5_hip.h,
     M5DeferredLN; reference model.py:179-203, same mathematics): every residual GEMM leaves a centred 16-bit copy of the rows
@@ -563,8 +569,6 @@ def decoder_layer_dln(x: torch.Tensor, lw: EncLayerW, ws: SeqWorkspace, step_ptr
                 ops.gemm_dln(ws.att, lw.out_w, x, L.EPI_RESIDUAL, None, bias=lw.out_b, stream=stream, rt=rc)
         else:
             ops.gemm_dln(ws.att, lw.out_w, x, L.EPI_RESIDUAL, dl.producer(ws), bias=lw.out_b, stream=stream, rt=rc)
-    if before_cross is not None:
-        before_cross()
     if first:
         ops.layernorm_mean(x, lw.n2_w, lw.n2_b, LAYERNORM_EPS, ws.xn, dl.start(), stream=stream)
     for i, seg in enumerate(plan):

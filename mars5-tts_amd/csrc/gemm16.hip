@@ -78,6 +78,8 @@ struct Gemm16Params {
     // lives in one padded layout (rows_per_seq rows each); the tiles that hold nothing but padding are not launched, and
     // the XCD-contiguous tile order runs over the compacted list (balanced whatever the lengths are).
     const int* rt_map; int rt_tpb;               // entry e -> batch e / rt_tpb, row tile e % rt_tpb (rt_tpb = 0: flat, row tile e)
+    const int* rt_len; int rt_rps;               // real rows per sequence (nullptr: none) and rows per sequence of the padded layout:
+                                                 // a deferred-LayerNorm consumer gives the pad rows of its tiles d = r = 0
     const M5RowTiles* rt_host;                   // host side only: the caller's lists (launch16 picks the one of its tile height)
 };
 
@@ -93,6 +95,8 @@ bool rt_apply(Gemm16Params& p, int batch) {
         p.rt_map = rt->map[idx];
         p.tilesM = rt->n[idx];
         p.rt_tpb = batch > 1 ? rt->rows_per_seq / BM : 0;
+        p.rt_len = rt->seq_len;
+        p.rt_rps = rt->rows_per_seq;
         return true;
     }
 }
@@ -643,13 +647,22 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
         // tile of a row derives the same two numbers); column tile 0 leaves the row's new centre for the next producer.
         // (visible to the epilogues behind their __syncthreads(); the partials are older than every K-step's barrier)
         const int np = p.dl_np;
+        // Row-tile lists: the tile's rows past its sequence's own length are padding that another tile height's producer may
+        // never have written (stale partials -> r up to 1 / sqrt(eps)): they get d = r = 0, i.e. the bias alone -- finite.
+        int real_rows = BM;
+        if (p.rt_len) {
+            const int sq = p.rt_tpb ? bz : m0 / p.rt_rps;               // (a tile never straddles sequences: rows_per_seq % BM == 0)
+            real_rows = p.rt_len[sq] - (p.rt_tpb ? m0 : m0 - sq * p.rt_rps);
+        }
         for (int r = tid; r < BM; r += NW * 64) {
             float2* pr = reinterpret_cast<float2*>(dl_lds + r * np * 8);
             float s1 = 0.f, s2 = 0.f;
             for (int n = 0; n < np; ++n) { const float2 v = pr[n]; s1 += v.x; s2 += v.y; }
-            const float d = s1 * p.dl_inv_n;
+            float d = s1 * p.dl_inv_n;
             const float var = fmaxf(s2 * p.dl_inv_n - d * d, 0.f);
-            pr[0] = make_float2(d, 1.0f / sqrtf(var + p.dl_eps));       // in place: this thread is the row's only reader
+            float rs = 1.0f / sqrtf(var + p.dl_eps);
+            if (r >= real_rows) { d = 0.f; rs = 0.f; }
+            pr[0] = make_float2(d, rs);                                  // in place: this thread is the row's only reader
             if (tn == 0 && p.dl_delta && m0 + r < p.M) p.dl_delta[dl_row0 + r] = d;          // a store, no load: nothing here waits on memory
         }
     }
@@ -1548,6 +1561,7 @@ static int dl_fill(Gemm16Params& p, const M5DeferredLN* dl, int epi_kind /* 1 pr
     return M5_OK;
 }
 
+#ifdef M5_TOOLS    // tools library only: measured slower inside the NAR step; kept as an A/B instrument
 // Q projection with the cross-attention it feeds fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
 // (M5_ERR_UNSUPPORTED otherwise; the caller then runs m5_gemm(EPI_QKV) + m5_attention): 16-bit operands, head_dim 64,
 // memory length <= 64, rows per sequence a multiple of 16.
@@ -1581,6 +1595,8 @@ extern "C" int m5_gemm_q_cross_attn(int dtype, const void* A, int64_t lda, const
     M5_CHECK_LAUNCH();
     return M5_OK;
 }
+
+#endif  // M5_TOOLS
 
 // Scores + per-head softmax of the absorbed cross-attention (include/mars5_hip.h, xattn_absorb.hip): P[b] = softmax_heads(
 // X[b] A[b]^T + c[b]) for `batch` sequences, head blocks of Lp = 48 or 64 columns (one per wave), 96-row tiles.
@@ -1656,6 +1672,7 @@ extern "C" int m5_xattn_scores_ex(int dtype, const void* X, int64_t ldx, int64_t
     return xattn_scores_impl(dtype, X, ldx, sX, A, sA_tab, c, sc_tab, P, ldp, sP, M, n_heads, Lp, K, batch, dl, rt, stream);
 }
 
+#ifdef M5_TOOLS    // tools library only: measured slower than GEMM + LayerNorm launches
 // Residual GEMM with the following LayerNorm fused into its epilogue (include/mars5_hip.h).  Eligible shapes only
 // (M5_ERR_UNSUPPORTED otherwise; the caller then runs m5_gemm + m5_layernorm): 16-bit operands, batch 1, region 96x128
 // tiling with the whole grid co-resident (one workgroup per CU), N a multiple of 128 and <= 2048.
@@ -1694,8 +1711,6 @@ extern "C" int m5_gemm_residual_ln(int dtype, const void* A, int64_t lda, const 
     return M5_OK;
 }
 
-
-#ifdef M5_TOOLS
 extern "C" int m5_debug_gemm_clock(unsigned long long* buf) {   // diagnostics (tools/gemm_clock.py); nullptr disables
     g_gemm_dbg = buf;
     return M5_OK;

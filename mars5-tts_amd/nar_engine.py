@@ -22,7 +22,6 @@ like the reference on the same device.
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
 
@@ -135,78 +134,14 @@ class NARConfig:
     div_mode: int = 0
 
 
-def _build_cross_operands(plan, step_ptr: torch.Tensor, main: torch.cuda.Stream, side: Optional[torch.cuda.Stream], st: int):
+def _build_cross_operands(plan, step_ptr: torch.Tensor, st: int) -> None:
     """Enqueue the launch that rebuilds the step's absorbed cross-attention operands (A, c, B^T of all 16 layers for this
-    step's memory block: HBM-bound, ~65 us, needed first by layer 0's CROSS-attention) and return the function that makes
-    `main` wait for it.  With a side stream (M5_NAR_SIDE=1, an A/B knob) the launch forks off `main` here and joins in front
-    of the first cross-attention block, so it runs beside the embedding and layer 0's self-attention block instead of in
-    front of them (under capture: a parallel branch of the step graph).  Measured on one box: 3.19 ms per step against 3.14
-    with the build in line -- the fork / join of a two-branch graph costs more than the 65 us it hides -- so it is off."""
-    segs = [seg[1] for seg in plan if seg[0] == "absorbed"]
-    if not segs:
-        return lambda: None
-    if side is None:
-        for sg in segs:
-            sg.build(step_ptr, st)
-        return lambda: None
-    side.wait_stream(main)
-    for sg in segs:
-        sg.build(step_ptr, side.cuda_stream)
-    state = {"joined": False}
-
-    def join() -> None:
-        if not state["joined"]:
-            main.wait_stream(side)
-            state["joined"] = True
-    return join
-
-
-class _UniformRing:
-    """(Opt-in, M5_NAR_RNG_SIDE=1: measured slower, see _ring_ok.)
-    The step's torch.rand draws (2 x 17 us at the bench shape, independent of the forward) on a second stream, into a ring
-    of two preallocated buffer pairs, so that they execute beside the forward instead of between the forward and the sample
-    kernel.  Only for draw callables that can fill a given buffer (``draw.out_ok``: diffuser's generator-backed ones -- the
-    same calls on the same generator, so the same values); anything else is drawn on the main stream as before.  No allocator
-    traffic crosses streams: pair k is rewritten only after the event recorded behind the sample kernel that read it."""
-
-    def __init__(self, main: torch.cuda.Stream, shapes: List[tuple], dev):
-        self.main = main
-        self.side = torch.cuda.Stream(device=dev)
-        self.buf = [[(torch.empty(sh, dtype=torch.float32, device=dev), torch.empty(sh, dtype=torch.float32, device=dev)) for sh in shapes]
-                    for _ in range(2)]
-        self.read_done: List[Optional[torch.cuda.Event]] = [None, None]
-        self.i = 0
-
-    def draw(self, draws: List[Callable], need_u2: bool) -> List[tuple]:
-        """Enqueue this step's draws on the second stream; returns [(u1, u2 or None)] per draw callable.  Call ``ready()``
-        on the main stream's side before the consumer and ``consumed()`` after it."""
-        k = self.i & 1
-        if self.read_done[k] is not None:
-            self.side.wait_event(self.read_done[k])
-        out = []
-        with torch.cuda.stream(self.side):
-            for d, (b1, b2) in zip(draws, self.buf[k]):
-                u1 = d(tuple(b1.shape), out=b1)
-                out.append((u1, d(tuple(b2.shape), out=b2) if need_u2 else None))
-            self._ev = torch.cuda.Event()
-            self._ev.record(self.side)
-        return out
-
-    def ready(self) -> None:
-        self.main.wait_event(self._ev)
-
-    def consumed(self) -> None:
-        ev = torch.cuda.Event()
-        ev.record(self.main)
-        self.read_done[self.i & 1] = ev
-        self.i += 1
-
-
-def _ring_ok(draws) -> bool:
-    # A/B knob, OFF: measured 3.15 vs 3.08 ms per step with the draws on the second stream (profiles/r3z2_*) -- the two
-    # cross-stream event waits per step cost more than the 34 us of draws they take off the chain (same finding as the
-    # operand build on a side stream: on this stack every cross-stream dependency inside a step is a loss).
-    return os.environ.get("M5_NAR_RNG_SIDE", "0") == "1" and all(getattr(d, "out_ok", False) for d in draws)
+    step's memory block: HBM-bound, ~65 us, needed first by layer 0's CROSS-attention).  (As a parallel graph branch beside
+    layer 0's self-attention block it measured 45 us per step SLOWER, profiles/r3w_*: on this stack every cross-stream
+    dependency inside a step costs more than it hides; that variant and the second-stream uniform draws are gone.)"""
+    for seg in plan:
+        if seg[0] == "absorbed":
+            seg[1].build(step_ptr, st)
 
 
 class NARSession:
@@ -309,7 +244,7 @@ class NARSession:
             Lep = round_up(Le, 64)
             self.mems: List[CrossMemory] = []
             # short memory: K and V as rows for the absorbed form (blocks.AbsorbedCross); M5_NAR_ABSORB=0: A/B knob (tools/nar_step_bench.py)
-            absorbed = dt != torch.float32 and AbsorbedCross.lp_of(Le, H) > 0 and H * 64 <= FF and os.environ.get("M5_NAR_ABSORB", "1") != "0"
+            absorbed = dt != torch.float32 and AbsorbedCross.lp_of(Le, H) > 0 and H * 64 <= FF and L.tool_knob("M5_NAR_ABSORB", "1") != "0"
             for lw in mdl.dec:
                 k = torch.empty(T * nb, H, Le, 64, dtype=dt, device=dev)
                 if absorbed:
@@ -343,18 +278,17 @@ class NARSession:
             self.Sr = Sr = self.ws.Sr
             # the two guidance branches enter the decoder with the SAME rows (x_t embedding + timestep vector) and first
             # differ in layer 0's cross-attention, so layer 0's self-attention block runs once (one-sequence workspace)
-            share0 = os.environ.get("M5_NAR_SHARE0", "1") != "0"          # A/B knob (tools/nar_step_bench.py)
-            over = self.ws if os.environ.get("M5_NAR_ALIAS", "1") != "0" else None     # A/B knob: private buffers for the two sub-problems
+            share0 = L.tool_knob("M5_NAR_SHARE0", "1") != "0"          # A/B knob (tools/nar_step_bench.py)
+            over = self.ws if L.tool_knob("M5_NAR_ALIAS", "1") != "0" else None     # A/B knob: private buffers for the two sub-problems
             self.ws0 = SeqWorkspace(1, S, D, FF, dt, dev, row_pad=64, inside=over) if (nb == 2 and share0) else None
             self.h = torch.zeros(nb, Sr, D, dtype=torch.float32, device=dev)
             self.hf = torch.zeros(nb * Sr, D, dtype=torch.float32, device=dev)
-            self.hn = torch.empty(Q - 1, nb * self.s_out, D, dtype=dt, device=dev)       # (folded heads use the first slab only)
             self.Kp = round_up(K, 4)
             self.logits = torch.empty(nb * self.s_out, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
             self.step_i = 0
             # cross-attention path of this utterance: absorbed operands (rebuilt per step by one launch) or the reference order
-            want_dln = DeferredLN.eligible(D, dt) and os.environ.get("M5_NAR_DLN", "1") != "0"      # A/B knob (tools/nar_step_bench.py)
+            want_dln = DeferredLN.eligible(D, dt) and L.tool_knob("M5_NAR_DLN", "1") != "0"      # A/B knob (tools/nar_step_bench.py)
             self.plan = make_cross_plan(mdl.dec, [[mem] for mem in self.mems], D, dt, dev, dln=want_dln)
             # LayerNorms deferred into the consuming GEMMs (blocks.decoder_layer_dln) when every utterance takes the absorbed path
             self.dl = DeferredLN(self.ws, dev) if (want_dln and plan_allows_dln(self.plan)) else None
@@ -366,13 +300,14 @@ class NARSession:
             so_r = round_up(self.s_out, 64)
             # (not with deferred LayerNorms: the compact layer would cost a row copy + three explicit LayerNorm launches to save
             # 0.1 % of the step)
-            if self.dl is None and self.row_offset > 0 and 4 * so_r <= 3 * Sr and os.environ.get("M5_NAR_LASTROWS", "1") != "0":
+            if self.dl is None and self.row_offset > 0 and 4 * so_r <= 3 * Sr and L.tool_knob("M5_NAR_LASTROWS", "1") != "0":
                 self.ws_l = SeqWorkspace(nb, self.s_out, D, FF, dt, dev, row_pad=64, inside=over)
                 self.x_l = torch.zeros(nb, so_r, D, dtype=torch.float32, device=dev)
                 self.hf_l = torch.zeros(nb * so_r, D, dtype=torch.float32, device=dev)
-        # A/B knob, off: as a parallel graph branch the build makes the step 45 us SLOWER (profiles/r3w_*): see _build_cross_operands
-        self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
-        self._ring = None                      # _UniformRing, made at the first step that can use it
+            # folded heads (one normalised copy feeds ONE GEMM over all heads) unless the compact last layer is in use; the
+            # reference order keeps one normalised slab per head
+            self.fold_heads = mdl.head_wf is not None and self.ws_l is None and L.tool_knob("M5_NAR_HEADFOLD", "1") != "0"
+            self.hn = torch.empty(1 if self.fold_heads else Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
         self.graph = None
 
     # ----------------------------------------------------------------------------- step
@@ -409,7 +344,7 @@ class NARSession:
         S, Sr, nb, D = self.S, self.Sr, self.nb, s.dim
         hx = self.h.view(nb * Sr, D)
         nl = len(mdl.dec)
-        join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
+        _build_cross_operands(self.plan, self.step_ptr, st)
         skip0 = False
         if self.ws0 is not None:
             # layer 0's self-attention block once for both guidance branches (they enter the decoder with the same rows)
@@ -425,8 +360,7 @@ class NARSession:
                               rows=S, stream=st)
         for l, lw in enumerate(mdl.dec):
             decoder_layer_dln(hx, lw, self.ws, self.step_ptr, self.dl, self.plan, l, chain_in=l > 0, chain_out=l + 1 < nl, stream=st,
-                              before_cross=join if l == 0 else None, skip_self=(skip0 and l == 0), mems=[self.mems[l]])
-        join()
+                              skip_self=(skip0 and l == 0), mems=[self.mems[l]])
 
     def enqueue_forward(self, st: int) -> None:
         """x_t -> logits for both guidance branches (the loop body's GEMM/attention work)."""
@@ -439,7 +373,7 @@ class NARSession:
             return
         layers = list(zip(mdl.dec, self.mems))
         self.ws.ln_tag, self.ws.ln_tag_step = 0, self.step_ptr      # fused LN launches: tag = f(step counter, call index)
-        join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
+        _build_cross_operands(self.plan, self.step_ptr, st)
         if self.ws0 is not None:
             ops.chunked_embed(self.h[:1], mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
                               rows=S, stream=st)
@@ -448,7 +382,6 @@ class NARSession:
             ops.mark("torch copy: branch 0 -> branch 1", st)
             with torch.cuda.stream(self.stream):
                 self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
-            join()
             nxt = (mdl.dec[1].n1_w, mdl.dec[1].n1_b) if len(mdl.dec) > 1 else None
             normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b), xa=self.xa[0], plan=self.plan, layer=0)
             normed = ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st, normed=normed, next_ln=nxt)
@@ -462,13 +395,10 @@ class NARSession:
         for k, (lw, mem) in enumerate(layers):
             l = l0 + k                                         # every LayerNorm but the first rides on the residual GEMM before it
             if compact and l == len(mdl.dec) - 1:
-                join()                                         # (a one-layer decoder: no earlier join)
                 self._last_layer_compact(lw, mem, normed, st)
                 break
             nxt = (mdl.dec[l + 1].n1_w, mdl.dec[l + 1].n1_b) if l + 1 < len(mdl.dec) else None
-            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l], plan=self.plan, layer=l,
-                                   before_cross=join if l == 0 else None)
-        join()
+            normed = decoder_layer(hx, lw, self.ws, mem, self.step_ptr, st, normed=normed, next_ln=nxt, xa=self.xa[l], plan=self.plan, layer=l)
         self._enqueue_heads(hx, st, compact)
 
     def _enqueue_heads(self, hx: torch.Tensor, st: int, compact: bool = False) -> None:
@@ -476,7 +406,7 @@ class NARSession:
         mdl, s = self.m, self.m.shape
         Sr, nb, D, Q = self.Sr, self.nb, s.dim, s.n_codebooks
         so = self.s_out
-        if mdl.head_wf is not None and not compact and os.environ.get("M5_NAR_HEADFOLD", "1") != "0":      # A/B knob (tools/nar_step_bench.py)
+        if self.fold_heads:
             # final LayerNorm + the heads' (folded) LayerNorm of the generated rows of both branches in one launch, then ONE GEMM
             ops.layernorm_twice(hx[self.row_offset:], mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, 1e-5, self.hn[0], so, n_seq=nb, x_seq_stride=Sr,
                                 stream=st)
@@ -508,17 +438,10 @@ class NARSession:
         ops.add_int(self.step_ptr, 1, stream=st)
 
     def step(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True) -> None:
-        """One reverse step t = times[step_i]: draw uniforms (beside the forward when the callable allows: _UniformRing),
-        forward (graph), sample."""
+        """One reverse step t = times[step_i]: forward (graph), uniform draws, sample."""
         st = self.stream.cuda_stream
         t = self.times[self.step_i]
         shape = (1, self.S, self.m.shape.n_codebooks, self.m.shape.n_quant)
-        ring = None
-        if _ring_ok([uniform]):
-            if self._ring is None:
-                self._ring = _UniformRing(self.stream, [shape], self.m.dev)
-            ring = self._ring
-            (u1, u2), = ring.draw([uniform], t > 0)
         if use_graph and self.graph is None and self.step_i == 0 and len(self.times) > 1:
             # The first step goes out launch by launch, and the step graph is captured (a few ms of host time) while the GPU works on
             # it: with the capture in front of the first step the GPU sat idle for its duration (round 4).
@@ -532,14 +455,9 @@ class NARSession:
         else:
             self.enqueue_forward(st)
         with torch.cuda.stream(self.stream):
-            if ring is None:
-                u1 = uniform(shape)
-                u2 = uniform(shape) if t > 0 else None
-            else:
-                ring.ready()
+            u1 = uniform(shape)
+            u2 = uniform(shape) if t > 0 else None
             self.enqueue_sample(u1[0], u2[0] if u2 is not None else None, st)
-            if ring is not None:
-                ring.consumed()
         self.step_i += 1
 
     def run(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True, n_steps: Optional[int] = None,
@@ -627,8 +545,8 @@ class NARBatchSession:
             # Deferred LayerNorms + row-tile lists (every utterance on the absorbed cross-attention path): sequences start on
             # 384-row boundaries and the GEMMs / attention skip the tiles that hold only padding -- a group no longer pays for
             # being padded to its longest member.  M5_NAR_ROWTILES=0: A/B knob (tools/nar_batch_bench.py).
-            want_dln = DeferredLN.eligible(D, dt) and os.environ.get("M5_NAR_DLN", "1") != "0"
-            use_rt = want_dln and os.environ.get("M5_NAR_ROWTILES", "1") != "0"
+            want_dln = DeferredLN.eligible(D, dt) and L.tool_knob("M5_NAR_DLN", "1") != "0"
+            use_rt = want_dln and L.tool_knob("M5_NAR_ROWTILES", "1") != "0"
             self.ws = SeqWorkspace(U * nb, S_max, D, FF, dt, dev, row_pad=RowTiles.ALIGN if use_rt else 64)
             self.Sr = Sr = self.ws.Sr
             self.rt = RowTiles([sub.S for sub in self.subs for _ in range(nb)], Sr, dev) if use_rt else None
@@ -641,7 +559,8 @@ class NARBatchSession:
                 self.row0.append(r)
                 r += nb * sub.s_out
             self.R = r
-            self.hn = torch.empty(Q - 1, self.R, D, dtype=dt, device=dev)
+            self.fold_heads = mdl.head_wf is not None and L.tool_knob("M5_NAR_HEADFOLD", "1") != "0"
+            self.hn = torch.empty(1 if self.fold_heads else Q - 1, self.R, D, dtype=dt, device=dev)
             self.Kp = round_up(K, 4)
             self.logits = torch.empty(self.R, Q - 1, self.Kp, dtype=torch.float32, device=dev)
             self.step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -650,8 +569,9 @@ class NARBatchSession:
             self.dl = DeferredLN(self.ws, dev) if (want_dln and plan_allows_dln(self.plan)) else None
             if self.dl is None:
                 assert self.rt is None, "row-tile lists need the deferred-LayerNorm path"
-        self.side = torch.cuda.Stream(device=dev) if os.environ.get("M5_NAR_SIDE", "0") == "1" else None
-        self._ring = None
+            if self.rt is not None:
+                # the per-run sub-lists now (host -> device copies), not inside the first -- possibly captured -- launch sequence
+                self.rt.prebuild([(seg[1].s0, seg[1].n_seq) if seg[0] == "absorbed" else (seg[1], seg[2] - seg[1]) for seg in self.plan])
         self.graph = None
 
     def enqueue_forward(self, st: int) -> None:
@@ -662,17 +582,15 @@ class NARBatchSession:
             ops.chunked_embed(self.h[u * nb:(u + 1) * nb], mdl.res_tables, sub.x, None, mdl.pos_alpha, mdl.pe, add=t_dec,
                               add_index=self.step_ptr, rows=sub.S, stream=st)
         hx = self.h.view(-1, D)
-        join = _build_cross_operands(self.plan, self.step_ptr, self.stream, self.side, st)
+        _build_cross_operands(self.plan, self.step_ptr, st)
         nl = len(mdl.dec)
         for l, lw in enumerate(mdl.dec):
             if self.dl is not None:
                 decoder_layer_dln(hx, lw, self.ws, self.step_ptr, self.dl, self.plan, l, chain_in=l > 0, chain_out=l + 1 < nl, stream=st,
-                                  key_len=self.key_len, before_cross=join if l == 0 else None, rt=self.rt, mems=[sub.mems[l] for sub in self.subs])
+                                  key_len=self.key_len, rt=self.rt, mems=[sub.mems[l] for sub in self.subs])
                 continue
-            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l,
-                          before_cross=join if l == 0 else None)
-        join()
-        if mdl.head_wf is not None and os.environ.get("M5_NAR_HEADFOLD", "1") != "0":
+            decoder_layer(hx, lw, self.ws, [sub.mems[l] for sub in self.subs], self.step_ptr, st, key_len=self.key_len, plan=self.plan, layer=l)
+        if self.fold_heads:
             for u, sub in enumerate(self.subs):
                 ops.layernorm_twice(hx[u * nb * Sr + sub.row_offset:], mdl.dec_norm[0], mdl.dec_norm[1], LAYERNORM_EPS, 1e-5, self.hn[0, self.row0[u]:],
                                     sub.s_out, n_seq=nb, x_seq_stride=Sr, stream=st)
@@ -695,12 +613,6 @@ class NARBatchSession:
         Q = s.n_codebooks
         shapes = [(1, sub.S, Q, s.n_quant) for sub in self.subs]
         draws = [uniforms[self._order[u]] for u in range(len(self.subs))]         # uniforms are in the caller's order
-        ring, drawn = None, None
-        if _ring_ok(draws):
-            if self._ring is None:
-                self._ring = _UniformRing(self.stream, shapes, self.m.dev)
-            ring = self._ring
-            drawn = ring.draw(draws, t > 0)
         if use_graph and self.graph is None and self.step_i == 0 and len(self.times) > 1:
             self.enqueue_forward(st)                # first step eager, the graph is captured behind it (NARSession.step)
         elif use_graph:
@@ -712,15 +624,9 @@ class NARBatchSession:
         else:
             self.enqueue_forward(st)
         with torch.cuda.stream(self.stream):
-            if ring is not None:
-                ring.ready()
             for u, sub in enumerate(self.subs):
-                if ring is None:
-                    u1 = draws[u](shapes[u])
-                    u2 = draws[u](shapes[u]) if t > 0 else None
-                else:
-                    u1, u2 = drawn[u]
-                u2 = u2 if u2 is not None else u1
+                u1 = draws[u](shapes[u])
+                u2 = draws[u](shapes[u]) if t > 0 else u1
                 lc = self.logits[self.row0[u]:]
                 lu = self.logits[self.row0[u] + sub.s_out:] if self.nb == 2 else None
                 a = L.NarSampleArgs(logits_c=lc.data_ptr(), logits_u=lu.data_ptr() if lu is not None else None,
@@ -731,8 +637,6 @@ class NARBatchSession:
                                     log_eps=log_eps(), div_mode=cfg.div_mode, q0_override_steps=cfg.q0_override_steps)
                 ops.nar_sample(a, stream=st)
             ops.add_int(self.step_ptr, 1, stream=st)
-            if ring is not None:
-                ring.consumed()
         self.step_i += 1
 
     def run(self, uniforms: List[Callable[[tuple], torch.Tensor]], use_graph: bool = True, n_steps: Optional[int] = None,

@@ -6,7 +6,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
-import os
 import threading
 
 import torch
@@ -101,7 +100,7 @@ def gemm_q_cross_attn(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Ten
     """out = cross-attention of the projected queries a @ w^T + bias against short pre-projected memories, one launch.
     mem_table (n_seq, 6) int64 device (include/mars5_hip.h).  False if the shape is not eligible (nothing launched)."""
     assert a.dtype == w.dtype == out.dtype and mem_table.dtype == torch.int64 and mem_table.is_contiguous()
-    if os.environ.get("M5_GEMM_XATTN") != "1":      # tested opt-in: measured slower inside the NAR step (csrc/gemm16.hip)
+    if L.tool_knob("M5_GEMM_XATTN", "0") != "1":    # tools build only (the product library does not export it): measured slower inside the NAR step (csrc/gemm16.hip)
         return False
     st = lib.m5_gemm_q_cross_attn(DT_CODE[a.dtype], _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), a.shape[0], n_heads, w.shape[1],
                                   _p(mem_table), max_le, rows_per_seq, _p(step), scale, _p(out), out.stride(0), _s(stream))
@@ -134,7 +133,7 @@ def gemm_residual_ln(a: torch.Tensor, w: torch.Tensor, x: torch.Tensor, bias: Op
     (nothing was launched; run gemm + layernorm instead).  Consecutive calls on one `scratch` need different launch tags
     (tag, or the device counter `tag_step` under graph replay): see include/mars5_hip.h."""
     assert a.dtype == w.dtype == xn.dtype and x.dtype == torch.float32 and scratch.dtype == torch.uint8
-    if os.environ.get("M5_GEMM_LN") != "1":         # tested opt-in: measured slower than GEMM + LayerNorm launches (csrc/gemm16.hip)
+    if L.tool_knob("M5_GEMM_LN", "0") != "1":       # tools build only (the product library does not export it): measured slower than GEMM + LayerNorm launches (csrc/gemm16.hip)
         return False
     N, K = w.shape
     st = lib.m5_gemm_residual_ln(DT_CODE[a.dtype], _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), x.stride(0), a.shape[0], N, K,

@@ -429,30 +429,6 @@ def test_tts_batch_equals_sequential_seeded_calls(dev, tiny_bundle):
     print("generated frames per request:", [int(a.shape[0]) for a, _ in seq])
 
 
-def test_uniform_ring_on_the_second_stream_changes_nothing(dev, tiny_bundle, monkeypatch):
-    """The step's torch.rand draws run on the session's second stream into a two-pair ring (nar_engine._UniformRing).  The
-    final codes must equal those of the same seeded call with the draws on the main stream (M5_NAR_RNG_SIDE=0), lone and
-    batched, and the device generator must end where the main-stream form leaves it."""
-    from inference import InferenceConfig
-    from mars5_tts_amd import synth
-    m = _tiny_tts(tiny_bundle, dev, torch.bfloat16)
-    texts, trs = ["The quick brown rat.", "Hi there."], ["We meet.", "Demand is high."]
-    refs = [synth.make_ref_codes(n, seed=27 + i) for i, n in enumerate([50, 31])]
-    cfg = InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, freq_penalty=3, rep_penalty_window=100, generate_max_len_override=200)
-    res = {}
-    for side in ("0", "1"):
-        monkeypatch.setenv("M5_NAR_RNG_SIDE", side)
-        torch.manual_seed(77)
-        lone = m.tts_from_codes(texts[0], refs[0], trs[0], cfg)
-        after = torch.rand(4, device=dev)
-        batch = m.tts_batch_from_codes(texts, refs, trs, cfg, seeds=[5, 6], nar_batch=2)
-        res[side] = (lone, after, batch)
-    assert torch.equal(res["0"][0][1].cpu(), res["1"][0][1].cpu()), "lone call: final codes differ"
-    assert torch.equal(res["0"][1].cpu(), res["1"][1].cpu()), "the generator was left somewhere else"
-    for i in range(2):
-        assert torch.equal(res["0"][2][i][1].cpu(), res["1"][2][i][1].cpu()), f"batched request {i}: final codes differ"
-
-
 def test_tts_stream_equals_sequential_seeded_calls(dev, tiny_bundle):
     """``tts_stream_from_codes`` (request i+1's AR decode overlapped with request i's NAR steps on two streams) must
     return, per request, exactly what ``torch.manual_seed(s_i); tts_from_codes(...)`` returns."""

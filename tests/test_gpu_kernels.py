@@ -137,12 +137,22 @@ def test_gemm_skinny_decode_shapes(dev, dt, M):
         assert _rel(outs[0], outs[1]) < tol, f"M={M} N={N} K={K} epi={epi}: skinny vs wide-tile kernel"
 
 
+def _tools_build():
+    from mars5_tts_amd import _lib as L
+    return L.TOOLS
+
+
+TOOLS_ONLY = "an A/B kernel of the tools library (measured slower in the NAR step, not shipped): run with M5_HIP_TOOLS=1"
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gemm_residual_layernorm_fused(dev, dt):
     """m5_gemm_residual_ln: x += A W^T + bias and xn = LayerNorm(x) from ONE launch (row statistics exchanged between
     the workgroups of a row tile) vs fp32 torch; repeated launches reuse the same scratch (launch tags);
     ineligible shapes report unsupported without launching."""
     from mars5_tts_amd import ops
+    if not _tools_build():
+        pytest.skip(TOOLS_ONLY)
     torch.manual_seed(0)
     os.environ["M5_GEMM_LN"] = "1"          # opt-in path (off by default: slower than two launches, see gemm16.hip)
     for (M, N, K) in [(2816, 1024, 1024), (1408, 1024, 3072), (100, 1024, 64), (2816, 256, 128)]:
@@ -289,6 +299,150 @@ def test_deferred_layernorm_chain(dev, dt, M):
         xc2 = (x.cpu() - cen_now[:, None]).view(M, npart, 128)
         assert torch.allclose(part.cpu()[..., 0], xc2.sum(-1), rtol=1e-4, atol=2e-3)
         assert float((xt[:M].float().cpu() - xc2.view(M, D)).abs().max()) <= float(xc2.abs().max()) * (2 ** -8 if dt == torch.bfloat16 else 2 ** -11) * 1.01
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_row_tile_lists_equal_the_dense_launch(dev, dt):
+    """M5RowTiles through the C ABI (m5_gemm_ex / m5_xattn_scores_ex with `rt`, m5_attention with `q_len`): three sequences of
+    90 / 500 / 700 real rows in a 768-row padded layout.  For the residual producer (flat and batched), the QKV and SwiGLU
+    consumers, the per-head-softmax scores and self-attention: every REAL row equals the dense launch bit for bit, rows past
+    every tile height's coverage of a sequence keep the poison they were filled with (unlisted tiles are neither read nor
+    written), and the pad rows INSIDE a consumer's tiles -- whose partials no producer of that tile height wrote (here: poison
+    that would give r = 1 / sqrt(eps)) -- come out as the bias alone (M5RowTiles.seq_len: d = r = 0), finite in f16."""
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.blocks import RowTiles, interleave_rows
+    torch.manual_seed(0)
+    D, K0, H, FF, Lp, Sr = 1024, 256, 16, 512, 48, 768
+    lens = [90, 500, 700]
+    B = len(lens)
+    M = B * Sr
+    npart, eps = D // 128, 4e-5
+    rt = RowTiles(lens, Sr, dev)
+    real = torch.zeros(M, dtype=torch.bool)
+    beyond = torch.zeros(M, dtype=torch.bool)                 # rows past the coverage of the tallest tile (192): in no list
+    for b, n in enumerate(lens):
+        real[b * Sr: b * Sr + n] = True
+        beyond[b * Sr + (n + 191) // 192 * 192: (b + 1) * Sr] = True
+    pad_all = ~real & ~beyond                                 # pad rows some tile height covers
+    pad96 = torch.zeros(M, dtype=torch.bool)                  # pad rows EVERY tile height covers
+    for b, n in enumerate(lens):
+        pad96[b * Sr + n: b * Sr + (n + 95) // 96 * 96] = True
+    POISON = 7.0
+
+    a0 = _q(_rand((M, K0), 1), dt).to(dev, dt)
+    w0 = _q(_rand((D, K0), 2, 2.0 / math.sqrt(K0)), dt).to(dev, dt)
+    b0 = _rand((D,), 3).to(dev)
+    x0 = (_rand((M, D), 4, 2.0) + 6.0 * _rand((M, 1), 5)).to(dev)
+    cen0 = (x0.mean(dim=1) + 0.3 * _rand((M,), 6).to(dev)).contiguous()
+
+    def producer(rtc, batched):
+        x = x0.clone()
+        xt = torch.full((M, D), POISON, device=dev, dtype=dt)
+        part = torch.full((M, npart, 2), -3.0, device=dev)   # poison: sum = -3, sumsq = -3 -> var clamps to 0 -> r = 1 / sqrt(eps) without seq_len
+        cen_b = torch.full((M,), POISON, device=dev)
+        dlp = L.DeferredLN(mode=1, np=npart, xt=xt.data_ptr(), ld_xt=D, part=part.data_ptr(), cen_in=cen0.data_ptr(), cen_out=cen_b.data_ptr(), delta=None,
+                           s=None, s_bs=0, eps=0.0, n_feat=D, rows_bs=Sr if batched else M)
+        if batched:
+            ops.gemm_dln(a0, w0, x, L.EPI_RESIDUAL, dlp, bias=b0, M=Sr, batch=B, sA=Sr * K0, sW=0, sC=Sr * D, sBias=0, rt=rtc)
+        else:
+            ops.gemm_dln(a0, w0, x, L.EPI_RESIDUAL, dlp, bias=b0, rt=rtc)
+        torch.cuda.synchronize()
+        return x, xt, part, cen_b
+
+    dense = producer(None, False)
+    for batched in (False, True):
+        got = producer(rt.c, batched)
+        for name, d_, g_ in zip(("x", "centred copy", "partials", "centres"), dense, got):
+            assert torch.equal(g_.cpu()[real], d_.cpu()[real]), f"producer (batched={batched}): {name} of real rows differs from the dense launch"
+        assert torch.equal(got[0].cpu()[beyond], x0.cpu()[beyond]), "residual stream of unlisted rows was written"
+        assert bool((got[1].float().cpu()[beyond] == POISON).all()) and bool((got[2].cpu()[beyond] == -3.0).all()) and bool((got[3].cpu()[beyond] == POISON).all())
+    x, xt, part, _ = producer(rt.c, False)                     # the state the consumers see: pad rows past the producer's tiles hold poison
+    g, be = 1.0 + 0.3 * _rand((D,), 7), 0.2 * _rand((D,), 8)
+
+    def fold(W, b):
+        Wf = (W * g[None, :]).to(dt)
+        return Wf.to(dev).contiguous(), (W @ be + (b if b is not None else 0.0)).to(dev).contiguous(), Wf.float().sum(1).to(dev).contiguous()
+
+    def consumer(s_vec, rows_bs=M, s_bs=0):
+        return L.DeferredLN(mode=2, np=npart, xt=None, ld_xt=0, part=part.data_ptr(), cen_in=None, cen_out=None, delta=None,
+                            s=s_vec.data_ptr(), s_bs=s_bs, eps=eps, n_feat=D, rows_bs=rows_bs)
+
+    # -- QKV scatter consumer
+    wqf, bqf, sq = fold(_rand((3 * D, D), 9, 1.5 / math.sqrt(D)), _rand((3 * D,), 10))
+
+    def qkv(rtc):
+        q = torch.full((B, H, Sr, 64), POISON, device=dev, dtype=dt)
+        k = torch.full((B, H, Sr, 64), POISON, device=dev, dtype=dt)
+        vt = torch.full((B, H, 64, Sr), POISON, device=dev, dtype=dt)
+        sc = L.QkvScatter(q=q.data_ptr(), k=k.data_ptr(), vt=vt.data_ptr(), rows_per_batch=Sr, n_heads=H, head_dim=64, q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64,
+                          k_bs=H * Sr * 64, k_hs=Sr * 64, k_rs=64, vt_bs=H * 64 * Sr, vt_hs=64 * Sr, vt_ds=Sr)
+        ops.gemm_dln(xt, wqf, None, L.EPI_QKV, consumer(sq), bias=bqf, scatter=sc, rt=rtc)
+        torch.cuda.synchronize()
+        # rows as the leading axis: (M, H, 64) each
+        return (q.permute(0, 2, 1, 3).reshape(M, H, 64).float().cpu(), k.permute(0, 2, 1, 3).reshape(M, H, 64).float().cpu(),
+                vt.permute(0, 3, 1, 2).reshape(M, H, 64).float().cpu()), (q, k, vt)
+
+    (qd, kd, vd), _ = qkv(None)
+    (qr, kr, vr), (q_dev, k_dev, vt_dev) = qkv(rt.c)
+    bias_rows = [bqf.cpu()[i * D:(i + 1) * D].to(dt).float().view(H, 64) for i in range(3)]
+    for name, d_, r_, brow in zip("qkv", (qd, kd, vd), (qr, kr, vr), bias_rows):
+        assert torch.equal(r_[real], d_[real]), f"QKV consumer: {name} of real rows differs from the dense launch"
+        assert bool((r_[beyond] == POISON).all()), f"QKV consumer wrote {name} rows of unlisted tiles"
+        assert bool(torch.isfinite(r_).all())
+        pr = r_[pad_all]
+        is_bias = (pr == brow[None]).flatten(1).all(1)
+        is_poison = (pr == POISON).flatten(1).all(1)
+        assert bool((is_bias | is_poison).all()), f"QKV consumer: a pad row of {name} is neither untouched nor the bias alone (stale partials leaked: r != 0)"
+        assert bool((r_[pad96] == brow[None]).all()), f"QKV consumer: pad rows inside every tile height's coverage must be the bias alone ({name})"
+    # ... whereas the dense launch (no list, no lengths) amplifies the rows whose partials nobody wrote -- rows 128..191 of the
+    # 90-row sequence: past the producer's 96- or 128-row tile, inside a 192-row consumer tile -- by 1 / sqrt(eps): the case ADVICE r4 #1 named
+    assert float(qd[128:192].abs().max()) > 10 * float(bias_rows[0].abs().max())
+
+    # -- SwiGLU consumer
+    wsf, bsf, ss = fold(interleave_rows(_rand((FF, D), 11, 1.5 / math.sqrt(D)), _rand((FF, D), 12, 1.5 / math.sqrt(D))), None)
+
+    def swiglu(rtc):
+        hff = torch.full((M, FF), POISON, device=dev, dtype=dt)
+        ops.gemm_dln(xt, wsf, hff, L.EPI_SWIGLU, consumer(ss), bias=bsf, rt=rtc)
+        torch.cuda.synchronize()
+        return hff.float().cpu()
+    hd, hr = swiglu(None), swiglu(rt.c)
+    assert torch.equal(hr[real], hd[real]) and bool((hr[beyond] == POISON).all()) and bool(torch.isfinite(hr).all())
+    assert float(hr[pad_all].abs().max()) <= max(POISON, 1.0)     # silu(b') b' with b' = W beta: small; or untouched poison
+
+    # -- scores with per-head softmax (batched: per-sequence operand tables)
+    N = H * Lp
+    A = _rand((B, N, D), 13, 2.0 / math.sqrt(D))
+    c = _rand((B, N), 14)
+    c.view(B, H, Lp)[:, :, 40:] = -1e30
+    Af = (A * g[None, None, :]).to(dt).to(dev).contiguous()
+    cf = (torch.einsum("bnk,k->bn", A, be) + c).to(dev).contiguous()
+    sA = Af.float().sum(-1).contiguous()
+
+    def scores(rtc):
+        P = torch.full((M, N), POISON, device=dev, dtype=dt)
+        ops.xattn_scores_dln(xt, Sr * D, Af, cf, P, Sr * N, Sr, H, Lp, B, consumer(sA, rows_bs=Sr, s_bs=N), rt=rtc)
+        torch.cuda.synchronize()
+        return P.float().cpu()
+    pd_, pr_ = scores(None), scores(rt.c)
+    assert torch.equal(pr_[real], pd_[real]) and bool((pr_[beyond] == POISON).all()) and bool(torch.isfinite(pr_).all())
+
+    # -- self-attention with q_len: query blocks past a sequence's own length are not computed
+    kl = torch.tensor(lens, dtype=torch.int32, device=dev)
+
+    def attn(with_q_len):
+        o = torch.full((M, D), POISON, device=dev, dtype=dt)
+        a = L.AttnArgs(q=q_dev.data_ptr(), q_bs=H * Sr * 64, q_hs=Sr * 64, q_rs=64, k=k_dev.data_ptr(), k_bs=H * Sr * 64, k_hs=Sr * 64, k_rs=64,
+                       vt=vt_dev.data_ptr(), vt_bs=H * 64 * Sr, vt_hs=64 * Sr, vt_ds=Sr, o=o.data_ptr(), o_bs=Sr * D, o_rs=D, B=B, H=H, Sq=Sr, Sk=Sr,
+                       key_len=kl.data_ptr(), causal=0, scale=64 ** -0.5, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0,
+                       q_len=kl.data_ptr() if with_q_len else None)
+        ops.attention(dt, a)
+        torch.cuda.synchronize()
+        return o.float().cpu()
+    od, orr = attn(False), attn(True)
+    assert torch.equal(orr[real], od[real]), "attention with q_len: real query rows differ"
+    assert bool((orr[beyond] == POISON).all()) and not bool((od[beyond] == POISON).any())
+    assert bool(torch.isfinite(orr[real]).all())
 
 
 @pytest.mark.parametrize("dt", DTS)
@@ -446,6 +600,8 @@ def test_gemm_q_cross_attention_fused(dev, dt):
     to memories of different lengths (39, 64, 17 keys) inside the block selected by a device step index."""
     from mars5_tts_amd import ops
     from mars5_tts_amd.blocks import CrossMemory, cross_memory_table
+    if not _tools_build():
+        pytest.skip(TOOLS_ONLY)
     os.environ["M5_GEMM_XATTN"] = "1"       # opt-in path (off by default: no gain inside the NAR step, see gemm16.hip)
     H, Kd, Sr, T, step_i = 16, 1024, 112, 3, 1
     D = H * 64

@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: schedule constants taken from the caller's diffusion object, the cross-attention
 path plan of a batch, request wire format, reference-handle LRU bookkeeping."""
+import os
 import math
 
 import numpy as np
@@ -248,3 +249,50 @@ def test_deferred_layernorm_fold_is_the_same_linear_map():
     assert p2a.delta == dl.delta.data_ptr() + 8 * 4 and p2a.xt == ws.xn.data_ptr() + 8 * D * 2 and p2a.part == dl.part.data_ptr() + 8 * (D // 128) * 8
     p3 = dl.producer(ws)
     assert (p3.cen_in, p3.cen_out) == (dl.cen[0].data_ptr(), dl.cen[1].data_ptr())
+
+
+def test_product_reads_no_environment_variable_but_its_two(monkeypatch):
+    """The product (package + inference.py + hubconf.py) may read MARS5_DTYPE (the engines' default operand type, model.py)
+    and M5_HIP_TOOLS / M5_HIP_TOOLS_LIB (which library _lib.py loads) and nothing else: every A/B knob of the host engines goes
+    through ``_lib.tool_knob``, which answers with the default unless the tools library is loaded.  (The library itself:
+    tests/test_abi_cpu.py checks that libmars5_hip.so does not even import getenv.)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "mars5-tts_amd", f) for f in sorted(os.listdir(os.path.join(root, "mars5-tts_amd"))) if f.endswith(".py")]
+    files += [os.path.join(root, "inference.py"), os.path.join(root, "hubconf.py"), os.path.join(root, "mars5_tts_amd.py")]
+    allowed = {"MARS5_DTYPE", "M5_HIP_TOOLS", "M5_HIP_TOOLS_LIB"}
+    reads = []
+    for f in files:
+        src = open(f).read()
+        for m in re.finditer(r"(os\.environ|os\.getenv|getenv\()", src):
+            line = src[src.rfind("\n", 0, m.start()) + 1: src.find("\n", m.end())]
+            names = set(re.findall(r"[\"']([A-Z][A-Z0-9_]+)[\"']", line))
+            if os.path.basename(f) == "_lib.py" and "os.environ.get(name, default) if TOOLS else default" in line:
+                continue                                                     # tool_knob itself: gated on the tools library
+            reads.append((os.path.basename(f), line.strip(), names))
+    assert reads, "the scan found nothing: pattern broken?"
+    for f, line, names in reads:
+        assert names and names <= allowed, f"{f}: `{line}` reads the environment outside the allowed set {sorted(allowed)}"
+    from mars5_tts_amd import _lib as L
+    assert not L.TOOLS, "the CPU suite runs on the product library"
+    monkeypatch.setenv("M5_NAR_DLN", "0")
+    monkeypatch.setenv("M5_AR_MEGA", "0")
+    assert L.tool_knob("M5_NAR_DLN", "1") == "1" and L.tool_knob("M5_AR_MEGA", "1") == "1"
+
+
+def test_row_tile_lists_carry_the_sequence_lengths():
+    """M5RowTiles.seq_len: the lists of the three tile heights cover different pad rows (ceil(len / BM) * BM), so the kernels are
+    told each sequence's own length (deferred-LayerNorm consumers give pad rows d = r = 0); sub-lists of a run of sequences are
+    made ahead of the launch sequence (``prebuild``), not inside it."""
+    from mars5_tts_amd.blocks import RowTiles, _rt_sub
+    lens = [90, 90, 100, 100, 700, 700]
+    rt = RowTiles(lens, 768, torch.device("cpu"))
+    assert rt.len_dev.tolist() == lens and rt.c.seq_len == rt.len_dev.data_ptr() and rt.c.rows_per_seq == 768
+    cover = [[-(-n // bm) * bm for n in lens] for bm in (96, 128, 192)]
+    assert cover[0][0] == 96 and cover[1][0] == 128 and cover[2][0] == 192          # the case the advisor named: rows 96..191 of a 90-row sequence
+    assert rt.n == [sum(c // bm for c in cv) for cv, bm in zip(cover, (96, 128, 192))]
+    rt.prebuild([(2, 2), (4, 2)])
+    assert set(rt._subs) == {(2, 2), (4, 2)}
+    sub = rt._subs[(4, 2)]
+    assert sub.len_dev.tolist() == [700, 700] and _rt_sub(rt, 4, 2) is sub.c and _rt_sub(rt, 0, 6) is rt.c
+    assert sub.maps[1].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]            # 6 tiles of 128 per sequence, numbered from the run's first row
