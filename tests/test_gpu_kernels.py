@@ -326,7 +326,7 @@ def test_row_tile_lists_equal_the_dense_launch(dev, dt):
     pad_all = ~real & ~beyond                                 # pad rows some tile height covers
     pad96 = torch.zeros(M, dtype=torch.bool)                  # pad rows EVERY tile height covers
     for b, n in enumerate(lens):
-        pad96[b * Sr + n: b * Sr + (n + 95) // 96 * 96] = True
+        pad96[b * Sr + n: b * Sr + min((n + h - 1) // h * h for h in (96, 128, 192))] = True
     POISON = 7.0
 
     a0 = _q(_rand((M, K0), 1), dt).to(dev, dt)
