@@ -348,6 +348,26 @@ typedef struct {
 } M5NarSampleArgs;
 M5_API int m5_nar_sample(const M5NarSampleArgs* a, void* stream);
 
+/* The reverse step's uniforms, bit-identical to what `torch.rand((1, S, n_q, K), device=..., generator=g)` draws on this device
+ * (reference diffuser.py:219-228, 380-390 draws them with torch.rand_like, twice per step, once at t = 0), generated inside this
+ * library so that the whole reverse step can be one captured hipGraph and the loop holds no ATen launch.  torch's Philox4x32-10
+ * geometry: grid_threads = 256 * min(CUs * (maxThreadsPerMultiProcessor / 256), ceil(n / 256)); a draw of n values advances the
+ * generator offset by inc = ceil(n / (4 * grid_threads)) * 4.  rng (DEVICE memory, so that a captured graph serves every run) =
+ * {seed, offset0}: reverse step i = *step draws at offset0 + 2 i inc and, unless consts[i][6] (= t) is 0, at offset0 + (2 i + 1) inc
+ * (offset0 = the generator's offset when step 0 of the session ran; a multiple of 4 like every torch offset).
+ * out[e] = m[e / K] ? second draw : first draw -- m5_nar_sample reads the first draw on the rows it samples from the model and the
+ * second on the known rows, so one merged buffer serves as its u1 AND u2.  m = NULL: out = the first draw alone (= torch.rand).
+ * k_magic / k_shift: e / K = (e * k_magic) >> (32 + k_shift) for every e < n (0 = divide); the host computes and the call checks it. */
+typedef struct {
+    float* out; int64_t n;                          /* n = S * n_q * K < 2^32                  */
+    int32_t K; uint32_t k_magic, k_shift;
+    const uint8_t* m;                               /* [S * n_q] or NULL                       */
+    const uint64_t* rng;                            /* device: {seed, offset0}                 */
+    uint32_t inc, grid_threads;
+    const int32_t* step; const float* consts;       /* as in M5NarSampleArgs (may be NULL with m = NULL) */
+} M5NarUniformArgs;
+M5_API int m5_nar_uniforms(const M5NarUniformArgs* a, void* stream);
+
 /* AR -> NAR hand-off on device (reference inference.py:272-275 with speechtok.decode_int, minbpe/codebook.py:88-126):
  * tokens[i] (global AR ids, i < n) -> speech-vocabulary id max(tokens[i] - n_text, 0) -> the run of codebook-0 codes that
  * BPE token was merged from: vals[off[id] .. off[id + 1]) (CSR over n_vocab ids; special tokens have empty runs),

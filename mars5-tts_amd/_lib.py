@@ -127,6 +127,12 @@ class NarSampleArgs(C.Structure):
                 ("div_mode", i32), ("q0_override_steps", i32)]
 
 
+class NarUniformArgs(C.Structure):
+    """M5NarUniformArgs (include/mars5_hip.h): the step's uniforms as torch.rand draws them, generated in the library."""
+    _fields_ = [("out", vp), ("n", i64), ("K", i32), ("k_magic", C.c_uint32), ("k_shift", C.c_uint32), ("m", vp),
+                ("rng", vp), ("inc", C.c_uint32), ("grid_threads", C.c_uint32), ("step", vp), ("consts", vp)]
+
+
 class RowTiles(C.Structure):
     """M5RowTiles (include/mars5_hip.h): the row tiles of a padded batch layout that hold real rows, per tile height 96 / 128 / 192."""
     _fields_ = [("map", vp * 3), ("n", i32 * 3), ("rows_per_seq", i32), ("seq_len", vp)]
@@ -167,6 +173,7 @@ PROTOTYPES = {
                                         C.c_int, vp, vp]),
     "m5_ar_attn_combine_batch": (C.c_int, [C.c_int, vp, i64, C.c_int, C.c_int, C.c_int, vp, i32, vp, i64, vp]),
     "m5_nar_sample": (C.c_int, [C.POINTER(NarSampleArgs), vp]),
+    "m5_nar_uniforms": (C.c_int, [C.POINTER(NarUniformArgs), vp]),
     "m5_expand_tokens": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
     "m5_trim_bounds": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32, vp, C.c_int, vp, vp]),
     "m5_add_int": (C.c_int, [vp, i32, vp]),

@@ -137,7 +137,89 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
     if (lane == 0) a.x[row] = result;
 }
 
+// ---- The step's uniforms, generated in this library exactly as `torch.rand` generates them on this device (reference
+// diffuser.py:219-228, 380-390: `torch.rand_like(logits)` once for log_sample_categorical of the model branch, once for q_sample
+// of the known branch), so the two ATen `uniform_` launches, their 2 x 4 n bytes and the eager launch gaps around them leave
+// the loop and the WHOLE reverse step (forward + uniforms + posterior / sample + step counter) is one captured hipGraph.
+// torch (ATen/native/cuda/DistributionTemplates.h, distribution_nullary_kernel; rocrand's Philox4x32-10 behind hiprand):
+//   G = 256 * min(CUs * (maxThreadsPerMultiProcessor / 256), ceil(n / 256)) threads, thread idx starts Philox(seed,
+//   subsequence idx, offset) and per loop iteration `it` takes ONE 4-output call for elements
+//   e = it * 4 G + ii * G + idx, ii = 0..3: counter = {offset / 4 + it (64 bit), idx (64 bit)}, key = seed;
+//   u = 2^-32 + float(x) * 2^-32 (rocrand uniform_distribution: (0, 1]), then 1.0 -> 0.0 (uniform_kernel's bound reversal).
+// A draw advances the generator by inc = (ceil-div(n, 4 G)) * 4.  Reverse step i makes draw 1 at offset0 + 2 i inc and --
+// unless t = 0 -- draw 2 at offset0 + (2 i + 1) inc (only the LAST step has t = 0); {seed, offset0} live in DEVICE memory
+// (rng[0..1]), so a captured step graph serves any generator state the host binds a run to.
+// The posterior / sample kernel reads draw 1 on the rows it samples from the model (m = 0) and draw 2 on the known rows, so
+// ONE merged buffer is written: out[e] = m[row(e)] ? u2[e] : u1[e]  (m = NULL: draw 1 everywhere = torch.rand itself).
+__device__ inline uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long m0 = (unsigned long long)0xD2511F53u * c.x, m1 = (unsigned long long)0xCD9E8D57u * c.z;
+        c = make_uint4((unsigned)(m1 >> 32) ^ c.y ^ k.x, (unsigned)m1, (unsigned)(m0 >> 32) ^ c.w ^ k.y, (unsigned)m0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ inline float torch_uniform(unsigned v) {
+    const float u = 2.3283064e-10f + ((float)v * 2.3283064e-10f);      // rocrand_device::detail::uniform_distribution
+    return u == 1.0f ? 0.0f : u;                                       // at::native uniform_kernel: (0, 1] -> [0, 1)
+}
+
+__global__ __launch_bounds__(256) void nar_uniform_kernel(M5NarUniformArgs a) {
+    const unsigned G = a.grid_threads;
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
+    const unsigned it = (unsigned)(t / G), idx = (unsigned)(t - (unsigned long long)it * G);
+    const long long e0 = (long long)it * 4 * G + idx;
+    if (e0 >= a.n) return;
+    const int step = a.step ? a.step[0] : 0;
+    const bool second = a.m && !(a.consts && (int)a.consts[(long long)step * M5_NAR_CONSTS + 6] == 0);      // t = 0: one draw only
+    const unsigned long long seed = a.rng[0], off1 = a.rng[1] + (unsigned long long)step * 2ull * a.inc;
+    const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
+    const unsigned long long c1 = off1 / 4 + it;
+    const uint4 r1 = philox4x32_10(make_uint4((unsigned)c1, (unsigned)(c1 >> 32), idx, 0u), key);
+    uint4 r2 = r1;
+    if (second) {
+        const unsigned long long c2 = (off1 + a.inc) / 4 + it;
+        r2 = philox4x32_10(make_uint4((unsigned)c2, (unsigned)(c2 >> 32), idx, 0u), key);
+    }
+    const unsigned v1[4] = {r1.x, r1.y, r1.z, r1.w}, v2[4] = {r2.x, r2.y, r2.z, r2.w};
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const long long e = e0 + (long long)ii * G;
+        if (e < a.n) {
+            bool known = false;
+            if (second) {
+                // row = e / K by the host's multiply-shift (exact for e < 2^32, checked there), or a plain division
+                const unsigned row = a.k_magic ? (unsigned)(((unsigned long long)(unsigned)e * a.k_magic) >> (32 + a.k_shift)) : (unsigned)(e / a.K);
+                known = a.m[row] != 0;
+            }
+            a.out[e] = torch_uniform(known ? v2[ii] : v1[ii]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int m5_nar_uniforms(const M5NarUniformArgs* a, void* stream) {
+    if (!a || !a->out || !a->rng || a->n <= 0 || a->n >= (1ll << 32) || a->grid_threads == 0 || (a->grid_threads % 256) || (a->inc % 4)) return M5_ERR_ARG;
+    if (a->m && (a->K <= 0 || !a->consts || !a->step)) return M5_ERR_ARG;
+    if (a->m && a->k_magic) {                     // the multiply-shift must divide exactly over the whole range: checked at the row boundaries
+        const long long rows = (a->n + a->K - 1) / a->K;
+        for (long long r = 1; r <= rows; r += (rows > 64 ? rows / 64 : 1)) {
+            const unsigned long long lo = (unsigned long long)r * a->K - 1, hi = (unsigned long long)r * a->K;
+            if (lo < (1ull << 32) && (unsigned)((lo * a->k_magic) >> (32 + a->k_shift)) != (unsigned)(r - 1)) return M5_ERR_ARG;
+            if (hi < (1ull << 32) && hi < (unsigned long long)a->n && (unsigned)((hi * a->k_magic) >> (32 + a->k_shift)) != (unsigned)r) return M5_ERR_ARG;
+        }
+    }
+    const long long G = a->grid_threads;
+    const long long iters = (a->n + 4 * G - 1) / (4 * G);
+    const long long blocks = iters * (G / 256);
+    if (blocks > 0x7fffffffll) return M5_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(nar_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    M5_CHECK_LAUNCH();
+    return M5_OK;
+}
 
 extern "C" int m5_nar_sample(const M5NarSampleArgs* a, void* stream) {
     if (!a || !a->logits_c || !a->x || !a->x_known || !a->m || !a->u1 || !a->u2 || !a->consts || !a->step) return M5_ERR_ARG;

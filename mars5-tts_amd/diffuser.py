@@ -182,6 +182,9 @@ def _generator_uniform(dev, generator: Optional[torch.Generator]):
         assert tuple(out.shape) == tuple(shape) and out.dtype == torch.float32
         return out.uniform_(0.0, 1.0, generator=generator)
     uniform.out_ok = True
+    # the engine may generate these draws inside its own step graph (nar_engine.PhiloxDraws: same values, same generator advance)
+    uniform.gen = generator if generator is not None else torch.cuda.default_generators[
+        torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()]
     return uniform
 
 

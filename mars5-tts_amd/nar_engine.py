@@ -144,6 +144,63 @@ def _build_cross_operands(plan, step_ptr: torch.Tensor, st: int) -> None:
             seg[1].build(step_ptr, st)
 
 
+_INC_CACHE: Dict[tuple, int] = {}          # (device index, n) -> generator offset one torch.rand of n floats consumes
+
+
+def _magic_div(d: int) -> tuple:
+    """(m, s) with e // d == (e * m) >> (32 + s) for every 0 <= e < 2^32 when m fits 32 bits, else (0, 0) (the kernel divides)."""
+    s = max(d.bit_length() - 1, 0)
+    m = (1 << (32 + s)) // d + 1
+    return (m, s) if m < (1 << 32) else (0, 0)
+
+
+class PhiloxDraws:
+    """The reverse steps' uniforms generated INSIDE the step graph (csrc/nar_sample.hip, m5_nar_uniforms) instead of by two
+    ``torch.rand`` launches per step: bit-identical values (torch's Philox4x32-10 launch geometry on this device) and the same
+    advance of the caller's generator, which is moved past ALL the run's draws when the run is enqueued (so a pipelined caller
+    that draws from the same generator afterwards sees the reference's stream).  One merged buffer: first draw on the rows
+    sampled from the model, second draw on the known rows -- what m5_nar_sample reads."""
+
+    def __init__(self, gen: torch.Generator, S: int, n_q: int, K: int, m_mask: torch.Tensor, consts: torch.Tensor, step_ptr: torch.Tensor,
+                 times: List[int], dev):
+        assert all(t > 0 for t in times[:-1]), "only the last reverse step may have t = 0 (one draw)"
+        self.gen, self.n = gen, S * n_q * K
+        prop = torch.cuda.get_device_properties(dev)
+        per_mp = max(int(getattr(prop, "max_threads_per_multi_processor", 2048)) // 256, 1)
+        self.grid_threads = 256 * min(int(prop.multi_processor_count) * per_mp, (self.n + 255) // 256)
+        self.inc = ((self.n - 1) // (4 * self.grid_threads) + 1) * 4
+        key = (torch.device(dev).index, self.n)
+        if key not in _INC_CACHE:
+            # once per shape and process: let torch itself say what one such draw consumes (guards the formula above against
+            # another torch build's launch geometry; tests/test_gpu_kernels.py compares the values themselves)
+            off = gen.get_offset()
+            torch.empty(self.n, dtype=torch.float32, device=dev).uniform_(0.0, 1.0, generator=gen)
+            _INC_CACHE[key] = int(gen.get_offset() - off)
+            gen.set_offset(off)
+        if _INC_CACHE[key] != self.inc:
+            raise RuntimeError(f"torch.rand of {self.n} floats advances the generator by {_INC_CACHE[key]}, not {self.inc}: "
+                               "this torch build uses another Philox launch geometry than m5_nar_uniforms reproduces")
+        self.buf = torch.empty(S, n_q, K, dtype=torch.float32, device=dev)
+        self.rng = torch.zeros(2, dtype=torch.int64, device=dev)             # {seed, offset0}: read by the kernel, so the step graph outlives a run
+        km, ks = _magic_div(K)
+        self.m_mask, self.consts, self.step_ptr = m_mask, consts, step_ptr
+        self.args = L.NarUniformArgs(out=self.buf.data_ptr(), n=self.n, K=K, k_magic=km, k_shift=ks, m=m_mask.data_ptr(), rng=self.rng.data_ptr(),
+                                     inc=self.inc, grid_threads=self.grid_threads, step=step_ptr.data_ptr(), consts=consts.data_ptr())
+
+    def reserve(self, times: List[int], first_step: int, stream: torch.cuda.Stream) -> None:
+        """Bind the steps first_step .. of the session (`times`: their t) to the generator's present state and move the generator
+        past their draws (two per step, one at t = 0).  Stream-ordered: the state words reach the device behind whatever the
+        stream already holds (an earlier run's steps)."""
+        wrap = lambda v: v - (1 << 64) if v >= (1 << 63) else v                 # noqa: E731  (uint64 bit pattern in an int64 tensor)
+        seed, off = int(self.gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF, int(self.gen.get_offset())
+        with torch.cuda.stream(stream):
+            self.rng.copy_(torch.tensor([wrap(seed), wrap((off - 2 * first_step * self.inc) & 0xFFFFFFFFFFFFFFFF)], dtype=torch.int64), non_blocking=True)
+        self.gen.set_offset(off + sum(2 if t > 0 else 1 for t in times) * self.inc)
+
+    def enqueue(self, st: int) -> None:
+        ops.nar_uniforms(self.args, stream=st)
+
+
 class NARSession:
     """One utterance.  ``prepare`` = everything x_t-independent; ``step`` = one reverse step."""
 
@@ -152,6 +209,8 @@ class NARSession:
         self.m, self.cfg = model, cfg
         self.stream = stream if stream is not None else ops.session_stream(model.dev, "nar")
         self.graph: Optional[ops.Graph] = None
+        self.graph_step: Optional[ops.Graph] = None
+        self._ph: Optional[PhiloxDraws] = None
         self.diff_tables = diff_tables
 
     def _enter(self) -> None:
@@ -309,6 +368,7 @@ class NARSession:
             self.fold_heads = mdl.head_wf is not None and self.ws_l is None and L.tool_knob("M5_NAR_HEADFOLD", "1") != "0"
             self.hn = torch.empty(1 if self.fold_heads else Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
         self.graph = None
+        self.graph_step, self._ph = None, None      # whole-step graph and in-graph uniform generator (made at the first run that can use them)
 
     # ----------------------------------------------------------------------------- step
     def _last_layer_compact(self, lw, mem, normed: bool, st: int) -> None:
@@ -437,6 +497,39 @@ class NARSession:
         ops.nar_sample(a, stream=st)
         ops.add_int(self.step_ptr, 1, stream=st)
 
+    def _philox(self, uniform) -> Optional[PhiloxDraws]:
+        """The in-graph generator for this session's draws, if `uniform` is the generator-backed draw of diffuser.py (it carries
+        its generator) and the schedule has its only t = 0 step last; else None (explicit uniforms: parity tests)."""
+        gen = getattr(uniform, "gen", None)
+        if gen is None or not all(t > 0 for t in self.times[:-1]):
+            return None
+        ph = self._ph
+        if ph is None or ph.gen is not gen:
+            s = self.m.shape
+            with torch.cuda.stream(self.stream):
+                ph = self._ph = PhiloxDraws(gen, self.S, s.n_codebooks, s.n_quant, self.m_mask, self.consts, self.step_ptr, self.times, self.m.dev)
+            self.graph_step = None
+        return ph
+
+    def _step_philox(self, ph: PhiloxDraws, use_graph: bool) -> None:
+        """One reverse step as ONE launch sequence -- forward, the step's uniforms (generated here, bit-identical to torch.rand's),
+        posterior / sample, step counter -- replayed as one hipGraph from the second step on."""
+        st = self.stream.cuda_stream
+
+        def body():
+            self.enqueue_forward(st)
+            ph.enqueue(st)
+            self.enqueue_sample(ph.buf, ph.buf, st)
+        if not use_graph or (self.graph_step is None and self.step_i == 0 and len(self.times) > 1):
+            body()                                  # first step launch by launch: the capture below runs while the GPU works on it
+        else:
+            if self.graph_step is None:
+                ops.Graph.begin(st)
+                body()
+                self.graph_step = ops.Graph().end(st)
+            self.graph_step.launch(st)
+        self.step_i += 1
+
     def step(self, uniform: Callable[[tuple], torch.Tensor], use_graph: bool = True) -> None:
         """One reverse step t = times[step_i]: forward (graph), uniform draws, sample."""
         st = self.stream.cuda_stream
@@ -469,7 +562,13 @@ class NARSession:
         st = self.stream.cuda_stream
         ev0, ev1 = ops.Event(), ops.Event()
         ev0.record(st)
+        ph = self._philox(uniform) if on_step is None else None
+        if ph is not None:
+            ph.reserve(self.times[self.step_i: self.step_i + n], self.step_i, self.stream)
         for i in range(n):
+            if ph is not None:
+                self._step_philox(ph, use_graph)
+                continue
             if on_step is None:
                 self.step(uniform, use_graph)
                 continue
@@ -515,6 +614,8 @@ class NARBatchSession:
         self.m, self.cfg = model, cfg
         self.stream = stream if stream is not None else ops.session_stream(model.dev, "nar")
         self.graph: Optional[ops.Graph] = None
+        self.graph_step: Optional[ops.Graph] = None
+        self._phs: Optional[List[PhiloxDraws]] = None
         self.subs: List[NARSession] = []
         self.diff_tables = diff_tables
 
@@ -573,6 +674,7 @@ class NARBatchSession:
                 # the per-run sub-lists now (host -> device copies), not inside the first -- possibly captured -- launch sequence
                 self.rt.prebuild([(seg[1].s0, seg[1].n_seq) if seg[0] == "absorbed" else (seg[1], seg[2] - seg[1]) for seg in self.plan])
         self.graph = None
+        self.graph_step, self._phs = None, None
 
     def enqueue_forward(self, st: int) -> None:
         mdl, s = self.m, self.m.shape
@@ -627,16 +729,56 @@ class NARBatchSession:
             for u, sub in enumerate(self.subs):
                 u1 = draws[u](shapes[u])
                 u2 = draws[u](shapes[u]) if t > 0 else u1
-                lc = self.logits[self.row0[u]:]
-                lu = self.logits[self.row0[u] + sub.s_out:] if self.nb == 2 else None
-                a = L.NarSampleArgs(logits_c=lc.data_ptr(), logits_u=lu.data_ptr() if lu is not None else None,
-                                    ld_row=(Q - 1) * self.Kp, ld_q=self.Kp, S=sub.S, n_q=Q, K=s.n_quant, row_offset=sub.row_offset,
-                                    x=sub.x.data_ptr(), x_known=sub.x_known.data_ptr(), m=sub.m_mask.data_ptr(),
-                                    u1=u1.data_ptr(), u2=u2.data_ptr(), consts=sub.consts.data_ptr(),
-                                    step=self.step_ptr.data_ptr(), guidance_w=cfg.guidance_w, temperature=cfg.x_0_temp,
-                                    log_eps=log_eps(), div_mode=cfg.div_mode, q0_override_steps=cfg.q0_override_steps)
-                ops.nar_sample(a, stream=st)
+                ops.nar_sample(self._sample_args(u, sub, u1, u2), stream=st)
             ops.add_int(self.step_ptr, 1, stream=st)
+        self.step_i += 1
+
+    def _sample_args(self, u: int, sub: NARSession, u1: torch.Tensor, u2: torch.Tensor) -> L.NarSampleArgs:
+        s, cfg = self.m.shape, self.cfg
+        Q = s.n_codebooks
+        lc = self.logits[self.row0[u]:]
+        lu = self.logits[self.row0[u] + sub.s_out:] if self.nb == 2 else None
+        return L.NarSampleArgs(logits_c=lc.data_ptr(), logits_u=lu.data_ptr() if lu is not None else None,
+                               ld_row=(Q - 1) * self.Kp, ld_q=self.Kp, S=sub.S, n_q=Q, K=s.n_quant, row_offset=sub.row_offset,
+                               x=sub.x.data_ptr(), x_known=sub.x_known.data_ptr(), m=sub.m_mask.data_ptr(),
+                               u1=u1.data_ptr(), u2=u2.data_ptr(), consts=sub.consts.data_ptr(),
+                               step=self.step_ptr.data_ptr(), guidance_w=cfg.guidance_w, temperature=cfg.x_0_temp,
+                               log_eps=log_eps(), div_mode=cfg.div_mode, q0_override_steps=cfg.q0_override_steps)
+
+    def _philox(self, uniforms) -> Optional[List[PhiloxDraws]]:
+        """Per utterance the in-graph generator of its draws (NARSession._philox), or None if any utterance's draw is not
+        generator-backed."""
+        draws = [uniforms[self._order[u]] for u in range(len(self.subs))]
+        if not all(getattr(d, "gen", None) is not None for d in draws) or not all(t > 0 for t in self.times[:-1]):
+            return None
+        phs = self._phs
+        if phs is None or any(p.gen is not d.gen for p, d in zip(phs, draws)):
+            s = self.m.shape
+            with torch.cuda.stream(self.stream):
+                phs = self._phs = [PhiloxDraws(d.gen, sub.S, s.n_codebooks, s.n_quant, sub.m_mask, sub.consts, self.step_ptr, self.times, self.m.dev)
+                                   for d, sub in zip(draws, self.subs)]
+            self.graph_step = None
+        return phs
+
+    def _step_philox(self, phs: List[PhiloxDraws], use_graph: bool) -> None:
+        """One reverse step of the group as ONE launch sequence / hipGraph: the batched forward, then per utterance its uniforms
+        (its own generator's stream) and its posterior / sample launch, then the step counter."""
+        st = self.stream.cuda_stream
+
+        def body():
+            self.enqueue_forward(st)
+            for u, (sub, ph) in enumerate(zip(self.subs, phs)):
+                ph.enqueue(st)
+                ops.nar_sample(self._sample_args(u, sub, ph.buf, ph.buf), stream=st)
+            ops.add_int(self.step_ptr, 1, stream=st)
+        if not use_graph or (self.graph_step is None and self.step_i == 0 and len(self.times) > 1):
+            body()
+        else:
+            if self.graph_step is None:
+                ops.Graph.begin(st)
+                body()
+                self.graph_step = ops.Graph().end(st)
+            self.graph_step.launch(st)
         self.step_i += 1
 
     def run(self, uniforms: List[Callable[[tuple], torch.Tensor]], use_graph: bool = True, n_steps: Optional[int] = None,
@@ -647,7 +789,14 @@ class NARBatchSession:
         st = self.stream.cuda_stream
         ev0, ev1 = ops.Event(), ops.Event()
         ev0.record(st)
+        phs = self._philox(uniforms)
+        if phs is not None:
+            for ph in phs:
+                ph.reserve(self.times[self.step_i: self.step_i + n], self.step_i, self.stream)
         for _ in range(n):
+            if phs is not None:
+                self._step_philox(phs, use_graph)
+                continue
             self.step(uniforms, use_graph)
         ev1.record(st)
         self._pending = (ev0, ev1, n)

@@ -250,6 +250,10 @@ def nar_sample(args: L.NarSampleArgs, stream: Optional[int] = None) -> None:
     check(lib.m5_nar_sample(C.byref(args), _s(stream)), "m5_nar_sample")
 
 
+def nar_uniforms(args: L.NarUniformArgs, stream: Optional[int] = None) -> None:
+    check(lib.m5_nar_uniforms(C.byref(args), _s(stream)), "m5_nar_uniforms")
+
+
 def expand_tokens(tokens: torch.Tensor, n_text: int, off: torch.Tensor, vals: torch.Tensor, max_run: int,
                   stream: Optional[int] = None) -> torch.Tensor:
     """AR token ids (n,) int64 -> codebook-0 frames (G,) int64 through the CSR expansion table (off int32 (V+1,), vals int64):

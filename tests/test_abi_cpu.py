@@ -264,7 +264,7 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     hdr = os.path.join(ROOT, "include", "mars5_hip.h")
     pairs = {"M5QkvScatter": L.QkvScatter, "M5AttnArgs": L.AttnArgs, "M5Prefetch": L.Prefetch, "M5GemvArgs": L.GemvArgs,
              "M5AttnDecodeArgs": L.AttnDecodeArgs, "M5SampleArgs": L.SampleArgs, "M5NarSampleArgs": L.NarSampleArgs,
-             "M5ArMegaArgs": L.ArMegaArgs, "M5DeferredLN": L.DeferredLN, "M5RowTiles": L.RowTiles}
+             "M5ArMegaArgs": L.ArMegaArgs, "M5DeferredLN": L.DeferredLN, "M5RowTiles": L.RowTiles, "M5NarUniformArgs": L.NarUniformArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')

@@ -429,6 +429,45 @@ def test_tts_batch_equals_sequential_seeded_calls(dev, tiny_bundle):
     print("generated frames per request:", [int(a.shape[0]) for a, _ in seq])
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_in_graph_uniforms_equal_torch_rand_draws(dev, tiny_bundle, gold_dir, dt):
+    """The reverse steps' uniforms generated inside the step graph (nar_engine.PhiloxDraws / m5_nar_uniforms: what every
+    generator-backed call uses) against the same utterance with explicit ``torch.rand`` draws from an identically seeded
+    generator (the reference's own calls, diffuser.py:219-228): identical codes after all steps, and the caller's generator is
+    left exactly where the two-draws-per-step loop leaves it -- lone (hipGraph and eager) and as a batch of three."""
+    from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_batch_inference, perform_simple_inference
+    fx = np.load(os.path.join(gold_dir, "nar_tiny_deep.npz"))
+    nar = _nar(tiny_bundle, dt, dev)
+    T = 12
+    c_text, c_codes, x_l0 = torch.from_numpy(fx["c_text"]), torch.from_numpy(fx["c_codes"]), torch.from_numpy(fx["x_l0"])
+    diff = MultinomialDiffusion(1025, timesteps=200, device="cpu")
+    dsh = DSH(last_greedy=True, x_0_temp=0.7, guidance_w=3, deep_clone=True, q0_override_steps=20)
+    utts = [(c_text, c_codes, x_l0), (c_text[:5], c_codes[:33], x_l0[:17]), (torch.cat([c_text, c_text[1:-1]]), c_codes[:50], x_l0[:41])]
+
+    def gen(seed):
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        return g
+
+    want, offs = [], []
+    for i, (ct, cc, xl) in enumerate(utts):
+        g = gen(900 + i)
+        legacy = lambda shp, _g=g: torch.rand(shp, generator=_g, device=dev)      # noqa: E731  (no .gen attribute: drawn by torch, passed as buffers)
+        want.append(perform_simple_inference(nar, _nar_batch_tuple(ct, cc, xl), diff, T, dsh=dsh, uniform=legacy, generator=g).cpu())
+        offs.append(g.get_offset())
+    for use_graph in (True, False):
+        for i, (ct, cc, xl) in enumerate(utts):
+            g = gen(900 + i)
+            got = perform_simple_inference(nar, _nar_batch_tuple(ct, cc, xl), diff, T, dsh=dsh, generator=g, use_graph=use_graph).cpu()
+            assert torch.equal(got, want[i]), f"utterance {i} (graph={use_graph}): {int((got != want[i]).sum())} codes differ from the torch.rand run"
+            assert g.get_offset() == offs[i], "the generator is not where the reference's draws leave it"
+    gs = [gen(900 + i) for i in range(len(utts))]
+    outs = perform_batch_inference(nar, [_nar_batch_tuple(ct, cc, xl) for ct, cc, xl in utts], diff, T, dsh=dsh, generators=gs)
+    for i, o in enumerate(outs):
+        assert torch.equal(o.cpu(), want[i]), f"batched, utterance {i}: codes differ from the lone torch.rand run"
+        assert gs[i].get_offset() == offs[i]
+
+
 def test_tts_stream_equals_sequential_seeded_calls(dev, tiny_bundle):
     """``tts_stream_from_codes`` (request i+1's AR decode overlapped with request i's NAR steps on two streams) must
     return, per request, exactly what ``torch.manual_seed(s_i); tts_from_codes(...)`` returns."""

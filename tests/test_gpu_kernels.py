@@ -1066,6 +1066,63 @@ def test_nar_sample_vs_oracle(dev):
     print(f"nar_sample: {total_bad} tie-excused mismatching ids over {len(times) * S * Q}")
 
 
+def test_nar_uniforms_equal_torch_rand(dev):
+    """m5_nar_uniforms reproduces ``torch.rand`` on this device bit for bit (Philox4x32-10 with torch's launch geometry and
+    rocrand's uint -> float map): whole draws at the NAR bench shape (11 M values: several grid-stride iterations) and at small
+    sizes (one partial iteration), consecutive draws selected by the device step counter, and the merged form -- first draw on the
+    rows sampled from the model, second draw on the known rows, one draw only at t = 0 -- that m5_nar_sample consumes; the
+    generator advance per draw is the one the engine assumes."""
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.nar_engine import _magic_div
+    prop = torch.cuda.get_device_properties(dev)
+    per_mp = prop.max_threads_per_multi_processor // 256
+    for S, Q, K, seed, off0 in [(1349, 8, 1025, 1234, 0), (37, 8, 1025, 2 ** 63 + 11, 4096), (3, 2, 7, 5, 8), (450, 8, 1025, 99, 2 ** 33)]:
+        n = S * Q * K
+        G = 256 * min(prop.multi_processor_count * per_mp, (n + 255) // 256)
+        inc = ((n - 1) // (4 * G) + 1) * 4
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        g.set_offset(off0)
+        draws = []
+        for _ in range(5):
+            o = g.get_offset()
+            draws.append(torch.rand((1, S, Q, K), generator=g, device=dev)[0])
+            assert g.get_offset() - o == inc, (n, g.get_offset() - o, inc)
+        wrap = lambda v: v - (1 << 64) if v >= (1 << 63) else v                 # noqa: E731
+        rng = torch.tensor([wrap(seed), off0], dtype=torch.int64, device=dev)
+        out = torch.full((S, Q, K), -1.0, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        km, ks = _magic_div(K)
+        # plain form: the first draw of step i = draw 2 i of the generator
+        for i in (0, 1, 2):
+            step.fill_(i)
+            a = L.NarUniformArgs(out=out.data_ptr(), n=n, K=K, k_magic=km, k_shift=ks, m=None, rng=rng.data_ptr(), inc=inc, grid_threads=G,
+                                 step=step.data_ptr(), consts=None)
+            ops.nar_uniforms(a)
+            torch.cuda.synchronize()
+            assert torch.equal(out, draws[2 * i]), f"n={n} step {i}: {int((out != draws[2 * i]).sum())} of {n} values differ from torch.rand"
+        assert float(out.min()) >= 0.0 and float(out.max()) < 1.0
+        # merged form
+        gm = torch.Generator().manual_seed(seed % 1000)
+        m = (torch.rand(S, Q, generator=gm) < 0.4).to(torch.uint8).to(dev)
+        consts = torch.zeros(3, L.NAR_CONSTS, device=dev)
+        consts[:, 6] = torch.tensor([199.0, 1.0, 0.0])
+        for i in (0, 1, 2):
+            step.fill_(i)
+            out.fill_(-1.0)
+            for magic in ((km, ks), (0, 0)):                                   # multiply-shift row index and the plain division
+                a = L.NarUniformArgs(out=out.data_ptr(), n=n, K=K, k_magic=magic[0], k_shift=magic[1], m=m.data_ptr(), rng=rng.data_ptr(), inc=inc,
+                                     grid_threads=G, step=step.data_ptr(), consts=consts.data_ptr())
+                ops.nar_uniforms(a)
+                torch.cuda.synchronize()
+                want = torch.where(m[:, :, None].bool(), draws[2 * i + 1], draws[2 * i]) if i < 2 else draws[2 * i]
+                assert torch.equal(out, want), f"merged form, n={n} step {i}: {int((out != want).sum())} values differ"
+    # bad arguments answer with a status code
+    a = L.NarUniformArgs(out=out.data_ptr(), n=n, K=K, k_magic=km // 2, k_shift=ks, m=m.data_ptr(), rng=rng.data_ptr(), inc=inc, grid_threads=G,
+                         step=step.data_ptr(), consts=consts.data_ptr())
+    assert L.lib.m5_nar_uniforms(a, None) == L.M5_ERR_ARG          # a multiply-shift that does not divide exactly is refused
+
+
 def test_graph_capture_replay(dev):
     from mars5_tts_amd import ops
     st = torch.cuda.Stream(device=dev)
