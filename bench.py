@@ -125,6 +125,8 @@ def parse():
     ap.add_argument("--ref-frames", type=int, default=450)
     ap.add_argument("--n-gen", type=int, default=450)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="cpu_baseline: torch threads of the CPU sample (0 = min(logical CPUs, 32), the measured "
+                                                               "optimum: profiles/r5f_cpu_baseline_threads.txt)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-batch-leg", action="store_true")
@@ -938,14 +940,16 @@ def parity_leg(m, bundle, ref_codes, dtype_name, n_ar=48):
 
 
 # ------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=24.0):
+def cpu_baseline_leg(m, bundle, ref_codes, cfg, n_gen, budget_s=24.0, threads=0):
     """The oracle (a torch-CPU restatement of the reference path, incl. the reference's
     per-token speaker-encoder recompute and per-forward NAR speaker encoder so the COST is the
     reference's) on a bounded sample of the same workload, extrapolated linearly:
     AR prefill + a few decode tokens, and one NAR forward (x2 for CFG) at the bench shapes."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import mars5_oracle as O
-    cores = min(os.cpu_count() or 1, 32)       # more threads than this slow torch-CPU down on these shapes
+    # more than 32 threads slow torch-CPU down on these shapes (measured on the GPU box's host with --cpu-threads 64 / 128:
+    # profiles/r5f_cpu_baseline_threads.txt)
+    cores = threads if threads > 0 else min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     tt = m.texttok.encode("<|startoftext|>" + TRANSCRIPT + ' ' + TEXT.strip() + "<|endoftext|>", allowed_special='all')
     sp = m.speechtok.encode(' '.join(str(t) for t in ref_codes[0, 0].tolist()))
@@ -1155,7 +1159,7 @@ def main():
             out["time_split_ms"] = {"ar_decode": round(ar_engine.LAST_STATS["decode_ms"], 1), "nar_loop": round(nar["ms_per_step"] * 200, 1)}
         leg("roofline", _roofline)
     if single and not args.no_cpu_baseline:
-        leg("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baseline_leg(m, bundle, ref_codes, cfg, args.n_gen)))
+        leg("cpu_baseline", lambda: out.__setitem__("cpu_baseline", cpu_baseline_leg(m, bundle, ref_codes, cfg, args.n_gen, threads=args.cpu_threads)))
     if single and not args.no_parity and args.workload == "c2":
         leg("parity", lambda: out.__setitem__("parity", parity_leg(m, bundle, ref_codes, args.dtype)))
     if single and args.workload == "c2" and not args.no_batch_leg:

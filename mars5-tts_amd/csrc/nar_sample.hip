@@ -168,18 +168,36 @@ __device__ inline float torch_uniform(unsigned v) {
 
 __global__ __launch_bounds__(256) void nar_uniform_kernel(M5NarUniformArgs a) {
     const unsigned G = a.grid_threads;
-    const unsigned long long t = (unsigned long long)blockIdx.x * 256u + threadIdx.x;
-    const unsigned it = (unsigned)(t / G), idx = (unsigned)(t - (unsigned long long)it * G);
+    const unsigned it = blockIdx.y, idx = blockIdx.x * 256u + threadIdx.x;         // grid = (G / 256, iterations): no division
     const long long e0 = (long long)it * 4 * G + idx;
     if (e0 >= a.n) return;
     const int step = a.step ? a.step[0] : 0;
     const bool second = a.m && !(a.consts && (int)a.consts[(long long)step * M5_NAR_CONSTS + 6] == 0);      // t = 0: one draw only
     const unsigned long long seed = a.rng[0], off1 = a.rng[1] + (unsigned long long)step * 2ull * a.inc;
     const uint2 key = make_uint2((unsigned)seed, (unsigned)(seed >> 32));
-    const unsigned long long c1 = off1 / 4 + it;
-    const uint4 r1 = philox4x32_10(make_uint4((unsigned)c1, (unsigned)(c1 >> 32), idx, 0u), key);
-    uint4 r2 = r1;
-    if (second) {
+    // which draw each of this thread's four elements takes: a wave's 64 threads cover 64 consecutive elements of four rows, so
+    // most waves need only ONE of the two Philox calls (prompt frames: all known; generated frames: known for codebook 0 only) --
+    // the calls are skipped wave-uniformly (twenty 32 x 32 -> 64-bit multiplies each: they are this kernel's time)
+    bool known[4] = {false, false, false, false}, need1 = false, need2 = false;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+        const long long e = e0 + (long long)ii * G;
+        if (e < a.n) {
+            if (second) {
+                // row = e / K by the host's multiply-shift (exact for e < 2^32, checked there), or a plain division
+                const unsigned row = a.k_magic ? (unsigned)(((unsigned long long)(unsigned)e * a.k_magic) >> (32 + a.k_shift)) : (unsigned)(e / a.K);
+                known[ii] = a.m[row] != 0;
+            }
+            need2 = need2 || known[ii];
+            need1 = need1 || !known[ii];
+        }
+    }
+    uint4 r1 = make_uint4(0u, 0u, 0u, 0u), r2 = r1;
+    if (__ballot(need1) != 0) {
+        const unsigned long long c1 = off1 / 4 + it;
+        r1 = philox4x32_10(make_uint4((unsigned)c1, (unsigned)(c1 >> 32), idx, 0u), key);
+    }
+    if (__ballot(need2) != 0) {
         const unsigned long long c2 = (off1 + a.inc) / 4 + it;
         r2 = philox4x32_10(make_uint4((unsigned)c2, (unsigned)(c2 >> 32), idx, 0u), key);
     }
@@ -187,15 +205,7 @@ __global__ __launch_bounds__(256) void nar_uniform_kernel(M5NarUniformArgs a) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
         const long long e = e0 + (long long)ii * G;
-        if (e < a.n) {
-            bool known = false;
-            if (second) {
-                // row = e / K by the host's multiply-shift (exact for e < 2^32, checked there), or a plain division
-                const unsigned row = a.k_magic ? (unsigned)(((unsigned long long)(unsigned)e * a.k_magic) >> (32 + a.k_shift)) : (unsigned)(e / a.K);
-                known = a.m[row] != 0;
-            }
-            a.out[e] = torch_uniform(known ? v2[ii] : v1[ii]);
-        }
+        if (e < a.n) a.out[e] = torch_uniform(known[ii] ? v2[ii] : v1[ii]);
     }
 }
 
@@ -214,9 +224,8 @@ extern "C" int m5_nar_uniforms(const M5NarUniformArgs* a, void* stream) {
     }
     const long long G = a->grid_threads;
     const long long iters = (a->n + 4 * G - 1) / (4 * G);
-    const long long blocks = iters * (G / 256);
-    if (blocks > 0x7fffffffll) return M5_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(nar_uniform_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    if (iters > 65535) return M5_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(nar_uniform_kernel, dim3((unsigned)(G / 256), (unsigned)iters), dim3(256), 0, (hipStream_t)stream, *a);
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

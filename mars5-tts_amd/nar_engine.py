@@ -501,7 +501,7 @@ class NARSession:
         """The in-graph generator for this session's draws, if `uniform` is the generator-backed draw of diffuser.py (it carries
         its generator) and the schedule has its only t = 0 step last; else None (explicit uniforms: parity tests)."""
         gen = getattr(uniform, "gen", None)
-        if gen is None or not all(t > 0 for t in self.times[:-1]):
+        if gen is None or not all(t > 0 for t in self.times[:-1]) or L.tool_knob("M5_NAR_PHILOX", "1") == "0":      # A/B knob (tools/nar_step_bench.py)
             return None
         ph = self._ph
         if ph is None or ph.gen is not gen:
@@ -749,7 +749,7 @@ class NARBatchSession:
         """Per utterance the in-graph generator of its draws (NARSession._philox), or None if any utterance's draw is not
         generator-backed."""
         draws = [uniforms[self._order[u]] for u in range(len(self.subs))]
-        if not all(getattr(d, "gen", None) is not None for d in draws) or not all(t > 0 for t in self.times[:-1]):
+        if not all(getattr(d, "gen", None) is not None for d in draws) or not all(t > 0 for t in self.times[:-1]) or L.tool_knob("M5_NAR_PHILOX", "1") == "0":
             return None
         phs = self._phs
         if phs is None or any(p.gen is not d.gen for p, d in zip(phs, draws)):

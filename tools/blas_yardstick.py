@@ -27,6 +27,14 @@ SHAPES = [   # (name, M, N, K, our epilogue)
 ]
 
 
+# MROWS=35840 (a batched NAR group of 16 utterances) / 98304 (a group of 32): the same seven shapes at throughput-mode row counts
+# (how far is the large-M gemm16 configuration from what the vendor library reaches there?)
+if os.environ.get("MROWS"):
+    _m = int(os.environ["MROWS"])
+    SHAPES = [(n, (_m if M == 2816 else _m * 12586 // 2816 // 64 * 64), N, K, e) for n, M, N, K, e in SHAPES]
+    REP = max(2, REP // 4)
+
+
 def time_graph(fn, stream):
     st = stream.cuda_stream
     with torch.cuda.stream(stream):
@@ -84,7 +92,7 @@ def main():
         print(json.dumps(r), flush=True)
         res.append(r)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    json.dump(res, open(os.path.join(ROOT, "gpurun_out", "blas_yardstick.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(ROOT, "gpurun_out", f"blas_yardstick{os.environ.get('MROWS', '')}.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

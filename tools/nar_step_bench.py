@@ -37,7 +37,7 @@ def main():
             sess.prepare(c_text, ref_codes[0].T.contiguous(), x, z, mm, off, list(range(199, 159, -1)))
             gen = torch.Generator(device=dev).manual_seed(1)
             from mars5_tts_amd.diffuser import _generator_uniform
-            uni = _generator_uniform(dev, gen)          # the product's draw (may run on the session's second stream: M5_NAR_RNG_SIDE)
+            uni = _generator_uniform(dev, gen)          # the product's draw (generator-backed: the uniforms are generated inside the step graph; M5_NAR_PHILOX=0: two torch.rand launches)
             sess.run(uni, True, n_steps=5)
             st = sess.stream.cuda_stream
             e0, e1 = ops.Event(), ops.Event()
