@@ -8,6 +8,8 @@
 //   mode 1  ordered launches + release fence / counter add / acquire (price of the fences alone)
 //   mode 2  any-order launches, consumer waits for ALL tiles of the producer (one counter per launch)
 //   mode 3  any-order launches, consumer waits for the ONE producer tile it reads (a flag word per tile)
+//   mode 4  = mode 2 with WRITE-THROUGH stores (sc0 sc1) + s_waitcnt vmcnt(0) instead of the release fence's L2 write-back
+//   mode 5  = mode 1 with the same write-through stores (ordered launches: the price of that hand-off alone)
 // Each workgroup stamps the 100 MHz wall clock at entry, after its wait and at exit: the overlap of launch i+1's entries with
 // launch i's exits is read off the stamps.  Spins are bounded (a grid that is not dispatched in order costs ms, never hangs).
 // build: hipcc --offload-arch=gfx950 -O3 tools/probes/anyorder_probe.hip -o tools/probes/anyorder_probe.bin
@@ -37,6 +39,7 @@ struct Args {
     u64* stamps;              // [G][3]
     unsigned* timeouts;
     int shift;
+    int wt;                   // 1: write-through stores + vmcnt(0) instead of fence(release, agent)
 };
 
 __global__ __launch_bounds__(256) void chain_kernel(Args a) {
@@ -69,12 +72,19 @@ __global__ __launch_bounds__(256) void chain_kernel(Args a) {
         float z = 0.f;
         for (int k = 0; k < a.spin; ++k) z = __builtin_fmaf(z, 0.5f, v.x * 1e-30f);
         v.x += 1.f + z; v.y += 1.f; v.z += 1.f; v.w += 1.f;
-        out[i] = v;
+        if (a.wt) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v vv = {v.x, v.y, v.z, v.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(out + i), "v"(vv) : "memory");
+        } else {
+            out[i] = v;
+        }
     }
     if (tid == 0) lds[0] = 1.f;
     __syncthreads();                                   // every thread's stores are issued
     if (a.done_ctr || a.done_flags) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // each wave waits for its own stores + writes L2 back
+        if (a.wt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // write-through stores: acknowledged = at the memory side
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // each wave waits for its own stores + writes L2 back
         __syncthreads();
         if (tid == 0) {
             if (a.done_ctr) __hip_atomic_fetch_add(a.done_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -104,7 +114,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> host(n);
     std::vector<u64> hst((size_t)L * G * 3);
-    for (int mode = 0; mode < 4; ++mode) {
+    for (int mode = 0; mode < 6; ++mode) {
         double best = 1e30, host_us = 0;
         long bad = 0; unsigned to = 0;
         for (int r = 0; r < reps; ++r) {
@@ -118,9 +128,10 @@ int main(int argc, char** argv) {
                 a.in = (i & 1) ? B : A; a.out = (i & 1) ? A : B;
                 a.tile_floats = tile_floats; a.spin = spin; a.shift = 37;
                 a.stamps = stamps + (size_t)i * G * 3; a.timeouts = timeouts; a.epoch = i + 1;
-                if (mode == 1 || mode == 2) { a.wait_ctr = i ? ctr + i - 1 : nullptr; a.wait_for = G; a.done_ctr = ctr + i; }
+                if (mode == 1 || mode == 2 || mode >= 4) { a.wait_ctr = i ? ctr + i - 1 : nullptr; a.wait_for = G; a.done_ctr = ctr + i; }
+                a.wt = mode >= 4;
                 if (mode == 3) { a.wait_flags = i ? flags + ((i - 1) & 1) * G : nullptr; a.done_flags = flags + (i & 1) * G; }
-                int fl = (mode >= 2 && i > 0) ? hipExtAnyOrderLaunch : 0;
+                int fl = ((mode == 2 || mode == 3 || mode == 4) && i > 0) ? hipExtAnyOrderLaunch : 0;
                 hipExtLaunchKernelGGL(chain_kernel, dim3(G), dim3(256), lds, s, nullptr, nullptr, fl, a);
             }
             auto h1 = std::chrono::high_resolution_clock::now();
