@@ -147,11 +147,15 @@ def _build_cross_operands(plan, step_ptr: torch.Tensor, st: int) -> None:
 _INC_CACHE: Dict[tuple, int] = {}          # (device index, n) -> generator offset one torch.rand of n floats consumes
 
 
-def _magic_div(d: int) -> tuple:
-    """(m, s) with e // d == (e * m) >> (32 + s) for every 0 <= e < 2^32 when m fits 32 bits, else (0, 0) (the kernel divides)."""
-    s = max(d.bit_length() - 1, 0)
-    m = (1 << (32 + s)) // d + 1
-    return (m, s) if m < (1 << 32) else (0, 0)
+def _magic_div(d: int, n_max: int = 1 << 32) -> tuple:
+    """(m, s) with e // d == (e * m) >> (32 + s) for every 0 <= e < n_max, m a 32-bit multiplier -- or (0, 0) when there is none
+    (the kernel then divides).  m = floor(2^(32+s) / d) + 1 overshoots 2^(32+s) / d by r / d with r = m d - 2^(32+s) in (0, d]; the
+    quotient stays exact while e r < 2^(32+s)."""
+    for s in (max(d.bit_length() - 1, 0), d.bit_length()):
+        m = (1 << (32 + s)) // d + 1
+        if m < (1 << 32) and (m * d - (1 << (32 + s))) * max(n_max - 1, 0) < (1 << (32 + s)):
+            return m, s
+    return 0, 0
 
 
 class PhiloxDraws:
@@ -182,7 +186,7 @@ class PhiloxDraws:
                                "this torch build uses another Philox launch geometry than m5_nar_uniforms reproduces")
         self.buf = torch.empty(S, n_q, K, dtype=torch.float32, device=dev)
         self.rng = torch.zeros(2, dtype=torch.int64, device=dev)             # {seed, offset0}: read by the kernel, so the step graph outlives a run
-        km, ks = _magic_div(K)
+        km, ks = _magic_div(K, self.n)
         self.m_mask, self.consts, self.step_ptr = m_mask, consts, step_ptr
         self.args = L.NarUniformArgs(out=self.buf.data_ptr(), n=self.n, K=K, k_magic=km, k_shift=ks, m=m_mask.data_ptr(), rng=self.rng.data_ptr(),
                                      inc=self.inc, grid_threads=self.grid_threads, step=step_ptr.data_ptr(), consts=consts.data_ptr())

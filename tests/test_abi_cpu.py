@@ -51,6 +51,9 @@ def test_argument_validation_returns_status_codes():
     assert lib.m5_attention(_lib.BF16, None, None) == _lib.M5_ERR_ARG
     assert lib.m5_ar_sample(None, None) == _lib.M5_ERR_ARG
     assert lib.m5_nar_sample(None, None) == _lib.M5_ERR_ARG
+    assert lib.m5_nar_uniforms(None, None) == _lib.M5_ERR_ARG
+    bad = _lib.NarUniformArgs(out=None, n=16, K=4, k_magic=0, k_shift=0, m=None, rng=None, inc=4, grid_threads=256, step=None, consts=None)
+    assert lib.m5_nar_uniforms(bad, None) == _lib.M5_ERR_ARG          # no output / no generator state: refused before any launch
     assert lib.m5_graph_begin(None) == _lib.M5_ERR_ARG
     with pytest.raises(_lib.Mars5HipError):
         _lib.check(_lib.M5_ERR_UNSUPPORTED, "unit test")

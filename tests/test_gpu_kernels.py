@@ -1092,7 +1092,7 @@ def test_nar_uniforms_equal_torch_rand(dev):
         rng = torch.tensor([wrap(seed), off0], dtype=torch.int64, device=dev)
         out = torch.full((S, Q, K), -1.0, device=dev)
         step = torch.zeros(1, dtype=torch.int32, device=dev)
-        km, ks = _magic_div(K)
+        km, ks = _magic_div(K, n)
         # plain form: the first draw of step i = draw 2 i of the generator
         for i in (0, 1, 2):
             step.fill_(i)

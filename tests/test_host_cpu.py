@@ -296,3 +296,25 @@ def test_row_tile_lists_carry_the_sequence_lengths():
     sub = rt._subs[(4, 2)]
     assert sub.len_dev.tolist() == [700, 700] and _rt_sub(rt, 4, 2) is sub.c and _rt_sub(rt, 0, 6) is rt.c
     assert sub.maps[1].tolist() == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11]            # 6 tiles of 128 per sequence, numbered from the run's first row
+
+
+def test_multiply_shift_row_index_of_the_uniform_kernel():
+    """m5_nar_uniforms finds the row of element e as (e * m) >> (32 + s) (nar_engine._magic_div): exact for every e below the
+    stated bound -- all 32-bit e for K = 1025 classes -- and (0, 0) = "divide" where no 32-bit multiplier is exact (7 over 2^32)."""
+    import random
+    from mars5_tts_amd.nar_engine import _magic_div
+    rnd = random.Random(5)
+    for d, n_max in [(1025, 2 ** 32), (1024, 2 ** 32), (7, 2 ** 32), (7, 6000 * 8 * 7), (3, 2 ** 32), (641, 2 ** 32), (1, 2 ** 20), (2, 2 ** 32),
+                     (65537, 2 ** 32), (4097, 2 ** 31), (999983, 2 ** 32), (1025, 6000 * 8 * 1025)]:
+        m, s = _magic_div(d, n_max)
+        if m == 0:
+            continue
+        assert m < 2 ** 32
+        probes = [0, 1, d - 1, d, d + 1, n_max - 1, n_max - d, n_max // 2]
+        probes += [k * d + o for k in (1, 2, 1000, (n_max - 1) // d, (n_max - 1) // d - 1, rnd.randrange(1, max(n_max // d, 2))) for o in (-1, 0, 1)]
+        probes += [rnd.randrange(0, n_max) for _ in range(20000)]
+        for e in probes:
+            if 0 <= e < n_max:
+                assert (e * m) >> (32 + s) == e // d, (d, n_max, e)
+    assert _magic_div(1025)[0] != 0, "the real class count takes the multiply-shift path over the whole 32-bit range"
+    assert _magic_div(7) == (0, 0) and _magic_div(7, 6000 * 8 * 7)[0] != 0      # no 32-bit multiplier divides by 7 over 2^32; over a real draw one does
