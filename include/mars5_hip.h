@@ -327,6 +327,12 @@ typedef struct {
     int32_t batch, state_bs;
     int64_t logits_bs, tokens_bs, noise_bs, xres_bs, eos_table_bs;
     const int32_t* n_est_b; const int32_t* max_len_b;
+    /* noise = NULL: the Exp(1) row of sampler call i (= n_gen) is generated here, bit-identical to the i-th
+     * `torch.empty(V).exponential_(1, generator=g)` of a generator that stood at (seed, offset0) before call 0 (torch.multinomial's
+     * draw, ar_generate.py:115): rng = device {seed, offset0} (sequence b: rng + b * rng_bs words), call i draws at offset0 + i * noise_inc,
+     * noise_grid = torch's launch width for V values (see m5_nar_uniforms).  Only the kept tokens' values are ever computed. */
+    const uint64_t* rng; int64_t rng_bs;
+    uint32_t noise_inc, noise_grid;
 } M5SampleArgs;
 M5_API int m5_ar_sample(const M5SampleArgs* a, void* stream);
 
@@ -365,6 +371,7 @@ typedef struct {
     const uint64_t* rng;                            /* device: {seed, offset0}                 */
     uint32_t inc, grid_threads;
     const int32_t* step; const float* consts;       /* as in M5NarSampleArgs (may be NULL with m = NULL) */
+    int32_t transform;                              /* 0: torch.rand (uniform [0, 1));  1: Tensor.exponential_(1) of the same draw */
 } M5NarUniformArgs;
 M5_API int m5_nar_uniforms(const M5NarUniformArgs* a, void* stream);
 

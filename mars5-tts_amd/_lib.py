@@ -114,7 +114,8 @@ class SampleArgs(C.Structure):
                 ("embed", vp), ("dim", i32), ("xres", vp),
                 ("batch", i32), ("state_bs", i32),
                 ("logits_bs", i64), ("tokens_bs", i64), ("noise_bs", i64), ("xres_bs", i64), ("eos_table_bs", i64),
-                ("n_est_b", vp), ("max_len_b", vp)]
+                ("n_est_b", vp), ("max_len_b", vp),
+                ("rng", vp), ("rng_bs", i64), ("noise_inc", C.c_uint32), ("noise_grid", C.c_uint32)]
 
 
 class NarSampleArgs(C.Structure):
@@ -130,7 +131,7 @@ class NarSampleArgs(C.Structure):
 class NarUniformArgs(C.Structure):
     """M5NarUniformArgs (include/mars5_hip.h): the step's uniforms as torch.rand draws them, generated in the library."""
     _fields_ = [("out", vp), ("n", i64), ("K", i32), ("k_magic", C.c_uint32), ("k_shift", C.c_uint32), ("m", vp),
-                ("rng", vp), ("inc", C.c_uint32), ("grid_threads", C.c_uint32), ("step", vp), ("consts", vp)]
+                ("rng", vp), ("inc", C.c_uint32), ("grid_threads", C.c_uint32), ("step", vp), ("consts", vp), ("transform", i32)]
 
 
 class RowTiles(C.Structure):

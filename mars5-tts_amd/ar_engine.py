@@ -270,24 +270,38 @@ class ARSession:
                                 pf=self._pf(nxt if plan == 1 else None, npf))
             ops.ar_gemv(m.dt, L.PRO_DT, L.GEPI_RESIDUAL, a, stream=st)
 
-    def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: torch.Tensor) -> None:
-        """noise: (n_steps, V) fp32 device tensor of Exp(1) draws (one row per sampler call)."""
+    def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: Optional[torch.Tensor], rng: Optional[tuple] = None,
+                          n_steps: Optional[int] = None) -> None:
+        """noise: (n_steps, V) fp32 device tensor of Exp(1) draws (one row per sampler call) -- or None with
+        rng = (seed, offset0, generator offset per draw, torch's launch width for V values): the sampler then generates the row
+        of call i itself, bit-identical to the i-th ``torch.empty(V).exponential_(1)`` of a generator that stood at (seed, offset0)
+        (include/mars5_hip.h, M5SampleArgs.rng): no noise buffer, no ATen launch in the decode loop."""
         m, s = self.m, self.m.shape
+        self._rng = None
+        if noise is None:
+            assert rng is not None and n_steps is not None
+            seed, off0, inc, grid = rng
+            wrap = lambda v: v - (1 << 64) if v >= (1 << 63) else v                 # noqa: E731
+            with torch.cuda.stream(self.stream):
+                self._rng = torch.tensor([wrap(int(seed) & 0xFFFFFFFFFFFFFFFF), int(off0)], dtype=torch.int64).to(m.dev)
         eos_tab = None
         n_est = 0
         if cfg.n_phones_gen is not None:
             n_est = int(cfg.n_phones_gen)
             eos_tab = eos_penalty_table(n_est, cfg.eos_penalty_decay, cfg.eos_penalty_factor).to(m.dev)
         self._eos_tab, self._noise = eos_tab, noise
-        assert noise.dtype == torch.float32 and noise.shape[1] == s.n_vocab and noise.is_contiguous()
+        assert noise is None or (noise.dtype == torch.float32 and noise.shape[1] == s.n_vocab and noise.is_contiguous())
         a = L.SampleArgs(logits=self.logits.data_ptr(), V=s.n_vocab, state=self.state.data_ptr(), tokens=self.tokens.data_ptr(),
                          max_len=self.max_len, alpha_frequency=cfg.alpha_frequency, alpha_presence=cfg.alpha_presence,
                          penalty_window=cfg.penalty_window, n_text=n_text, eos_idx=eos_idx, n_est=n_est,
                          eos_table=eos_tab.data_ptr() if eos_tab is not None else None, temperature=cfg.temperature,
-                         div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, typical_p=float(cfg.typical_p), noise=noise.data_ptr(),
-                         noise_stride=s.n_vocab, embed=m.embed.data_ptr(), dim=s.dim, xres=self.xdec.data_ptr())
+                         div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, typical_p=float(cfg.typical_p),
+                         noise=noise.data_ptr() if noise is not None else None,
+                         noise_stride=s.n_vocab, embed=m.embed.data_ptr(), dim=s.dim, xres=self.xdec.data_ptr(),
+                         rng=self._rng.data_ptr() if self._rng is not None else None, rng_bs=0,
+                         noise_inc=int(rng[2]) if noise is None else 0, noise_grid=int(rng[3]) if noise is None else 0)
         self._sample_args = a
-        self.n_noise = noise.shape[0]
+        self.n_noise = noise.shape[0] if noise is not None else int(n_steps)
 
     def capture(self) -> None:
         """Capture one decode step (layers + head + sampler) as a hipGraph."""
@@ -440,12 +454,21 @@ class ARBatchSession:
             sub.prefill(prompts[b], ref_codes[b])
             self.P[b] = sub.P
 
-    def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: torch.Tensor,
-                          n_phones_gen: Optional[List[Optional[int]]] = None) -> None:
-        """noise (B, n_steps, V) fp32 device: row [b][i] feeds sequence b's i-th sampler call.
+    def configure_sampler(self, cfg: ARSamplingConfig, n_text: int, eos_idx: int, noise: Optional[torch.Tensor],
+                          n_phones_gen: Optional[List[Optional[int]]] = None, rng: Optional[tuple] = None, n_steps: Optional[int] = None) -> None:
+        """noise (B, n_steps, V) fp32 device: row [b][i] feeds sequence b's i-th sampler call -- or None with
+        rng = ([(seed_b, offset0_b)], generator offset per draw, torch's launch width for V values): every sequence's sampler
+        generates its own Exp(1) values (ARSession.configure_sampler).
         n_phones_gen: per-sequence EOS-penalty length estimates (``cfg.n_phones_gen`` for all when None)."""
         m, s, B = self.m, self.m.shape, self.B
-        assert noise.dtype == torch.float32 and noise.shape[0] == B and noise.shape[2] == s.n_vocab and noise.is_contiguous()
+        rng_dev = None
+        if noise is None:
+            assert rng is not None and n_steps is not None and len(rng[0]) == B
+            wrap = lambda v: v - (1 << 64) if v >= (1 << 63) else v                 # noqa: E731
+            with torch.cuda.stream(self.stream):
+                rng_dev = torch.tensor([[wrap(int(sd) & 0xFFFFFFFFFFFFFFFF), int(of)] for sd, of in rng[0]], dtype=torch.int64).to(m.dev)
+        else:
+            assert noise.dtype == torch.float32 and noise.shape[0] == B and noise.shape[2] == s.n_vocab and noise.is_contiguous()
         ests = n_phones_gen if n_phones_gen is not None else [cfg.n_phones_gen] * B
         eos_tab = n_est_b = None
         if any(e is not None for e in ests):
@@ -457,16 +480,19 @@ class ARBatchSession:
             eos_tab = eos_tab.to(m.dev)
             n_est_b = torch.tensor([int(e) for e in ests], dtype=torch.int32, device=m.dev)
         max_len_b = torch.tensor(self.max_lens, dtype=torch.int32, device=m.dev)
-        self._keep = [eos_tab, n_est_b, max_len_b, noise]
+        self._keep = [eos_tab, n_est_b, max_len_b, noise, rng_dev]
         self.eos_idx = eos_idx
-        self.n_noise = noise.shape[1]
+        self.n_noise = noise.shape[1] if noise is not None else int(n_steps)
         self._sample_args = L.SampleArgs(
             logits=self.logits.data_ptr(), V=s.n_vocab, state=self.state.data_ptr(), tokens=self.tokens.data_ptr(), max_len=max(self.max_lens),
             alpha_frequency=cfg.alpha_frequency, alpha_presence=cfg.alpha_presence, penalty_window=cfg.penalty_window, n_text=n_text,
             eos_idx=eos_idx, n_est=0, eos_table=eos_tab.data_ptr() if eos_tab is not None else None, temperature=cfg.temperature,
-            div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, typical_p=float(cfg.typical_p), noise=noise.data_ptr(),
+            div_mode=cfg.div_mode, top_k=int(cfg.topk or 0), top_p=cfg.top_p, typical_p=float(cfg.typical_p),
+            noise=noise.data_ptr() if noise is not None else None,
             noise_stride=s.n_vocab, embed=m.embed.data_ptr(), dim=s.dim, xres=self.x.data_ptr(),
-            batch=B, state_bs=L.ST_WORDS, logits_bs=s.n_vocab, tokens_bs=self.tokens.stride(0), noise_bs=noise.stride(0), xres_bs=s.dim,
+            batch=B, state_bs=L.ST_WORDS, logits_bs=s.n_vocab, tokens_bs=self.tokens.stride(0), noise_bs=noise.stride(0) if noise is not None else 0, xres_bs=s.dim,
+            rng=rng_dev.data_ptr() if rng_dev is not None else None, rng_bs=2, noise_inc=int(rng[1]) if rng_dev is not None else 0,
+            noise_grid=int(rng[2]) if rng_dev is not None else 0,
             eos_table_bs=eos_tab.stride(0) if eos_tab is not None else 0,
             n_est_b=n_est_b.data_ptr() if n_est_b is not None else None, max_len_b=max_len_b.data_ptr())
 

@@ -8,6 +8,7 @@ from typing import List, Optional, Union
 import torch
 from torch import Tensor
 
+from . import _lib as L
 from .ar_engine import ARBatchSession, ARSamplingConfig, ARSession
 
 
@@ -50,6 +51,7 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
     n_steps = max_len - P
     gen = None
     fill = None
+    rng = None
     with torch.cuda.stream(sess.stream):
         if noise is None:
             # One Exp(1) vector per sampler call, drawn call-by-call like torch.multinomial does (ar_generate.py:115).
@@ -59,26 +61,35 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
             # NAR stage) sees the same stream.
             gen = generator if generator is not None else torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
             off0 = gen.get_offset()
-            noise_d = torch.empty(n_steps, n_vocab, dtype=torch.float32, device=dev)
             probe = torch.empty(n_vocab, dtype=torch.float32, device=dev)
-
-            def fill(lo, hi, _chunk=64):
-                hi = min(n_steps, (hi + _chunk - 1) // _chunk * _chunk)      # whole chunks: fewer host round trips
-                with torch.cuda.stream(sess.stream):
-                    for i in range(lo, hi):
-                        noise_d[i].exponential_(1, generator=generator)
-                return hi
-
             probe.exponential_(1, generator=generator)                       # the generator offset one (V,) draw consumes
             per_draw = gen.get_offset() - off0
             gen.set_offset(off0)
+            # Round 5: the sampler generates each call's Exp(1) values itself, bit-identical to these exponential_ draws (torch's
+            # Philox4x32-10 launch geometry for V values: csrc/common.h, m5_torch_draw_bits) -- provided this torch build advances the
+            # generator the way that geometry implies; otherwise (or M5_AR_PHILOX=0, tools A/B) the rows are drawn by torch, in
+            # chunks just ahead of the graph replays that read them.
+            prop = torch.cuda.get_device_properties(dev)
+            grid = 256 * min(int(prop.multi_processor_count) * max(int(getattr(prop, "max_threads_per_multi_processor", 2048)) // 256, 1),
+                             (n_vocab + 255) // 256)
+            if per_draw == ((n_vocab - 1) // (4 * grid) + 1) * 4 and L.tool_knob("M5_AR_PHILOX", "1") != "0":
+                rng, noise_d = (int(gen.initial_seed()), int(off0), int(per_draw), int(grid)), None
+            else:
+                noise_d = torch.empty(n_steps, n_vocab, dtype=torch.float32, device=dev)
+
+                def fill(lo, hi, _chunk=64):
+                    hi = min(n_steps, (hi + _chunk - 1) // _chunk * _chunk)      # whole chunks: fewer host round trips
+                    with torch.cuda.stream(sess.stream):
+                        for i in range(lo, hi):
+                            noise_d[i].exponential_(1, generator=generator)
+                    return hi
         else:
             noise_d = noise.to(device=dev, dtype=torch.float32).contiguous()
     cfg = ARSamplingConfig(temperature=float(temperature), topk=topk, top_p=float(top_p), alpha_frequency=float(alpha_frequency),
                            alpha_presence=float(alpha_presence), penalty_window=int(penalty_window), typical_p=float(typical_p),
                            eos_penalty_factor=float(eos_penalty_factor), eos_penalty_decay=float(eos_penalty_decay),
                            n_phones_gen=n_phones_gen, div_mode=div_mode)
-    sess.configure_sampler(cfg, n_text, eos_idx, noise_d)
+    sess.configure_sampler(cfg, n_text, eos_idx, noise_d, rng=rng, n_steps=n_steps)
     sess.prefill(xx, ss_gen, spk_vec=spk_vec)
     out = sess.decode(use_graph=use_graph, noise_fill=fill)
     if gen is not None:
@@ -132,7 +143,7 @@ def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: L
     n_steps = max(ml - P for ml, P in zip(max_lens, Ps))
     gens, offs, pers = [], [], []
     with torch.cuda.stream(sess.stream):
-        noise_d = torch.ones(B, n_steps, n_vocab, dtype=torch.float32, device=dev)
+        noise_d = torch.ones(B, n_steps, n_vocab, dtype=torch.float32, device=dev) if noises is not None else None
         probe = torch.empty(n_vocab, dtype=torch.float32, device=dev)
         for b in range(B):
             nb = max_lens[b] - Ps[b]
@@ -158,6 +169,18 @@ def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: L
                 offs[b] = offs[b] + run.get(id(gens[b]), 0)
                 run[id(gens[b])] = run.get(id(gens[b]), 0) + (max_lens[b] - Ps[b]) * pers[b]
 
+    # Round 5: every sequence's sampler generates its own Exp(1) values from its generator's Philox stream (M5SampleArgs.rng, one
+    # {seed, offset0} pair per sequence; see ar_generate above) -- no (B, n_steps, V) noise tensor, no exponential_ launches.
+    prop = torch.cuda.get_device_properties(dev)
+    grid = 256 * min(int(prop.multi_processor_count) * max(int(getattr(prop, "max_threads_per_multi_processor", 2048)) // 256, 1), (n_vocab + 255) // 256)
+    inc = ((n_vocab - 1) // (4 * grid) + 1) * 4
+    rng = None
+    if noises is None and all(p == inc for p in pers) and L.tool_knob("M5_AR_PHILOX", "1") != "0":
+        rng = ([(int(g.initial_seed()), int(o)) for g, o in zip(gens, offs)], inc, grid)
+    elif noises is None:
+        with torch.cuda.stream(sess.stream):
+            noise_d = torch.ones(B, n_steps, n_vocab, dtype=torch.float32, device=dev)
+
     def fill(lo, hi, _chunk=64):
         """rows lo..hi-1 of every sequence that draws from a generator, in whole chunks just ahead of the replays that read
         them.  Requests that share ONE generator (the global one) would interleave their draws chunk by chunk; a lone call
@@ -175,9 +198,9 @@ def ar_generate_batch(texttok, speechtok, codeclm, xxs: List[Tensor], ss_gens: L
                            alpha_presence=float(alpha_presence), penalty_window=int(penalty_window), typical_p=float(typical_p),
                            eos_penalty_factor=float(eos_penalty_factor), eos_penalty_decay=float(eos_penalty_decay),
                            n_phones_gen=None, div_mode=div_mode)
-    sess.configure_sampler(cfg, n_text, eos_idx, noise_d, n_phones_gen=n_phones_gens)
+    sess.configure_sampler(cfg, n_text, eos_idx, noise_d, n_phones_gen=n_phones_gens, rng=rng, n_steps=n_steps)
     sess.prefill(xxs, ss_gens)
-    outs = sess.decode(use_graph=use_graph, noise_fill=fill if any(g is not None for g in gens) else None)
+    outs = sess.decode(use_graph=use_graph, noise_fill=fill if (rng is None and any(g is not None for g in gens)) else None)
     for b in range(B):                      # leave every generator where a lone reference call leaves it
         if gens[b] is not None:
             n_iter = (int(outs[b].shape[-1]) - Ps[b]) + (1 if sess.ended_on_eos[b] else 0)

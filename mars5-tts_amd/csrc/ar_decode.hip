@@ -619,7 +619,8 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
         a.logits += b * a.logits_bs;
         a.state += b * a.state_bs;
         a.tokens += b * a.tokens_bs;
-        a.noise += b * a.noise_bs;
+        if (a.noise) a.noise += b * a.noise_bs;
+        if (a.rng) a.rng += b * a.rng_bs;
         a.xres += b * a.xres_bs;
         if (a.eos_table) a.eos_table += b * a.eos_table_bs;
         if (a.n_est_b) a.n_est = a.n_est_b[b];
@@ -879,14 +880,17 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
     for (int j = tid; j < n_keep; j += 1024) part += expf(key_to_float((uint32_t)(sk[j] >> 32)) - v0f);
     const float S2 = block_sum<16>(part, red);
     const float logS = logf(S2);
-    const float* q = a.noise + (int64_t)n_gen * a.noise_stride;
+    const float* q = a.noise ? a.noise + (int64_t)n_gen * a.noise_stride : nullptr;
+    // noise = NULL: the Exp(1) value of a kept token comes straight from torch's Philox stream for this sampler call (common.h)
+    const unsigned long long nseed = q ? 0ull : a.rng[0], noff = q ? 0ull : a.rng[1] + (unsigned long long)n_gen * a.noise_inc;
     float best = -1.f;
     int besti = 0x7fffffff;
     for (int j = tid; j < n_keep; j += 1024) {
         const float v = key_to_float((uint32_t)(sk[j] >> 32));
         const int id = (int)(sk[j] & 0xffffffffu);
         const float pz = expf((v - v0f) - logS);
-        const float sc = pz / q[id];
+        const float qv = q ? q[id] : m5_torch_exponential1(m5_torch_draw_bits(nseed, noff, (unsigned long long)id, a.noise_grid));
+        const float sc = pz / qv;
         if (sc > best || (sc == best && id < besti)) { best = sc; besti = id; }
     }
     // block argmax (value desc, index asc)
@@ -961,7 +965,8 @@ extern "C" int m5_ar_attn_decode(int dtype, const M5AttnDecodeArgs* a, void* str
 }
 
 extern "C" int m5_ar_sample(const M5SampleArgs* a, void* stream) {
-    if (!a || !a->logits || !a->state || !a->tokens || !a->noise || !a->embed || !a->xres || a->V <= 1) return M5_ERR_ARG;
+    if (!a || !a->logits || !a->state || !a->tokens || !a->embed || !a->xres || a->V <= 1) return M5_ERR_ARG;
+    if (!a->noise && (!a->rng || a->noise_grid == 0 || (a->noise_grid % 256) || (a->noise_inc % 4) || a->noise_inc == 0)) return M5_ERR_ARG;
     if (a->V > 8192) return M5_ERR_UNSUPPORTED;
     if (!(a->temperature > 0.f)) return M5_ERR_ARG;
     int V2 = 1024;

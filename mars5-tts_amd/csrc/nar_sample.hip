@@ -151,21 +151,6 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
 // (rng[0..1]), so a captured step graph serves any generator state the host binds a run to.
 // The posterior / sample kernel reads draw 1 on the rows it samples from the model (m = 0) and draw 2 on the known rows, so
 // ONE merged buffer is written: out[e] = m[row(e)] ? u2[e] : u1[e]  (m = NULL: draw 1 everywhere = torch.rand itself).
-__device__ inline uint4 philox4x32_10(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long m0 = (unsigned long long)0xD2511F53u * c.x, m1 = (unsigned long long)0xCD9E8D57u * c.z;
-        c = make_uint4((unsigned)(m1 >> 32) ^ c.y ^ k.x, (unsigned)m1, (unsigned)(m0 >> 32) ^ c.w ^ k.y, (unsigned)m0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-__device__ inline float torch_uniform(unsigned v) {
-    const float u = 2.3283064e-10f + ((float)v * 2.3283064e-10f);      // rocrand_device::detail::uniform_distribution
-    return u == 1.0f ? 0.0f : u;                                       // at::native uniform_kernel: (0, 1] -> [0, 1)
-}
-
 __global__ __launch_bounds__(256) void nar_uniform_kernel(M5NarUniformArgs a) {
     const unsigned G = a.grid_threads;
     const unsigned it = blockIdx.y, idx = blockIdx.x * 256u + threadIdx.x;         // grid = (G / 256, iterations): no division
@@ -195,17 +180,20 @@ __global__ __launch_bounds__(256) void nar_uniform_kernel(M5NarUniformArgs a) {
     uint4 r1 = make_uint4(0u, 0u, 0u, 0u), r2 = r1;
     if (__ballot(need1) != 0) {
         const unsigned long long c1 = off1 / 4 + it;
-        r1 = philox4x32_10(make_uint4((unsigned)c1, (unsigned)(c1 >> 32), idx, 0u), key);
+        r1 = m5_philox4x32_10(make_uint4((unsigned)c1, (unsigned)(c1 >> 32), idx, 0u), key);
     }
     if (__ballot(need2) != 0) {
         const unsigned long long c2 = (off1 + a.inc) / 4 + it;
-        r2 = philox4x32_10(make_uint4((unsigned)c2, (unsigned)(c2 >> 32), idx, 0u), key);
+        r2 = m5_philox4x32_10(make_uint4((unsigned)c2, (unsigned)(c2 >> 32), idx, 0u), key);
     }
     const unsigned v1[4] = {r1.x, r1.y, r1.z, r1.w}, v2[4] = {r2.x, r2.y, r2.z, r2.w};
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
         const long long e = e0 + (long long)ii * G;
-        if (e < a.n) a.out[e] = torch_uniform(known[ii] ? v2[ii] : v1[ii]);
+        if (e < a.n) {
+            const unsigned v = known[ii] ? v2[ii] : v1[ii];
+            a.out[e] = a.transform == 1 ? m5_torch_exponential1(v) : m5_torch_uniform(v);
+        }
     }
 }
 
@@ -214,6 +202,7 @@ __global__ __launch_bounds__(256) void nar_uniform_kernel(M5NarUniformArgs a) {
 extern "C" int m5_nar_uniforms(const M5NarUniformArgs* a, void* stream) {
     if (!a || !a->out || !a->rng || a->n <= 0 || a->n >= (1ll << 32) || a->grid_threads == 0 || (a->grid_threads % 256) || (a->inc % 4)) return M5_ERR_ARG;
     if (a->m && (a->K <= 0 || !a->consts || !a->step)) return M5_ERR_ARG;
+    if (a->transform != 0 && a->transform != 1) return M5_ERR_ARG;
     if (a->m && a->k_magic) {                     // the multiply-shift must divide exactly over the whole range: checked at the row boundaries
         const long long rows = (a->n + a->K - 1) / a->K;
         for (long long r = 1; r <= rows; r += (rows > 64 ? rows / 64 : 1)) {

@@ -556,6 +556,59 @@ def test_ar_generator_left_where_reference_leaves_it(dev, tiny_bundle):
     assert seen_full and seen_eos, f"max_len run seen: {seen_full}, EOS-terminated run seen: {seen_eos}"
 
 
+def test_ar_in_kernel_noise_equals_torch_exponential_rows(dev, tiny_bundle, gold_dir):
+    """The sampler's own Exp(1) values (M5SampleArgs.rng: torch's Philox stream for call i, csrc/common.h) against the same decode
+    fed explicit rows drawn by ``Tensor.exponential_`` from an identically seeded generator (torch.multinomial's draw, reference
+    ar_generate.py:115): identical tokens under a sampler setting where the draws decide (top_k 100, top_p 0.95, T 1.0), hipGraph
+    and eager, and the generator is left one draw per executed loop iteration further on."""
+    from mars5_tts_amd.ar_generate import ar_generate
+    fx = np.load(os.path.join(gold_dir, "ar_tiny_sampled_deep.npz"))
+    lm = _lm(tiny_bundle, torch.float32, dev)
+    tt, st = _toks(tiny_bundle)
+    prompt = torch.from_numpy(fx["prompt"])
+    ref = torch.from_numpy(fx["ref_codes"])[0].T.contiguous()
+    n_gen = 60
+    V = tiny_bundle.ar_shape.n_vocab
+
+    def run(**kw):
+        return ar_generate(tt, st, lm, prompt, ref, int(fx["first_codec_idx"]), max_len=prompt.shape[0] + n_gen, fp16=False, temperature=1.0,
+                           topk=100, top_p=0.95, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4, penalty_window=100, eos_penalty_decay=0.5,
+                           eos_penalty_factor=1.0, n_phones_gen=round(len(TEXT)), vocode=False, **kw).cpu()
+
+    g = torch.Generator(device=dev)
+    g.manual_seed(4242)
+    rows = torch.stack([torch.empty(V, device=dev).exponential_(1, generator=g) for _ in range(n_gen)])
+    per_draw = g.get_offset() // n_gen
+    want = run(noise=rows)
+    assert len(set(want[prompt.shape[0]:].tolist())) > 5, "the sampled continuation should not be degenerate"
+    for use_graph in (True, False):
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(4242)
+        got = run(generator=g2, use_graph=use_graph)
+        assert torch.equal(got, want), f"graph={use_graph}: tokens differ from the run on torch's exponential_ rows"
+        n_iter = int(got.shape[0]) - int(prompt.shape[0]) + (1 if got.shape[0] < prompt.shape[0] + n_gen else 0)
+        assert g2.get_offset() in (n_iter * per_draw, (n_iter + 1) * per_draw) and g2.get_offset() <= n_gen * per_draw
+    # the batched decode step: one {seed, offset} pair per sequence against explicit per-sequence rows
+    from mars5_tts_amd.ar_generate import ar_generate_batch
+    prompts = [prompt, prompt[: prompt.shape[0] - 7], torch.cat([prompt, prompt[-5:]])]
+    seeds = [11, 12, 13]
+    kw = dict(max_len=[int(p.shape[0]) + 40 for p in prompts], temperature=1.0, topk=100, top_p=0.95, typical_p=1.0, alpha_frequency=3, alpha_presence=0.4,
+              penalty_window=100, eos_penalty_decay=0.5, eos_penalty_factor=1.0, n_phones_gens=[round(len(TEXT))] * 3)
+    gens = []
+    rows_b = []
+    for sd in seeds:
+        gb = torch.Generator(device=dev)
+        gb.manual_seed(sd)
+        rows_b.append(torch.stack([torch.empty(V, device=dev).exponential_(1, generator=gb) for _ in range(40)]))
+        gb2 = torch.Generator(device=dev)
+        gb2.manual_seed(sd)
+        gens.append(gb2)
+    want_b = ar_generate_batch(tt, st, lm, prompts, [ref] * 3, [int(fx["first_codec_idx"])] * 3, noises=rows_b, **kw)
+    got_b = ar_generate_batch(tt, st, lm, prompts, [ref] * 3, [int(fx["first_codec_idx"])] * 3, generators=gens, **kw)
+    for i, (w, g_) in enumerate(zip(want_b, got_b)):
+        assert torch.equal(w.cpu(), g_.cpu()), f"batched decode, sequence {i}: tokens differ from the run on torch's exponential_ rows"
+
+
 def test_ar_batch_tiny_f32_matches_reference_tokens(dev, tiny_bundle, gold_dir):
     """Batched AR decode (config 3) in fp32: three reference fixtures (greedy deep, sampled deep, greedy
     shallow -- different prompts, lengths and noise streams, ONE sampler configuration is shared per batch, so

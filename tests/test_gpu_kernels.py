@@ -1117,6 +1117,25 @@ def test_nar_uniforms_equal_torch_rand(dev):
                 torch.cuda.synchronize()
                 want = torch.where(m[:, :, None].bool(), draws[2 * i + 1], draws[2 * i]) if i < 2 else draws[2 * i]
                 assert torch.equal(out, want), f"merged form, n={n} step {i}: {int((out != want).sum())} values differ"
+    # the exponential transform of the same draws (the AR sampler's Exp(1) noise: torch.multinomial's exponential_) -- incl. torch's
+    # guard against log(1) -- over 4 M values and at the sampler's size (one value per Philox call: V <= launch width)
+    for n_e, seed in [(4096, 321), (1 << 22, 7), (1025 * 4099, 2 ** 40 + 3)]:
+        G = 256 * min(prop.multi_processor_count * per_mp, (n_e + 255) // 256)
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        rows = [torch.empty(n_e, device=dev).exponential_(1, generator=g) for _ in range(3)]
+        inc = ((n_e - 1) // (4 * G) + 1) * 4
+        assert g.get_offset() == 3 * inc
+        rng = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+        oute = torch.empty(n_e, device=dev)
+        for i in range(3):
+            rng[1] = i * inc
+            a = L.NarUniformArgs(out=oute.data_ptr(), n=n_e, K=1, k_magic=0, k_shift=0, m=None, rng=rng.data_ptr(), inc=inc, grid_threads=G,
+                                 step=None, consts=None, transform=1)
+            ops.nar_uniforms(a)
+            torch.cuda.synchronize()
+            assert torch.equal(oute, rows[i]), f"exponential_, n={n_e} draw {i}: {int((oute != rows[i]).sum())} values differ (max rel {float(((oute - rows[i]).abs() / rows[i]).max()):.3g})"
+        assert float(oute.min()) > 0.0
     # bad arguments answer with a status code
     a = L.NarUniformArgs(out=out.data_ptr(), n=n, K=K, k_magic=km // 2, k_shift=ks, m=m.data_ptr(), rng=rng.data_ptr(), inc=inc, grid_threads=G,
                          step=step.data_ptr(), consts=consts.data_ptr())
