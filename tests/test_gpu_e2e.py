@@ -468,6 +468,40 @@ def test_in_graph_uniforms_equal_torch_rand_draws(dev, tiny_bundle, gold_dir, dt
         assert gs[i].get_offset() == offs[i]
 
 
+def test_in_graph_uniforms_survive_a_run_split_in_two(dev, tiny_bundle, gold_dir):
+    """A session whose reverse steps are enqueued by two ``run`` calls (4 steps, then the rest -- what tools/nar_step_bench.py does)
+    binds each part to the generator's state at that moment: the draw offsets follow the device step counter from the SESSION's
+    first step, so the codes and the generator's final state equal those of a single run."""
+    from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, _generator_uniform, _inpaint_state, _tables, get_schedule
+    from mars5_tts_amd.nar_engine import NARConfig, NARSession
+    fx = np.load(os.path.join(gold_dir, "nar_tiny_deep.npz"))
+    eng = _nar(tiny_bundle, torch.bfloat16, dev).engine()
+    T = 10
+    c_text, c_codes, x_l0 = torch.from_numpy(fx["c_text"]), torch.from_numpy(fx["c_codes"]), torch.from_numpy(fx["x_l0"])
+    dsh = DSH(x_0_temp=0.7, guidance_w=3, deep_clone=True, q0_override_steps=20)
+    diff = MultinomialDiffusion(1025, timesteps=200, device="cpu")
+    times = get_schedule(T, jump_n_sample=1, jump_len=1)[:-1]
+    outs, offs = [], []
+    for split in (None, 4):
+        g = torch.Generator(device=dev)
+        g.manual_seed(31)
+        xr, x_known, m, offset = _inpaint_state(_nar_batch_tuple(c_text, c_codes, x_l0), 1025, dsh, dev, None, g)
+        sess = NARSession(eng, NARConfig(T=T, x_0_temp=0.7, guidance_w=3.0, deep_clone=True, q0_override_steps=20), diff_tables=_tables(diff))
+        sess.prepare(c_text, c_codes.to(dev), xr, x_known, m, offset, times)
+        uni = _generator_uniform(dev, g)
+        if split is None:
+            x = sess.run(uni)
+        else:
+            sess.run(uni, n_steps=split)
+            mid = g.get_offset()
+            x = sess.run(uni, n_steps=len(times) - split)
+            assert mid < g.get_offset()
+        assert sess._ph is not None, "the generator-backed draw must take the in-graph path"
+        outs.append(x.clone().cpu())
+        offs.append(g.get_offset())
+    assert torch.equal(outs[0], outs[1]) and offs[0] == offs[1]
+
+
 def test_tts_stream_equals_sequential_seeded_calls(dev, tiny_bundle):
     """``tts_stream_from_codes`` (request i+1's AR decode overlapped with request i's NAR steps on two streams) must
     return, per request, exactly what ``torch.manual_seed(s_i); tts_from_codes(...)`` returns."""
