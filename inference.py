@@ -303,6 +303,15 @@ class Mars5TTS:
                                    spk_vec=h.nar_spk if h is not None else None, cond_from=h.cond.get(key) if h is not None else None,
                                    stream=streams[1] if streams else None)
         cache_cond = h is not None and key not in h.cond          # inserted only once the request has completed (below)
+        # The AR stage is ordered BEHIND the conditioning on the GPU (an event wait, the host does not block): the host prepares and
+        # enqueues the prefill while the conditioning runs, but the two stages' kernels never execute at the same time.  Round 5
+        # found out why that matters: until then a pageable host -> device copy at the END of prepare_cond had kept the host (and so
+        # the AR launches) waiting for the conditioning by accident; with the copy hoisted the fp32 engines' stages really ran
+        # concurrently on their two streams and the process aborted inside the ROCm runtime (tests/test_gpu_e2e.py::
+        # test_tts_entry_point_matches_reference_inference, deterministic; the fp32 GEMM kernels of both stages use scratch
+        # memory).  Pipelined serving (`streams` given) keeps its own ordering.
+        if streams is None and self.device.type == "cuda" and getattr(nar_sess, "cond_ready", None) is not None:
+            ops.session_stream(self.device, "ar").wait_event(nar_sess.cond_ready)
         ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
                                fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,
                                n_phones_gen=pr["n_phones_gen"], vocode=False, use_kv_cache=cfg.use_kv_cache, noise=ar_noise,

@@ -172,10 +172,15 @@ class ARSession:
         with torch.cuda.stream(self.stream):
             prompt = prompt.to(dev)
             ref_codes = ref_codes.to(dev).contiguous()
+            # Every host -> device copy of this function happens HERE, in front of the launches: a pageable copy blocks the host
+            # until the stream has executed it, i.e. until everything enqueued before it is done (the state words used to go last:
+            # the host then sat out the whole prefill before it could enqueue the first decode step).
+            self.tokens[:P].copy_(prompt)
+            self.state.copy_(torch.tensor([P, 0, 0, P, -1, 0, 0, 0], dtype=torch.int32, device="cpu"), non_blocking=False)
             # (D,) fp32; a cached vector of the same reference (Mars5TTS.prepare_reference) is the same tensor by construction
             spk = m.spk(ref_codes, stream=st) if spk_vec is None else spk_vec.to(dev)
             table = torch.cat([m.embed, spk[None]], dim=0)                       # plumbing: one extra row
-            idx = torch.cat([torch.tensor([s.n_vocab], device=dev, dtype=torch.int64), prompt])
+            idx = torch.cat([torch.full((1,), s.n_vocab, device=dev, dtype=torch.int64), prompt])      # (a device-side fill: no host copy)
             x = torch.empty(M, D, dtype=torch.float32, device=dev)
             ops.gather_rows(x, table, idx, stream=st)
             Mp = round_up(M, 64)
@@ -200,8 +205,6 @@ class ARSession:
                 ops.gemm(xn, m.w13[l], hb, L.EPI_SWIGLU, stream=st)
                 ops.gemm(hb, m.w2[l], x, L.EPI_RESIDUAL, stream=st)
             self.xdec.copy_(x[M - 1])
-            self.tokens[:P].copy_(prompt)
-            self.state.copy_(torch.tensor([P, 0, 0, P, -1, 0, 0, 0], dtype=torch.int32, device="cpu"), non_blocking=False)
             self.gran.zero_()                                  # granule tags are unique within one utterance only
             self.mega_err.zero_()
             self._keep = [table, x]

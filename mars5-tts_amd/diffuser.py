@@ -15,6 +15,17 @@ from .nar_engine import NARBatchSession, NARConfig, NARSession
 from .tables import diffusion_log_tables
 
 
+def _table_key(tensors) -> tuple:
+    """Identity of the four schedule tensors: object, storage and -- where torch tracks one (not for tensors made under
+    inference_mode) -- the in-place version counter."""
+    def ver(t):
+        try:
+            return t._version
+        except RuntimeError:
+            return -1
+    return tuple((id(t), t.data_ptr(), ver(t)) for t in tensors)
+
+
 class MultinomialDiffusion:
     def __init__(self, num_classes, timesteps=100, diffusion_s=0.008, loss_type='vb_stochastic', parametrization='x0',
                  dtype=torch.float32, device='cpu'):
@@ -29,6 +40,11 @@ class MultinomialDiffusion:
         self.log_1_min_alpha = l1ma.to(dtype).to(device)
         self.log_cumprod_alpha = lca.to(dtype).to(device)
         self.log_1_min_cumprod_alpha = l1mca.to(dtype).to(device)
+        # host copies of the four tables as they were made: the engine derives its per-step constants on the host, and reading
+        # the device tensors back cost four synchronising copies (6 ms) in front of every utterance's AR decode.  Used only
+        # while the attributes are still the tensors made here, unmodified (``_tables`` checks identity and version counters).
+        self._host_tables = tuple(t.to(dtype).to("cpu") for t in (la, l1ma, lca, l1mca))
+        self._host_key = _table_key((self.log_alpha, self.log_1_min_alpha, self.log_cumprod_alpha, self.log_1_min_cumprod_alpha))
 
 
 @dataclass
@@ -102,7 +118,11 @@ def _tables(diff) -> Optional[tuple]:
     diffuser.py:118-206), or None for the default schedule."""
     if diff is None:
         return None
-    return (diff.log_alpha, diff.log_1_min_alpha, diff.log_cumprod_alpha, diff.log_1_min_cumprod_alpha)
+    cur = (diff.log_alpha, diff.log_1_min_alpha, diff.log_cumprod_alpha, diff.log_1_min_cumprod_alpha)
+    host = getattr(diff, "_host_tables", None)
+    if host is not None and getattr(diff, "_host_key", None) == _table_key(cur):
+        return host                                    # the tables as constructed, already on the host (no device read-back)
+    return cur
 
 
 def _same_tables(a, b) -> bool:

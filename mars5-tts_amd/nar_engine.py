@@ -275,8 +275,13 @@ class NARSession:
         self.nb = nb
         self._enter()
         with torch.cuda.stream(self.stream):
+            # Every host -> device copy of this function happens HERE, in front of the launches: a pageable copy blocks the host
+            # until the stream has executed it -- behind the text encoder and the 16 K / V projections that used to be 6 ms in which
+            # the host could not prepare the AR stage (tools/host_profile.py).  (The caller orders the AR stream behind `cond_ready`:
+            # see inference._tts_core for why the two stages do not run concurrently.)
             c_text = c_text.to(dev)
             c_codes = c_codes.to(dev).contiguous()
+            self.consts = nar_step_consts(self.times, K, tables=self.diff_tables).to(dev)
             Lt = int(c_text.shape[0])
             Le = Lt + 1
             # -- speaker vectors (t-independent) and timestep MLPs for every scheduled t
@@ -288,7 +293,7 @@ class NARSession:
             # -- encoder input for every (step, cond/uncond): [spk, text] + pos + t_enc[step]
             table = torch.cat([mdl.text_embed] + [r[None] for r in rows], dim=0)
             nt = mdl.text_embed.shape[0]
-            one = torch.cat([torch.tensor([0], device=dev), c_text])                       # row 0 placeholder
+            one = torch.cat([torch.zeros(1, dtype=c_text.dtype, device=dev), c_text])      # row 0 placeholder (device-side fill: no host copy)
             idx = one[None, None, :].repeat(T, nb, 1)
             for b in range(nb):
                 idx[:, b, 0] = nt + b
@@ -324,7 +329,6 @@ class NARSession:
                                   vt_bs=H * 64 * Lep, vt_hs=64 * Lep, vt_ds=Lep)
                 ops.gemm(mem, lw.ca_kv_w, None, L.EPI_QKV, bias=lw.ca_kv_b, scatter=sc, stream=st)
                 self.mems.append(CrossMemory(k, vt, Le, Lep, nb))
-            self.consts = nar_step_consts(self.times, K, tables=self.diff_tables).to(dev)
             self._keep = [table, t_enc, mem]
             self.cond_ready = torch.cuda.Event()
             self.cond_ready.record(self.stream)
