@@ -276,6 +276,14 @@ class Mars5TTS:
         as ``tts_batch_from_codes``)."""
         n = len(texts)
         ar_stream, nar_stream = ops.session_stream(self.device, "ar"), ops.session_stream(self.device, "nar")
+        if torch.float32 in (self.codeclm.engine().dt, self.codecnar.engine().dt):
+            # The exact-fp32 parity engines' kernels use scratch memory, and two stages of them running at the same time on two
+            # streams abort inside the ROCm runtime (DESIGN.md 5, round 5): the fp32 mode is served request by request.
+            for i in range(n):
+                g = torch.Generator(device=self.device)
+                g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
+                yield self._tts_core(self._prompt(texts[i], prompt_codecs[i], ref_transcripts[i], cfg), cfg, None, g, None)
+            return
         pending = None
         for i in range(n):
             g = torch.Generator(device=self.device)
