@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor
 
+from mars5_tts_amd import _lib as _L
 from mars5_tts_amd import ops
 from mars5_tts_amd.ar_generate import ar_generate, ar_generate_batch
 from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, begin_inference, perform_batch_inference, perform_simple_inference
@@ -276,14 +277,6 @@ class Mars5TTS:
         as ``tts_batch_from_codes``)."""
         n = len(texts)
         ar_stream, nar_stream = ops.session_stream(self.device, "ar"), ops.session_stream(self.device, "nar")
-        if torch.float32 in (self.codeclm.engine().dt, self.codecnar.engine().dt):
-            # The exact-fp32 parity engines' kernels use scratch memory, and two stages of them running at the same time on two
-            # streams abort inside the ROCm runtime (DESIGN.md 5, round 5): the fp32 mode is served request by request.
-            for i in range(n):
-                g = torch.Generator(device=self.device)
-                g.manual_seed(int(seeds[i]) if seeds is not None else int(torch.randint(0, 2 ** 62, (1,)).item()))
-                yield self._tts_core(self._prompt(texts[i], prompt_codecs[i], ref_transcripts[i], cfg), cfg, None, g, None)
-            return
         pending = None
         for i in range(n):
             g = torch.Generator(device=self.device)
@@ -311,14 +304,16 @@ class Mars5TTS:
                                    spk_vec=h.nar_spk if h is not None else None, cond_from=h.cond.get(key) if h is not None else None,
                                    stream=streams[1] if streams else None)
         cache_cond = h is not None and key not in h.cond          # inserted only once the request has completed (below)
-        # The AR stage is ordered BEHIND the conditioning on the GPU (an event wait, the host does not block): the host prepares and
-        # enqueues the prefill while the conditioning runs, but the two stages' kernels never execute at the same time.  Round 5
-        # found out why that matters: until then a pageable host -> device copy at the END of prepare_cond had kept the host (and so
-        # the AR launches) waiting for the conditioning by accident; with the copy hoisted the fp32 engines' stages really ran
-        # concurrently on their two streams and the process aborted inside the ROCm runtime (tests/test_gpu_e2e.py::
-        # test_tts_entry_point_matches_reference_inference, deterministic; the fp32 GEMM kernels of both stages use scratch
-        # memory).  Pipelined serving (`streams` given) keeps its own ordering.
-        if streams is None and self.device.type == "cuda" and getattr(nar_sess, "cond_ready", None) is not None:
+        # The AR stage is ordered BEHIND the conditioning on the GPU (an event wait: the host does not block and enqueues the prefill
+        # while the conditioning runs).  History (round 5): until then a pageable host -> device copy at the END of prepare_cond had
+        # kept the host -- and so every AR launch -- waiting for the conditioning by accident.  With the copies hoisted the two stages
+        # really overlapped on their streams, and the fp32 `tts()` test died with a GPU memory fault: the text ids, a temporary of the
+        # CURRENT stream that this function drops as soon as begin_inference returns, were still to be gathered on the NAR stream when
+        # torch's caching allocator handed their block to the next allocation (fixed at the root: ops.use_on / record_stream on every
+        # tensor that crosses streams; tools/guard_tts_fp32.py reproduces it with M5_TTS_STAGE_ORDER=0 on the old tree).  The
+        # ordering stays because overlapping buys ~1 ms of 850 (the 5-6 ms of conditioning compete with the prefill for the same CUs).
+        if streams is None and self.device.type == "cuda" and getattr(nar_sess, "cond_ready", None) is not None and \
+                _L.tool_knob("M5_TTS_STAGE_ORDER", "1") != "0":      # (tools configuration: 0 = let the stages overlap, to reproduce that abort)
             ops.session_stream(self.device, "ar").wait_event(nar_sess.cond_ready)
         ar_codes = ar_generate(self.texttok, self.speechtok, self.codeclm, pr["prompt"], pr["spk_ref_codec"], pr["first_codec_idx"],
                                fp16=True if torch.cuda.is_available() else False, beam_width=cfg.beam_width, beam_length_penalty=1,

@@ -170,8 +170,9 @@ class ARSession:
         H, D, F = s.nhead, s.dim, s.hidden_dim
         self.stream.wait_stream(torch.cuda.current_stream(dev))       # prompt / ref_codes may have been produced there
         with torch.cuda.stream(self.stream):
-            prompt = prompt.to(dev)
-            ref_codes = ref_codes.to(dev).contiguous()
+            prompt = ops.use_on(prompt.to(dev), self.stream)
+            ref_codes = ops.use_on(ref_codes.to(dev).contiguous(), self.stream)
+            ops.use_on(spk_vec, self.stream)
             # Every host -> device copy of this function happens HERE, in front of the launches: a pageable copy blocks the host
             # until the stream has executed it, i.e. until everything enqueued before it is done (the state words used to go last:
             # the host then sat out the whole prefill before it could enqueue the first decode step).

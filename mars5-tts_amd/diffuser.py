@@ -82,8 +82,13 @@ def _inpaint_state(batch: tuple, K: int, dsh, dev, randint: Optional[Callable], 
     mode the reference codes prepended as fully known frames.  Returns (xr, x_known, m, offset)."""
     c_text, c_codes, c_text_lengths, c_codes_lengths, x, x_padding_mask = batch
     assert c_text.shape[0] == 1, "batch size 1 per call (the reference breaks for bs > 1, SURVEY App. B-9)"
+    cur = torch.cuda.current_stream(dev) if torch.device(dev).type == "cuda" else None      # the session's stream (the callers enter it)
     x = x.to(dev)
     c_codes = c_codes.to(dev)
+    if cur is not None:
+        from . import ops
+        ops.use_on(x, cur)
+        ops.use_on(c_codes, cur)
     assert int(x.max()) < K, f'Error: {int(x.max())} >= {K}'           # diffuser.py:36
     x_quant0 = x[0, :, 0].clone()
     if randint is None:

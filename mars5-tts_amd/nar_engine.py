@@ -237,9 +237,9 @@ class NARSession:
         dev = self.m.dev
         self._enter()
         with torch.cuda.stream(self.stream):
-            self.x = x.to(dev).contiguous().clone()
-            self.x_known = x_known.to(dev).contiguous()
-            self.m_mask = m_mask.to(device=dev, dtype=torch.uint8).contiguous()
+            self.x = ops.use_on(x.to(dev), self.stream).contiguous().clone()
+            self.x_known = ops.use_on(x_known.to(dev), self.stream).contiguous()
+            self.m_mask = ops.use_on(m_mask.to(device=dev), self.stream).to(dtype=torch.uint8).contiguous()
         self.S, self.row_offset = int(self.x.shape[0]), int(row_offset)
         self.s_out = self.S - self.row_offset
         assert self.S <= self.m.pe.shape[0]
@@ -279,8 +279,9 @@ class NARSession:
             # until the stream has executed it -- behind the text encoder and the 16 K / V projections that used to be 6 ms in which
             # the host could not prepare the AR stage (tools/host_profile.py).  (The caller orders the AR stream behind `cond_ready`:
             # see inference._tts_core for why the two stages do not run concurrently.)
-            c_text = c_text.to(dev)
-            c_codes = c_codes.to(dev).contiguous()
+            c_text = ops.use_on(c_text.to(dev), self.stream)
+            c_codes = ops.use_on(c_codes.to(dev).contiguous(), self.stream)
+            ops.use_on(spk_vec, self.stream)
             self.consts = nar_step_consts(self.times, K, tables=self.diff_tables).to(dev)
             Lt = int(c_text.shape[0])
             Le = Lt + 1

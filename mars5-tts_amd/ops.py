@@ -297,6 +297,17 @@ def clock_stamp(slots: torch.Tensor, i: int, stream: Optional[int] = None) -> No
     check(lib.m5_clock_stamp(slots.data_ptr() + 8 * i, _s(stream)), "m5_clock_stamp")
 
 
+def use_on(t: Optional[torch.Tensor], stream: torch.cuda.Stream) -> Optional[torch.Tensor]:
+    """`t` is about to be read by launches on `stream` although another stream's allocation may back it (a caller's temporary made on
+    the current stream and dropped as soon as the call returns): tell torch's caching allocator, which otherwise hands the block to
+    the next allocation of ITS stream while `stream` has not read it yet.  Round 5 found exactly that: the text ids of `tts()` -- a
+    temporary of the default stream, gathered on the NAR stream -- were overwritten once the host no longer waited for the
+    conditioning, and the gather read through garbage indices (a memory fault)."""
+    if t is not None and t.is_cuda:
+        t.record_stream(stream)
+    return t
+
+
 _SESSION_TLS = threading.local()      # per host thread: {(device index, role): stream}; the entries die with their thread
 
 
