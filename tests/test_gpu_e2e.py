@@ -502,6 +502,48 @@ def test_in_graph_uniforms_survive_a_run_split_in_two(dev, tiny_bundle, gold_dir
     assert torch.equal(outs[0], outs[1]) and offs[0] == offs[1]
 
 
+def test_tensors_that_cross_streams_are_recorded_on_the_consuming_stream(dev, tiny_bundle, monkeypatch):
+    """Round 5's GPU memory fault: `tts()` makes the text ids as a temporary of the CURRENT stream, `prepare_cond` gathers them on the
+    NAR stream and the caller drops them on return -- without ``Tensor.record_stream`` torch's caching allocator recycles the block
+    before the NAR stream has read it.  (i) the allocator contract ``ops.use_on`` relies on: a block recorded on a busy
+    stream is not handed out again; (ii) every entry point that consumes caller tensors on a session stream calls it."""
+    from inference import InferenceConfig
+    from mars5_tts_amd import ops, synth
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        torch.cuda._sleep(400_000_000)                      # keeps `side` busy for ~0.2 s
+    t = torch.arange(4096, device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        out = t * 2                                         # reads t behind the sleep
+    ops.use_on(t, side)
+    ptr = t.data_ptr()
+    del t
+    junk = torch.full((4096,), -1, dtype=torch.long, device=dev)      # same size, same (current) stream: would reuse the block
+    assert junk.data_ptr() != ptr, "the caching allocator recycled a block that a busy stream still has to read"
+    side.synchronize()
+    assert torch.equal(out, torch.arange(4096, device=dev) * 2)
+    # (ii) call sites
+    seen = []
+    real = ops.use_on
+
+    def spy(tensor, stream):
+        if tensor is not None and tensor.is_cuda:
+            seen.append((tuple(tensor.shape), tensor.dtype, stream))
+        return real(tensor, stream)
+    monkeypatch.setattr(ops, "use_on", spy)
+    m = _tiny_tts(tiny_bundle, dev, torch.bfloat16)
+    torch.manual_seed(5)
+    m.tts_from_codes("The quick brown rat.", synth.make_ref_codes(40, seed=7).to(dev), "We meet.",
+                     InferenceConfig(deep_clone=True, temperature=0.7, top_k=100, generate_max_len_override=120))
+    nar, ar = ops.session_stream(dev, "nar"), ops.session_stream(dev, "ar")
+    on_nar = [x for x in seen if x[2] is nar]
+    on_ar = [x for x in seen if x[2] is ar]
+    assert any(len(sh) == 1 and dt == torch.long for sh, dt, _ in on_nar), "prepare_cond must record the text ids on the NAR stream"
+    assert any(len(sh) == 2 and sh[1] == 8 for sh, dt, _ in on_nar), "the reference codes / inpainting state must be recorded on the NAR stream"
+    assert any(len(sh) == 1 and dt == torch.long for sh, dt, _ in on_ar), "prefill must record the prompt on the AR stream"
+
+
 def test_tts_stream_equals_sequential_seeded_calls(dev, tiny_bundle):
     """``tts_stream_from_codes`` (request i+1's AR decode overlapped with request i's NAR steps on two streams) must
     return, per request, exactly what ``torch.manual_seed(s_i); tts_from_codes(...)`` returns."""
