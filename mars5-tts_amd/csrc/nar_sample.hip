@@ -14,9 +14,12 @@ namespace {
 
 constexpr int MAXC = 17;   // K <= 64*17 = 1088
 
-__device__ inline float lae(float a, float b) {   // diffuser.py:22-24
-    const float mx = fmaxf(a, b);
-    return mx + logf(expf(a - mx) + expf(b - mx));
+__device__ inline float lae(float a, float b) {   // diffuser.py:22-24: max + log(exp(a - max) + exp(b - max))
+    // One of the two exponentials is exp(+0) = 1 exactly, and fp32 addition commutes, so exp(a - mx) + exp(b - mx) ==
+    // 1 + exp(min - mx) bit for bit: one libm expf per call instead of two (the kernel is bound by its transcendentals).
+    // (a = b = -inf: the reference computes exp(NaN) and returns NaN; min - mx is NaN here too.)
+    const float mx = fmaxf(a, b), mn = fminf(a, b);
+    return mx + logf(1.0f + expf(mn - mx));
 }
 __device__ inline float gumbel(float u) {          // diffuser.py:225-226
     return -logf(fmaxf(-logf(fmaxf(u, 1e-7f)), 1e-7f));

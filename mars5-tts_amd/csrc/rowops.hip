@@ -313,6 +313,31 @@ __global__ __launch_bounds__(256) void chunked_embed_kernel(float* out, int64_t 
     const int dq = D / n_q;
     const float al = alpha ? alpha[0] : 0.f;
     const float* ar = add ? add + (int64_t)(add_index ? add_index[0] : 0) * D : nullptr;
+    // vector form (round 5; the NAR step's embedding: D = 1024, 128 columns per codebook): four consecutive columns per thread --
+    // they share a codebook -- as float4 loads / stores; the same per-element arithmetic as the scalar loop below
+    if ((dq & 3) == 0 && (D & 3) == 0 && (ld_rep & 3) == 0 &&
+        ((((uintptr_t)out | (uintptr_t)tables | (uintptr_t)pe | (uintptr_t)add | (uintptr_t)lead_row) & 15) == 0)) {
+        for (int c = threadIdx.x * 4; c < D; c += 1024) {
+            float4 v;
+            if (r < lead) {
+                v = *reinterpret_cast<const float4*>(lead_row + c);
+            } else {
+                const int q = c / dq;
+                const int64_t code = codes[(int64_t)(r - lead) * n_q + q];
+                v = *reinterpret_cast<const float4*>(tables + ((int64_t)q * n_codes + code) * dq + (c - q * dq));
+            }
+            if (pe) {
+                const float4 p4 = *reinterpret_cast<const float4*>(pe + (int64_t)r * D + c);
+                v.x = v.x * 1.0f + al * p4.x; v.y = v.y * 1.0f + al * p4.y; v.z = v.z * 1.0f + al * p4.z; v.w = v.w * 1.0f + al * p4.w;
+            }
+            if (ar) {
+                const float4 a4 = *reinterpret_cast<const float4*>(ar + c);
+                v.x = v.x + a4.x; v.y = v.y + a4.y; v.z = v.z + a4.z; v.w = v.w + a4.w;
+            }
+            for (int rep = 0; rep < n_rep; ++rep) *reinterpret_cast<float4*>(out + rep * ld_rep + (int64_t)r * D + c) = v;
+        }
+        return;
+    }
     for (int c = threadIdx.x; c < D; c += 256) {
         float v;
         if (r < lead) {
