@@ -50,6 +50,12 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, lg = lane >> 4;
     const int nq = D / (4 * npart);                         // model-dimension columns per wave
     const int col0 = part * (D / npart);                    // first column of this workgroup
+    // output staging (round 5): with 64 columns per wave (the NAR geometry) a wave's output block is staged in its own LDS slice
+    // and stored as 16-byte row chunks; SROW = LDS row stride in elements (64 + 8: the 8-byte writes of a 16-lane group spread over banks)
+    constexpr int SROW = 72;
+    __shared__ __attribute__((aligned(16))) unsigned char stage_lds[4 * 64 * SROW * 2];
+    unsigned char* const stg = stage_lds + wave * (64 * SROW * 2);
+    const bool staged = nq == 64 && (((uintptr_t)ts[4] | (uintptr_t)ts[6]) & 15) == 0 && (D & 7) == 0;
     // memory rows of this head at this step: [Le][64], 16-bit
     const st* mem = reinterpret_cast<const st*>(which == 0 ? ts[0] : ts[1]) + stp * ts[3] + (int64_t)h * le * 64;
     uint4 mf[JT][2];                                        // fragments of the memory rows: row 16 jt + l15, k chunk 4 ks + lg
@@ -84,8 +90,20 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
                     st o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r] * scale);
-                    *reinterpret_cast<uint2*>(A + (int64_t)(jt * 16 + l15) * D + n0 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+                    if (staged) *reinterpret_cast<uint2*>(stg + ((jt * 16 + l15) * SROW + u * 16 + lg * 4) * 2) = *reinterpret_cast<const uint2*>(o);
+                    else *reinterpret_cast<uint2*>(A + (int64_t)(jt * 16 + l15) * D + n0 + lg * 4) = *reinterpret_cast<const uint2*>(o);
                 }
+            }
+        }
+        if (staged) {
+            // the wave's Lp rows x 64 columns leave as whole 128-byte rows, 16 bytes per lane (straight from the accumulator layout a
+            // store instruction wrote 16 rows x 32 bytes: 100 MB per step in 32-byte pieces)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int pass = 0; pass < Lp / 8; ++pass) {
+                const int row = pass * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + (row * SROW + ch * 8) * 2);
+                *reinterpret_cast<uint4*>(A + (int64_t)row * D + col0 + wave * nq + ch * 8) = v;
             }
         }
         // c[h Lp + j] = scale * K[j] . bq[h 64 ..]  (fp32);  padded keys: -1e30 (their softmax weight is exactly 0)
@@ -136,8 +154,20 @@ __global__ __launch_bounds__(256) void absorb_kernel(const int64_t* tab_seq, con
                     st o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = T::from_f32(acc[r]);
-                    *reinterpret_cast<uint2*>(Bt + (int64_t)(n0 + l15) * ldb + jt * 16 + lg * 4) = *reinterpret_cast<const uint2*>(o);
+                    if (staged) *reinterpret_cast<uint2*>(stg + ((u * 16 + l15) * SROW + jt * 16 + lg * 4) * 2) = *reinterpret_cast<const uint2*>(o);
+                    else *reinterpret_cast<uint2*>(Bt + (int64_t)(n0 + l15) * ldb + jt * 16 + lg * 4) = *reinterpret_cast<const uint2*>(o);
                 }
+            }
+        }
+        if (staged) {
+            // the wave's 64 rows x Lp columns leave as 16-byte chunks of whole Lp-column row segments
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            constexpr int CPR = Lp / 8;                         // 16-byte chunks per row
+#pragma unroll
+            for (int pass = 0; pass < CPR; ++pass) {
+                const int c = pass * 64 + lane, row = c / CPR, ch = c - row * CPR;
+                const uint4 v = *reinterpret_cast<const uint4*>(stg + (row * SROW + ch * 8) * 2);
+                *reinterpret_cast<uint4*>(Bt + (int64_t)(col0 + wave * nq + row) * ldb + ch * 8) = v;
             }
         }
     }
