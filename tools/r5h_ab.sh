@@ -1,4 +1,5 @@
 # whole-utterance A/B of one host-engine knob on one box, alternating (tools library: both sides run the same kernels)
+exec < /dev/null      # nothing in a gpurun script may wait on stdin (a `head` without a file name once held a box until the call limit)
 # usage: bash tools/r5h_ab.sh KNOB [tag]
 KNOB=${1:-M5_NAR_PHILOX}; TAG=${2:-r5h}
 mkdir -p gpurun_out/$TAG; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
 # absorb_kernel with LDS-staged 16-byte stores: parity tests + kernel stats of the single-request step (compare profiles/r5v)
+exec < /dev/null      # nothing in a gpurun script may wait on stdin (a `head` without a file name once held a box until the call limit)
 TAG=r5w; mkdir -p gpurun_out/$TAG; export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_parity16.py -m gpu -x -q -k "absorb or xattn or cross or nar" 2>&1 | tail -5 > gpurun_out/$TAG/tests.txt
 cat gpurun_out/$TAG/tests.txt
