@@ -59,6 +59,23 @@ def test_argument_validation_returns_status_codes():
         _lib.check(_lib.M5_ERR_UNSUPPORTED, "unit test")
 
 
+def test_every_compute_entry_point_rejects_null_arguments():
+    """All-null / all-zero arguments are an argument error at EVERY compute entry point of the product library, before anything is
+    launched (so the sweep runs without a GPU): a binding that passes a missing buffer gets a status, never a fault."""
+    from mars5_tts_amd import _lib as L
+    handles = {"m5_version", "m5_build_info", "m5_event_create", "m5_event_record", "m5_event_elapsed_ms", "m5_event_destroy",
+               "m5_graph_end", "m5_graph_launch", "m5_graph_destroy"}          # no buffers to validate / need a live handle
+    swept = 0
+    for name, (_, args) in L.PROTOTYPES.items():
+        if name in handles:
+            continue
+        vals = [0 if a in (C.c_int, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64) else (0.0 if a in (C.c_float, C.c_double) else None)
+                for a in args]
+        assert getattr(L.lib, name)(*vals) == L.M5_ERR_ARG, name
+        swept += 1
+    assert swept >= 27
+
+
 def test_persistent_decode_step_refuses_what_it_cannot_run():
     """m5_ar_layers_persistent validates before it touches the device: missing pointers are an argument error, any geometry
     but the CodecLM one (dim 1536, hidden 3584, 24 heads), fp32 operands or more than 31 layers are 'unsupported' -- the
