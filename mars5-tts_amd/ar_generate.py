@@ -66,7 +66,7 @@ def ar_generate(texttok, speechtok, codeclm, xx: Tensor, ss_gen: Tensor, first_c
             per_draw = gen.get_offset() - off0
             gen.set_offset(off0)
             # Round 5: the sampler generates each call's Exp(1) values itself, bit-identical to these exponential_ draws (torch's
-            # Philox4x32-10 launch geometry for V values: csrc/common.h, m5_torch_draw_bits) -- provided this torch build advances the
+            # Philox4x32-10 launch geometry for V values: csrc/philox.h, m5_torch_draw_bits) -- provided this torch build advances the
             # generator the way that geometry implies; otherwise (or M5_AR_PHILOX=0, tools A/B) the rows are drawn by torch, in
             # chunks just ahead of the graph replays that read them.
             prop = torch.cuda.get_device_properties(dev)

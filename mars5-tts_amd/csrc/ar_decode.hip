@@ -881,7 +881,7 @@ __global__ __launch_bounds__(1024) void sample_kernel(M5SampleArgs a, int V2) {
     const float S2 = block_sum<16>(part, red);
     const float logS = logf(S2);
     const float* q = a.noise ? a.noise + (int64_t)n_gen * a.noise_stride : nullptr;
-    // noise = NULL: the Exp(1) value of a kept token comes straight from torch's Philox stream for this sampler call (common.h)
+    // noise = NULL: the Exp(1) value of a kept token comes straight from torch's Philox stream for this sampler call (philox.h)
     const unsigned long long nseed = q ? 0ull : a.rng[0], noff = q ? 0ull : a.rng[1] + (unsigned long long)n_gen * a.noise_inc;
     float best = -1.f;
     int besti = 0x7fffffff;

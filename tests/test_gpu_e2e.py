@@ -633,7 +633,7 @@ def test_ar_generator_left_where_reference_leaves_it(dev, tiny_bundle):
 
 
 def test_ar_in_kernel_noise_equals_torch_exponential_rows(dev, tiny_bundle, gold_dir):
-    """The sampler's own Exp(1) values (M5SampleArgs.rng: torch's Philox stream for call i, csrc/common.h) against the same decode
+    """The sampler's own Exp(1) values (M5SampleArgs.rng: torch's Philox stream for call i, csrc/philox.h) against the same decode
     fed explicit rows drawn by ``Tensor.exponential_`` from an identically seeded generator (torch.multinomial's draw, reference
     ar_generate.py:115): identical tokens under a sampler setting where the draws decide (top_k 100, top_p 0.95, T 1.0), hipGraph
     and eager, and the generator is left one draw per executed loop iteration further on."""
