@@ -304,8 +304,9 @@ class Mars5TTS:
                                    spk_vec=h.nar_spk if h is not None else None, cond_from=h.cond.get(key) if h is not None else None,
                                    stream=streams[1] if streams else None)
         cache_cond = h is not None and key not in h.cond          # inserted only once the request has completed (below)
-        # The AR stage is ordered BEHIND the conditioning on the GPU (an event wait: the host does not block and enqueues the prefill
-        # while the conditioning runs).  History (round 5): until then a pageable host -> device copy at the END of prepare_cond had
+        # The AR stage is ordered BEHIND the conditioning on the GPU (an event wait on the AR stream).  The prefill's first operations
+        # are small blocking host -> device copies on that stream (ARSession.prefill: state words, prompt ids), so the host too waits
+        # for the conditioning there (~6 ms; it has nothing else to enqueue for this request).  History (round 5): until then a pageable host -> device copy at the END of prepare_cond had
         # kept the host -- and so every AR launch -- waiting for the conditioning by accident.  With the copies hoisted the two stages
         # really overlapped on their streams, and the fp32 `tts()` test died with a GPU memory fault: the text ids, a temporary of the
         # CURRENT stream that this function drops as soon as begin_inference returns, were still to be gathered on the NAR stream when

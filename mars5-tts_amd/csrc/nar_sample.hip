@@ -206,13 +206,14 @@ extern "C" int m5_nar_uniforms(const M5NarUniformArgs* a, void* stream) {
     if (!a || !a->out || !a->rng || a->n <= 0 || a->n >= (1ll << 32) || a->grid_threads == 0 || (a->grid_threads % 256) || (a->inc % 4)) return M5_ERR_ARG;
     if (a->m && (a->K <= 0 || !a->consts || !a->step)) return M5_ERR_ARG;
     if (a->transform != 0 && a->transform != 1) return M5_ERR_ARG;
-    if (a->m && a->k_magic) {                     // the multiply-shift must divide exactly over the whole range: checked at the row boundaries
-        const long long rows = (a->n + a->K - 1) / a->K;
-        for (long long r = 1; r <= rows; r += (rows > 64 ? rows / 64 : 1)) {
-            const unsigned long long lo = (unsigned long long)r * a->K - 1, hi = (unsigned long long)r * a->K;
-            if (lo < (1ull << 32) && (unsigned)((lo * a->k_magic) >> (32 + a->k_shift)) != (unsigned)(r - 1)) return M5_ERR_ARG;
-            if (hi < (1ull << 32) && hi < (unsigned long long)a->n && (unsigned)((hi * a->k_magic) >> (32 + a->k_shift)) != (unsigned)r) return M5_ERR_ARG;
-        }
+    if (a->inc == 0) return M5_ERR_ARG;           // (two draws at the same offset would be identical)
+    if (a->m && a->k_magic) {
+        // the multiply-shift must equal e / K for EVERY e < n: with m K = 2^(32+s) + r, r >= 0, (e m) >> (32+s) = floor(e / K + e r / (K 2^(32+s)))
+        // and the floor is unchanged iff e r < 2^(32+s) -- the closed-form bound, not a sample of row boundaries (a wrong magic would
+        // index m[] out of bounds)
+        if (a->k_shift > 31) return M5_ERR_ARG;
+        const unsigned __int128 one = (unsigned __int128)1 << (32 + a->k_shift), mk = (unsigned __int128)a->k_magic * (unsigned)a->K;
+        if (mk < one || (mk - one) * (unsigned __int128)(a->n - 1) >= one) return M5_ERR_ARG;
     }
     const long long G = a->grid_threads;
     const long long iters = (a->n + 4 * G - 1) / (4 * G);

@@ -15,15 +15,17 @@ from .nar_engine import NARBatchSession, NARConfig, NARSession
 from .tables import diffusion_log_tables
 
 
-def _table_key(tensors) -> tuple:
-    """Identity of the four schedule tensors: object, storage and -- where torch tracks one (not for tensors made under
-    inference_mode) -- the in-place version counter."""
-    def ver(t):
+def _table_key(tensors):
+    """Identity of the four schedule tensors: object, storage and the in-place version counter.  None when torch tracks no
+    version for one of them (tensors made under inference_mode): an in-place edit could then not be seen, so the caller
+    must not trust a host copy made earlier (None never compares equal to a key below)."""
+    key = []
+    for t in tensors:
         try:
-            return t._version
+            key.append((id(t), t.data_ptr(), t._version))
         except RuntimeError:
-            return -1
-    return tuple((id(t), t.data_ptr(), ver(t)) for t in tensors)
+            return None
+    return tuple(key)
 
 
 class MultinomialDiffusion:
@@ -125,7 +127,8 @@ def _tables(diff) -> Optional[tuple]:
         return None
     cur = (diff.log_alpha, diff.log_1_min_alpha, diff.log_cumprod_alpha, diff.log_1_min_cumprod_alpha)
     host = getattr(diff, "_host_tables", None)
-    if host is not None and getattr(diff, "_host_key", None) == _table_key(cur):
+    key = _table_key(cur)
+    if host is not None and key is not None and getattr(diff, "_host_key", None) == key:
         return host                                    # the tables as constructed, already on the host (no device read-back)
     return cur
 
@@ -224,7 +227,13 @@ def perform_batch_inference(model, batches: List[tuple], diff: MultinomialDiffus
     one batched decoder pass per reverse step over all of them (``NARBatchSession``).  Utterance i
     draws its random numbers from ``generators[i]`` in the order a lone call would (randint, then
     per step two rand), so result i equals ``perform_simple_inference(batches[i], generator=generators[i])``
-    whatever else is in the batch.  Returns a list of (1, S_i - offset_i, 8) int64 tensors; with `wait=False` the steps
+    whatever else is in the batch.  With ``generators=None`` (or the same generator given to several utterances) the draws of
+    the shared generator are bound per utterance, contiguously, in the engine's sorted utterance order -- all of utterance a's
+    steps, then utterance b's (since round 5, when the draws moved into the step graph) -- not interleaved step by step as
+    an eager loop would draw them: results are deterministic for a seed, but differ from the per-step interleaving; give every
+    utterance its own generator for placement-independent results.  A generator must not be shared between host THREADS
+    that run inference concurrently: each run reserves its range with a get_offset / set_offset pair (serialised by
+    nar_engine.GEN_LOCK for the NAR; the AR decode holds its range for the whole decode).  Returns a list of (1, S_i - offset_i, 8) int64 tensors; with `wait=False` the steps
     are only enqueued (on the session's own stream) and a callable that waits and returns that list comes back instead."""
     cfg = _nar_config(T, dsh, div_mode)
     eng = model.engine()

@@ -22,6 +22,7 @@ like the reference on the same device.
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional
 
@@ -144,7 +145,44 @@ def _build_cross_operands(plan, step_ptr: torch.Tensor, st: int) -> None:
             seg[1].build(step_ptr, st)
 
 
-_INC_CACHE: Dict[tuple, int] = {}          # (device index, n) -> generator offset one torch.rand of n floats consumes
+GEN_LOCK = threading.Lock()                # serialises the get_offset / set_offset pairs that reserve a generator range (PhiloxDraws.reserve, ar_generate)
+_PROBE_CACHE: Dict[tuple, bool] = {}       # (device index, n) -> m5_nar_uniforms reproduces torch.rand of n floats on this torch build
+
+
+def _philox_geometry(n: int, dev) -> tuple:
+    """(G, inc): threads of torch's `uniform_` launch for n floats on this device and the generator offset one draw consumes."""
+    prop = torch.cuda.get_device_properties(dev)
+    per_mp = max(int(getattr(prop, "max_threads_per_multi_processor", 2048)) // 256, 1)
+    G = 256 * min(int(prop.multi_processor_count) * per_mp, (n + 255) // 256)
+    return G, ((n - 1) // (4 * G) + 1) * 4
+
+
+def philox_matches_torch(n: int, dev) -> bool:
+    """Once per (device, n) and process: does m5_nar_uniforms reproduce `torch.rand(n)` on THIS torch / ROCm build?  Compared are
+    the VALUES of one draw (a private generator; m = NULL form = draw 1 everywhere) and the offset the draw consumes -- the
+    offset alone cannot tell launch widths apart (inc = ceil(n / 4G) * 4 is the same for many G, and always 4 when the draw fits
+    one grid pass).  False: the caller keeps the eager `torch.rand` path (same results, two ATen launches per step)."""
+    key = (torch.device(dev).index, n)
+    ok = _PROBE_CACHE.get(key)
+    if ok is None:
+        ok = False
+        try:
+            G, inc = _philox_geometry(n, dev)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(0x5EED5EED)
+            gen.set_offset(8)
+            ref = torch.empty(n, dtype=torch.float32, device=dev).uniform_(0.0, 1.0, generator=gen)
+            if int(gen.get_offset()) - 8 == inc:
+                out = torch.empty(n, dtype=torch.float32, device=dev)
+                rng = torch.tensor([0x5EED5EED, 8], dtype=torch.int64, device=dev)
+                a = L.NarUniformArgs(out=out.data_ptr(), n=n, K=1, k_magic=0, k_shift=0, m=None, rng=rng.data_ptr(), inc=inc, grid_threads=G,
+                                     step=None, consts=None)
+                ops.nar_uniforms(a, stream=torch.cuda.current_stream(dev).cuda_stream)
+                ok = bool(torch.equal(out, ref))
+        except Exception:          # an unsupported size / another generator implementation: the eager path serves it
+            ok = False
+        _PROBE_CACHE[key] = ok
+    return ok
 
 
 def _magic_div(d: int, n_max: int = 1 << 32) -> tuple:
@@ -169,21 +207,7 @@ class PhiloxDraws:
                  times: List[int], dev):
         assert all(t > 0 for t in times[:-1]), "only the last reverse step may have t = 0 (one draw)"
         self.gen, self.n = gen, S * n_q * K
-        prop = torch.cuda.get_device_properties(dev)
-        per_mp = max(int(getattr(prop, "max_threads_per_multi_processor", 2048)) // 256, 1)
-        self.grid_threads = 256 * min(int(prop.multi_processor_count) * per_mp, (self.n + 255) // 256)
-        self.inc = ((self.n - 1) // (4 * self.grid_threads) + 1) * 4
-        key = (torch.device(dev).index, self.n)
-        if key not in _INC_CACHE:
-            # once per shape and process: let torch itself say what one such draw consumes (guards the formula above against
-            # another torch build's launch geometry; tests/test_gpu_kernels.py compares the values themselves)
-            off = gen.get_offset()
-            torch.empty(self.n, dtype=torch.float32, device=dev).uniform_(0.0, 1.0, generator=gen)
-            _INC_CACHE[key] = int(gen.get_offset() - off)
-            gen.set_offset(off)
-        if _INC_CACHE[key] != self.inc:
-            raise RuntimeError(f"torch.rand of {self.n} floats advances the generator by {_INC_CACHE[key]}, not {self.inc}: "
-                               "this torch build uses another Philox launch geometry than m5_nar_uniforms reproduces")
+        self.grid_threads, self.inc = _philox_geometry(self.n, dev)
         self.buf = torch.empty(S, n_q, K, dtype=torch.float32, device=dev)
         self.rng = torch.zeros(2, dtype=torch.int64, device=dev)             # {seed, offset0}: read by the kernel, so the step graph outlives a run
         km, ks = _magic_div(K, self.n)
@@ -196,10 +220,11 @@ class PhiloxDraws:
         past their draws (two per step, one at t = 0).  Stream-ordered: the state words reach the device behind whatever the
         stream already holds (an earlier run's steps)."""
         wrap = lambda v: v - (1 << 64) if v >= (1 << 63) else v                 # noqa: E731  (uint64 bit pattern in an int64 tensor)
-        seed, off = int(self.gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF, int(self.gen.get_offset())
+        with GEN_LOCK:        # get_offset / set_offset is not atomic: two host threads sharing a generator must not bind overlapping ranges
+            seed, off = int(self.gen.initial_seed()) & 0xFFFFFFFFFFFFFFFF, int(self.gen.get_offset())
+            self.gen.set_offset(off + sum(2 if t > 0 else 1 for t in times) * self.inc)
         with torch.cuda.stream(stream):
             self.rng.copy_(torch.tensor([wrap(seed), wrap((off - 2 * first_step * self.inc) & 0xFFFFFFFFFFFFFFFF)], dtype=torch.int64), non_blocking=True)
-        self.gen.set_offset(off + sum(2 if t > 0 else 1 for t in times) * self.inc)
 
     def enqueue(self, st: int) -> None:
         ops.nar_uniforms(self.args, stream=st)
@@ -516,6 +541,8 @@ class NARSession:
         if ph is None or ph.gen is not gen:
             s = self.m.shape
             with torch.cuda.stream(self.stream):
+                if not philox_matches_torch(self.S * s.n_codebooks * s.n_quant, self.m.dev):
+                    return None                     # another torch build's launch geometry: the eager torch.rand path serves it
                 ph = self._ph = PhiloxDraws(gen, self.S, s.n_codebooks, s.n_quant, self.m_mask, self.consts, self.step_ptr, self.times, self.m.dev)
             self.graph_step = None
         return ph
@@ -764,6 +791,8 @@ class NARBatchSession:
         if phs is None or any(p.gen is not d.gen for p, d in zip(phs, draws)):
             s = self.m.shape
             with torch.cuda.stream(self.stream):
+                if not all(philox_matches_torch(sub.S * s.n_codebooks * s.n_quant, self.m.dev) for sub in self.subs):
+                    return None
                 phs = self._phs = [PhiloxDraws(d.gen, sub.S, s.n_codebooks, s.n_quant, sub.m_mask, sub.consts, self.step_ptr, self.times, self.m.dev)
                                    for d, sub in zip(draws, self.subs)]
             self.graph_step = None
