@@ -29,7 +29,7 @@ def tool_knob(name: str, default: str) -> str:
 
 
 M5_OK, M5_ERR_ARG, M5_ERR_LAUNCH, M5_ERR_UNSUPPORTED = 0, -1, -2, -3
-F32, F16, BF16 = 0, 1, 2
+F32, F16, BF16, F32X3 = 0, 1, 2, 3
 EPI_F32, EPI_DT, EPI_RESIDUAL, EPI_SWIGLU, EPI_QKV, EPI_SILU_DT = 0, 1, 2, 3, 4, 5
 ST_POS, ST_NGEN, ST_DONE, ST_NTOK, ST_LAST, ST_WORDS = 0, 1, 2, 3, 4, 8
 PRO_RMS, PRO_DT, PRO_ATTN = 0, 1, 2

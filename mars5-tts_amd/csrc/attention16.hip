@@ -59,7 +59,8 @@ constexpr int STAGE_B = 2 * TILE_B;              // K tile + V^T tile
 constexpr int NST = 3;
 
 // VARIANT: 0 = product kernel; 1..3 = timing ablations (WRONG results; M5_ATTN_VARIANT, tools only):
-// 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.
+// 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.  4 (round 6 probe, correct results): s_setprio 1 around the
+// two MFMA clusters of a tile (cdna_hip_programming.md T5: arbitration between the co-resident waves of a SIMD).
 template <typename T, int NWAVE, int VARIANT, int KH = 1>
 __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p) {
     using st = typename T::storage;
@@ -168,6 +169,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
 
     // S^T = K . Q^T of one tile: s[kb][8 m + j] = score(key 64 kt + 32 kb + 16 m + 8 hh + j, query l31)
     auto qk_tile = [&](const unsigned char* sb, f16_t (&s)[NKB]) {
+        if (VARIANT == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
                 s[kb] = mfma32<T>(a, qf[ds], s[kb]);
             }
         }
+        if (VARIANT == 4) __builtin_amdgcn_s_setprio(0);
     };
     // softmax of tile kt (scores in `s`, overwritten by the probabilities) and O^T += V^T . P^T
     auto softmax_pv = [&](const unsigned char* sb, int kt, f16_t (&s)[NKB]) {
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         }
+        if (VARIANT == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
                     oacc[db] = mfma32<T>(a, pb, oacc[db]);
                 }
             }
+        if (VARIANT == 4) __builtin_amdgcn_s_setprio(0);
     };
 
     // ---- key loop, software-pipelined across tiles: the S^T MFMAs of tile kt+1 are issued BEFORE
@@ -359,10 +364,11 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
         M5_A16(BF16T, 2, 0);
     } else if (nw == 8) {
         M5_A16(BF16T, 8, 0);
-    } else if (var >= 1 && var <= 3) {          // timing ablations, results are WRONG by construction
+    } else if (var >= 1 && var <= 4) {          // timing ablations (1-3: results are WRONG by construction) and probes
         switch (var) {
             case 1: M5_A16(BF16T, 4, 1); break;
             case 2: M5_A16(BF16T, 4, 2); break;
+            case 4: M5_A16(BF16T, 4, 4); break;
             default: M5_A16(BF16T, 4, 3); break;
         }
 #endif

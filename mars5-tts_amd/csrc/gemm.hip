@@ -43,11 +43,41 @@ __device__ inline f4_t mfma16<BF16T>(const uint4& a, const uint4& b, f4_t c) {
                                                    *reinterpret_cast<const b8_t*>(&b), c, 0, 0, 0);
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+// ---- X3: fp32 operands, products on the f16 matrix pipe at fp32-grade accuracy ("f16 x 3").
+// Every fp32 operand x is split when its slab is staged into LDS:  hi = f16(x) (11 significant bits, round to nearest),
+// lo = f16((x - hi) * 2^11) (the next 11 bits, pre-scaled into f16's normal range), so x = hi + lo 2^-11 up to 2^-22 |x|.
+// a w = hi_a hi_w + 2^-11 (hi_a lo_w + lo_a hi_w) + O(2^-22 a w): three v_mfma_f32_16x16x32_f16 per fragment pair -- the f16
+// products are exact in fp32 (11 x 11 bits) and accumulate in fp32; the two cross terms share a second accumulator that is
+// scaled by 2^-11 once, behind the K loop.  48 MFMAs of 16 pipe cycles per 32-deep slab and wave against 128 MFMAs of 32
+// cycles for v_mfma_f32_16x16x4_f32: the matrix pipe does the slab in a fifth of the time, with the operand error (2^-22
+// relative, random sign) at the level of fp32 rounding noise of a K = 1024 dot product.  NOT bitwise an fmaf chain: this is
+// the fast parity-grade mode (dtype M5_F32X3), the exact kernel stays the reference instrument (M5_F32).
+// Range.  f16 spans 2^-14 .. 65504 with full precision; the operands are pre-scaled by exact powers of two (activations x 2^4,
+// weights x 2^8, undone behind the K loop) so that the 22-bit representation holds for |a| in 3.8e-6 .. 4094 and |w| in
+// 2.4e-7 .. 255 -- LayerNorm outputs, attention outputs, SwiGLU products and weight matrices with room on both sides.  Smaller
+// operands lose significance gradually (hi = 0 below the range: the conversions run with f16 denormals flushed, MODE.fp_denorm,
+// so no denormal ever reaches the matrix pipe; the value survives in lo with 11 bits, absolute error below 2^-37 for
+// activations); LARGER ones overflow to inf / NaN visibly -- use M5_F32 for such data.
+constexpr float X3_SA = 16.0f, X3_SW = 256.0f;
+__device__ inline void x3_split(const uint4& v, float scale, uint2& hi, uint2& lo) {
+    const float x[4] = {__uint_as_float(v.x) * scale, __uint_as_float(v.y) * scale, __uint_as_float(v.z) * scale, __uint_as_float(v.w) * scale};
+    _Float16 h[4], l[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h[r] = (_Float16)x[r];
+        l[r] = (_Float16)((x[r] - (float)h[r]) * 2048.0f);
+    }
+    hi = *reinterpret_cast<const uint2*>(h);
+    lo = *reinterpret_cast<const uint2*>(l);
+}
+
+template <typename T, int EPI, bool X3 = false>
+__global__ __launch_bounds__(256, X3 ? 2 : 1) void gemm_kernel(GemmParams p) {
     using st = typename T::storage;
     constexpr int ES = sizeof(st);
     constexpr int BK = 128 / ES;
+    static_assert(!X3 || ES == 4, "X3: fp32 operands");
+    if constexpr (X3) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11) /* hwreg(HW_REG_MODE, offset 6, width 2): FP_DENORM of f16 / f64 */, 0);   // flush f16 denormals in the conversions
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * ROWB];
     unsigned char* As = lds;
     unsigned char* Ws = lds + 128 * ROWB;
@@ -79,6 +109,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
+    f4_t accc[X3 ? 4 : 1][X3 ? 4 : 1];                 // X3: the cross terms hi lo + lo hi (scaled by 2^-11 at the end)
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) accc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // stage one register slab into LDS.  X3: a row's 32 floats become 32 hi halves (bytes 0..63) + 32 lo halves (64..127)
+    auto stage_write = [&](const uint4 (&qa)[4], const uint4 (&qw)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (X3) {
+                uint2 h, l;
+                x3_split(qa[j], X3_SA, h, l);
+                *reinterpret_cast<uint2*>(As + (r0 + 32 * j) * ROWB + chunk * 8) = h;
+                *reinterpret_cast<uint2*>(As + (r0 + 32 * j) * ROWB + 64 + chunk * 8) = l;
+                x3_split(qw[j], X3_SW, h, l);
+                *reinterpret_cast<uint2*>(Ws + (r0 + 32 * j) * ROWB + chunk * 8) = h;
+                *reinterpret_cast<uint2*>(Ws + (r0 + 32 * j) * ROWB + 64 + chunk * 8) = l;
+            } else {
+                *reinterpret_cast<uint4*>(As + lds_st + 32 * j * ROWB) = qa[j];
+                *reinterpret_cast<uint4*>(Ws + lds_st + 32 * j * ROWB) = qw[j];
+            }
+        }
+    };
+
     uint4 ra[4], rw[4];
     const int nk = p.K / BK;
 #pragma unroll
@@ -86,11 +142,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         ra[j] = *reinterpret_cast<const uint4*>(ga[j]);
         rw[j] = *reinterpret_cast<const uint4*>(gw[j]);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        *reinterpret_cast<uint4*>(As + lds_st + 32 * j * ROWB) = ra[j];
-        *reinterpret_cast<uint4*>(Ws + lds_st + 32 * j * ROWB) = rw[j];
-    }
+    stage_write(ra, rw);
     __syncthreads();
 
     const unsigned char* a_base = As + (wm * 64 + l15) * ROWB;
@@ -106,7 +158,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 rw[j] = *reinterpret_cast<const uint4*>(gw[j] + koff);
             }
         }
-        if constexpr (ES == 2) {
+        if constexpr (X3) {
+            uint4 ahi[4], alo[4], whi[4], wlo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ahi[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * ROWB + lg * 16);
+                alo[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * ROWB + 64 + lg * 16);
+                whi[i] = *reinterpret_cast<const uint4*>(w_base + i * 16 * ROWB + lg * 16);
+                wlo[i] = *reinterpret_cast<const uint4*>(w_base + i * 16 * ROWB + 64 + lg * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] = mfma16<F16T>(ahi[i], whi[j], acc[i][j]);
+                    accc[i][j] = mfma16<F16T>(ahi[i], wlo[j], accc[i][j]);
+                    accc[i][j] = mfma16<F16T>(alo[i], whi[j], accc[i][j]);
+                }
+        } else if constexpr (ES == 2) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 uint4 af[4], bf[4];
@@ -140,13 +209,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         }
         __syncthreads();
         if (more) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                *reinterpret_cast<uint4*>(As + lds_st + 32 * j * ROWB) = ra[j];
-                *reinterpret_cast<uint4*>(Ws + lds_st + 32 * j * ROWB) = rw[j];
-            }
+            stage_write(ra, rw);
             __syncthreads();
         }
+    }
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + accc[i][j][r] * (1.0f / 2048.0f)) * (1.0f / (X3_SA * X3_SW));
     }
 
     // ---- epilogue: acc[i][j][r] is C[row = m0+wm*64+i*16+lg*4+r][col = n0+wn*64+j*16+l15]
@@ -206,15 +279,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 int launch_gemm(int epi, const GemmParams& p, dim3 grid, hipStream_t s) {
     switch (epi) {
-        case M5_EPI_F32: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_F32>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_DT>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_RESIDUAL>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_SWIGLU: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SWIGLU>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_QKV>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_SILU_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SILU_DT>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_F32: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_F32, X3>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_DT, X3>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_RESIDUAL, X3>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_SWIGLU: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SWIGLU, X3>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_QKV, X3>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_SILU_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SILU_DT, X3>), grid, dim3(256), 0, s, p); break;
         default: return M5_ERR_ARG;
     }
     M5_CHECK_LAUNCH();
@@ -241,7 +314,7 @@ extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int
                        int batch, int64_t sA, int64_t sW, int64_t sC, int64_t sBias, void* stream) {
     if (!A || !W || M <= 0 || N <= 0 || K <= 0 || batch <= 0) return M5_ERR_ARG;
     if (K % 64 != 0) return M5_ERR_UNSUPPORTED;
-    const int es = (dtype == M5_F32) ? 4 : 2;
+    const int es = (dtype == M5_F32 || dtype == M5_F32X3) ? 4 : 2;
     const int al = 16 / es;
     if (lda % al || ldw % al || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) return M5_ERR_ARG;
     if ((sA % al) || (sW % al)) return M5_ERR_ARG;
@@ -265,12 +338,13 @@ extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int
     hipStream_t s = (hipStream_t)stream;
     if (m5_gemm_skinny_fits(dtype, M, N, K, epi, batch, lda, ldw))          // batched decode step: M <= 32 rows
         return m5_gemm_skinny_dispatch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, s);
-    if (dtype != M5_F32 && !use_v1_gemm())
+    if (dtype != M5_F32 && dtype != M5_F32X3 && !use_v1_gemm())
         return m5_gemm16_dispatch(dtype, A, lda, W, ldw, bias, C, ldc, M, N, K, epi, epi == M5_EPI_QKV ? &p.sc : nullptr,
                                   p.sec_kind, batch, sA, sW, sC, sBias, s);
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     switch (dtype) {
         case M5_F32: return launch_gemm<F32T>(epi, p, grid, s);
+        case M5_F32X3: return launch_gemm<F32T, true>(epi, p, grid, s);
         case M5_F16: return launch_gemm<F16T>(epi, p, grid, s);
         case M5_BF16: return launch_gemm<BF16T>(epi, p, grid, s);
         default: return M5_ERR_ARG;

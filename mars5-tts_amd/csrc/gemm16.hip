@@ -1400,9 +1400,10 @@ constexpr bool fast_ok(int E, int WM, int WN, int TM, int TN, int BKB, int NSTAG
 
 // Deferred-LayerNorm instantiations (DLN = 1: residual producer; DLN = 2: QKV / SwiGLU consumers) exist for the tilings the
 // engines' shapes use (DLNC: bit 0 = producer, bit 1 = consumers); anything else answers M5_ERR_UNSUPPORTED.
-template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, int DLNC = 0>
+template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, int DLNC = 0, int ONLY = -1>
 int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = false, int dln = 0) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    if (ONLY >= 0 && epi != ONLY) return M5_ERR_UNSUPPORTED;        // a tiling instantiated for one epilogue only (compile time)
     if (dln) {
         if (!fast) return M5_ERR_UNSUPPORTED;
         p.tilesM = (p.M + BM - 1) / BM; p.tilesN = (p.N + BN - 1) / BN;
@@ -1452,6 +1453,9 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = fal
         }                                                                                                                  \
         hipLaunchKernelGGL((gemm16_kernel<T, E, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, false>), grid, blk, 0, s, p);        \
     } while (0)
+    if constexpr (ONLY == M5_EPI_RESIDUAL) {
+        M5_G16(M5_EPI_RESIDUAL);
+    } else {
     switch (epi) {
         case M5_EPI_F32: M5_G16(M5_EPI_F32); break;
         case M5_EPI_DT: M5_G16(M5_EPI_DT); break;
@@ -1460,6 +1464,7 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = fal
         case M5_EPI_QKV: M5_G16(M5_EPI_QKV); break;
         case M5_EPI_SILU_DT: M5_G16(M5_EPI_SILU_DT); break;
         default: return M5_ERR_ARG;
+    }
     }
 #undef M5_G16
     M5_CHECK_LAUNCH();
@@ -1482,6 +1487,8 @@ static const CfgInfo kCfg[] = {
     {192, 384, 6, 1, 8.f, 2.10f, -2},             // 9 (tools build, round-4 probe): = 5 with 32-deep K-steps and 4 stages (same 144 KB: three
                                                   //    half-steps of DMA in flight instead of one whole step)
     {192, 192, 4, 1, 7.f, 1.20f, -2},             // 10 (tools build): = 2 with 32-deep K-steps and 6 stages
+    { 96, 128, 2, 1, 8.f, 0.48f, -2},             // 11 (round 6): region 96x128 with EIGHT waves (2x4 of 48x32), 4 stages, one workgroup per CU:
+                                                  //    two waves per SIMD for the residual class (K loop overlap + twice the waves in the C burst)
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -1497,6 +1504,7 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool
         case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s, fast, dln);
         case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true, 1>(epi, p, batch, s, fast, dln);
         case 8: return launch16<T, 2, 2, 3, 4, 128, 5, 1, true>(epi, p, batch, s, fast, dln);
+        case 11: return launch16<T, 2, 4, 3, 2, 128, 4, 1, false, 1, M5_EPI_RESIDUAL>(epi, p, batch, s, fast, dln);
 #ifdef M5_TOOLS
         case 9: return launch16<T, 4, 4, 3, 6, 64, 4, 1>(epi, p, batch, s, fast, dln);
         case 10: return launch16<T, 4, 3, 3, 4, 64, 6, 1>(epi, p, batch, s, fast, dln);

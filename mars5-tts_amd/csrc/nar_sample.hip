@@ -46,14 +46,46 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
             // log_add_exp(one_hot_log + c4, c5) takes only two values per row: evaluate each once
             // (same arithmetic per element as the reference, just not 1025 times)
             const float q_hit = lae(0.f + c4, c5), q_miss = lae(a.log_eps + c4, c5);
-            float best = -INFINITY;
-            int bi = 0x7fffffff;
+            // v_k = gumbel(u_k) + (k == x_known ? q_hit : q_miss), arg-max with the first index on ties.  Among the K - 1 "miss"
+            // classes the constant is the same and gumbel is non-decreasing in u, so only each lane's LARGEST u (first index on
+            // equal u) can win: 64 candidates + the hit class get the two logf, not 1025 (this branch is 71 % of the rows and the
+            // kernel is bound by its transcendentals).  Exactness: a non-candidate could only win by TYING in v with a larger u
+            // at a lower index; for u >= 0.9 adjacent floats u are >= 6 ulps apart in v (|dv/du| >= 10, libm logf <= 1 ulp), so
+            // distinct u give distinct v there.  The row's largest u is below 0.9 with probability 0.9^1025 ~ 1e-47; the plain
+            // loop over every class is kept for that case (wave-uniform branch).
+            float ub = -1.f, uh = 0.f;
+            int ui = 0x7fffffff;
+            bool has_hit = false;
+            float uu[MAXC];
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int k = lane + 64 * i;
+                uu[i] = (k < K) ? u2[k] : -1.f;
+            }
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int k = lane + 64 * i;
                 if (k < K) {
-                    const float v = gumbel(u2[k]) + ((k == (int)xk) ? q_hit : q_miss);
-                    if (v > best) { best = v; bi = k; }
+                    if (k == (int)xk) { has_hit = true; uh = uu[i]; }
+                    else if (uu[i] > ub) { ub = uu[i]; ui = k; }        // ascending k: the first index of equal u stays
+                }
+            }
+            float best = -INFINITY;
+            int bi = 0x7fffffff;
+            if (wave_max(ub) >= 0.9f) {
+                if (ui != 0x7fffffff) { best = gumbel(ub) + q_miss; bi = ui; }
+                if (has_hit) {
+                    const float vh = gumbel(uh) + q_hit;
+                    if (vh > best || (vh == best && (int)xk < bi)) { best = vh; bi = (int)xk; }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int k = lane + 64 * i;
+                    if (k < K) {
+                        const float v = gumbel(uu[i]) + ((k == (int)xk) ? q_hit : q_miss);
+                        if (v > best) { best = v; bi = k; }
+                    }
                 }
             }
 #pragma unroll

@@ -15,6 +15,28 @@ from ._lib import check, lib
 
 DT_CODE = {torch.float32: L.F32, torch.float16: L.F16, torch.bfloat16: L.BF16}
 CODE_DT = {v: k for k, v in DT_CODE.items()}
+
+# How the fp32 engines multiply (process-wide; read when a launch is ENQUEUED, so a captured graph keeps the mode it was
+# captured with): "exact" = v_mfma_f32_16x16x4_f32, bitwise an fmaf chain -- the reference instrument; "f16x3" = the same fp32
+# operands split into two f16 halves on the fly and three f16 MFMAs per product (csrc/gemm.hip, M5_F32X3): fp32-grade results
+# (operand error 2^-22) at several times the rate -- the fast parity-grade mode.  Set with set_f32_products().
+_F32_PRODUCTS = "exact"
+
+
+def set_f32_products(mode: str) -> str:
+    """Select the fp32 engines' GEMM arithmetic ("exact" | "f16x3"); returns the previous mode."""
+    global _F32_PRODUCTS
+    assert mode in ("exact", "f16x3"), mode
+    prev, _F32_PRODUCTS = _F32_PRODUCTS, mode
+    return prev
+
+
+def f32_products() -> str:
+    return _F32_PRODUCTS
+
+
+def _gemm_code(dt: torch.dtype) -> int:
+    return L.F32X3 if (dt == torch.float32 and _F32_PRODUCTS == "f16x3") else DT_CODE[dt]
 DT_NAME = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
 
 
@@ -44,7 +66,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], epi: int
     if bias is not None:
         assert bias.dtype == torch.float32
     ld = ldc if ldc is not None else (out.stride(-2) if out is not None else 0)
-    check(lib.m5_gemm(DT_CODE[a.dtype], _p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(out), ld, Mv, N, K, epi,
+    check(lib.m5_gemm(_gemm_code(a.dtype), _p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(out), ld, Mv, N, K, epi,
                       C.byref(scatter) if scatter is not None else None, batch, sA, sW, sC, sBias, _s(stream)), "m5_gemm")
 
 

@@ -61,6 +61,36 @@ def test_gemm_epilogues(dev, dt, M, N, K):
     assert _rel(out3.float().cpu(), torch.nn.functional.silu(ref)) < max(TOL[dt], 8e-3 if dt != torch.float32 else 0)
 
 
+@pytest.mark.parametrize("M,N,K,scale", [(300, 260, 1024, 1.0), (129, 200, 3072, 1.0), (257, 129, 64, 1.0), (200, 256, 1024, 3e-5), (130, 140, 512, 900.0)])
+def test_gemm_f32_split_f16_products(dev, M, N, K, scale):
+    """M5_F32X3 (csrc/gemm.hip "X3"): fp32 operands multiplied as three split-f16 MFMA terms.  Against a float64 product of
+    the same fp32 operands its error must stay at fp32 level -- within 4x the exact fp32-MFMA kernel's own error (which is
+    accumulation-order noise) and below 2e-6 of max |ref| -- over every epilogue the fp32 engines use; small (3e-5)
+    and large (900) activations included (the operands are pre-scaled into f16's normal range, csrc/gemm.hip)."""
+    from mars5_tts_amd import _lib as L, ops
+    a, w, b = _rand((M, K), 11) * scale, _rand((N, K), 12), _rand((N,), 13) * scale
+    ref = (a.double() @ w.double().T + b.double())
+    ad, wd, bd = a.to(dev), w.to(dev), b.to(dev)
+    outs = {}
+    for mode in ("exact", "f16x3"):
+        prev = ops.set_f32_products(mode)
+        try:
+            o = torch.zeros(M, N, device=dev)
+            ops.gemm(ad, wd, o, L.EPI_F32, bias=bd)
+            res = (_rand((M, N), 14) * scale).to(dev)
+            res0 = res.clone()
+            ops.gemm(ad, wd, res, L.EPI_RESIDUAL, bias=bd)
+            torch.cuda.synchronize()
+            outs[mode] = (o.cpu(), (res - res0).cpu())
+        finally:
+            ops.set_f32_products(prev)
+    e_exact, e_x3 = _rel(outs["exact"][0], ref), _rel(outs["f16x3"][0], ref)
+    print(f"f32 GEMM {M}x{N}x{K} scale {scale}: rel err vs float64 exact-MFMA {e_exact:.2e}, split-f16 {e_x3:.2e}")
+    assert e_x3 < 2e-6 and e_x3 < max(4 * e_exact, 5e-7)
+    assert _rel(outs["f16x3"][1], ref) < 4e-6            # (the residual difference re-rounds against the old C)
+    # transposition / operand-order check on an asymmetric case is implied by the float64 comparison above
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("K", [64, 128, 192, 256, 320, 384, 512, 1024, 3072])
 def test_gemm_prefetched_fragment_loop_every_pipeline_depth(dev, dt, K):
@@ -1064,6 +1094,74 @@ def test_nar_sample_vs_oracle(dev):
         total_bad += n_mis
         assert not bad, f"t={t}: ids differ from the oracle away from any tie: {bad[:5]}"
     print(f"nar_sample: {total_bad} tie-excused mismatching ids over {len(times) * S * Q}")
+
+
+def test_nar_sample_known_rows_crafted_uniforms(dev):
+    """The known-row branch (q_sample) evaluates the Gumbel score only for each lane's largest uniform and for the hit class
+    (csrc/nar_sample.hip).  Crafted draws exercise what random ones never do: the largest uniform of a row duplicated at
+    several indices (same lane: k and k + 64; other lanes; at the hit class), rows whose largest uniform is below the 0.9 guard
+    (the plain all-classes loop), and the top float below 1.  Every id must equal a plain fp32 evaluation of all 1025 classes
+    with the first index winning ties (diffuser.py:219-236)."""
+    from mars5_tts_amd import _lib as L, ops
+    from mars5_tts_amd.tables import log_eps, nar_step_consts
+    S, Q, K = 48, 8, 1025
+    g = torch.Generator().manual_seed(23)
+    times = [150, 1]
+    consts = nar_step_consts(times, K).to(dev)
+    x_known = torch.randint(0, K, (S, Q), generator=g)
+    u = torch.rand(S, Q, K, generator=g)
+    rows = u.view(S * Q, K)
+    xk = x_known.view(-1)
+    top = torch.nextafter(torch.tensor(1.0), torch.tensor(0.0)).item()
+    for r in range(S * Q):
+        mode = r % 8
+        k0 = int(torch.randint(0, K - 200, (1,), generator=g))
+        if mode == 0:
+            rows[r] *= 0.85                                   # below the guard: the all-classes loop
+        elif mode == 1:
+            rows[r, k0] = rows[r, k0 + 64] = 0.99993          # the row maximum twice in ONE lane
+        elif mode == 2:
+            rows[r, k0 + 5] = rows[r, k0 + 70] = rows[r, k0 + 133] = 0.99991    # and across lanes
+        elif mode == 3:
+            rows[r, int(xk[r])] = 0.99995                     # the hit class holds the maximum
+            rows[r, (int(xk[r]) + 64) % K] = 0.99995          # ... tied with a miss class of its lane
+        elif mode == 4:
+            rows[r, k0] = top                                 # the largest float below 1 (the clamp of -log u)
+            rows[r, k0 + 1] = top
+        elif mode == 5:
+            rows[r, 0] = 0.0                                  # torch's 1.0 -> 0.0 reversal value at index 0
+    m = torch.ones(S, Q, dtype=torch.uint8)
+    lg = torch.zeros(1, Q - 1, 1028)
+    for si, t in enumerate(times):
+        c = consts[si].cpu()
+        c4, c5 = float(c[4]), float(c[5])
+        f32 = lambda v: torch.tensor(v, dtype=torch.float32)       # noqa: E731
+        lae = lambda a, b: torch.maximum(a, b) + torch.log(torch.exp(a - torch.maximum(a, b)) + torch.exp(b - torch.maximum(a, b)))   # noqa: E731
+        q_hit, q_miss = lae(f32(0.0) + f32(c4), f32(c5)), lae(f32(log_eps()) + f32(c4), f32(c5))
+        gum = -torch.log(torch.clamp(-torch.log(torch.clamp(rows, min=1e-7)), min=1e-7))
+        score = gum + q_miss
+        score[torch.arange(S * Q), xk] = gum[torch.arange(S * Q), xk] + q_hit
+        ref = score.argmax(dim=1)                                   # torch.argmax: first index of the maximum
+        best = score.max(dim=1).values
+        first = (score == best[:, None]).float().argmax(dim=1)
+        assert torch.equal(ref, first)
+        xd = torch.zeros(S, Q, dtype=torch.int64, device=dev)
+        keep = [lg.to(dev), x_known.to(dev), m.to(dev), u.to(dev)]
+        step = torch.tensor([si], dtype=torch.int32, device=dev)
+        a = L.NarSampleArgs(logits_c=keep[0].data_ptr(), logits_u=keep[0].data_ptr(), ld_row=(Q - 1) * 1028, ld_q=1028, S=S, n_q=Q, K=K,
+                            row_offset=S, x=xd.data_ptr(), x_known=keep[1].data_ptr(), m=keep[2].data_ptr(), u1=keep[3].data_ptr(),
+                            u2=keep[3].data_ptr(), consts=consts.data_ptr(), step=step.data_ptr(), guidance_w=3.0, temperature=0.7,
+                            log_eps=log_eps(), div_mode=0, q0_override_steps=1000)     # (no L0 override: every row reports its own draw)
+        ops.nar_sample(a)
+        torch.cuda.synchronize()
+        got = xd.cpu().view(-1)
+        diff = (got != ref).nonzero().view(-1)
+        # the CPU libm and the device libm may round log differently: a differing id is accepted only between classes whose
+        # reference scores are within 2 ulp of each other
+        for r in diff.tolist():
+            a_, b_ = float(score[r, got[r]]), float(score[r, ref[r]])
+            assert abs(a_ - b_) <= 2 * abs(b_) * 2 ** -23, (t, r, r % 8, int(got[r]), int(ref[r]), a_, b_)
+        print(f"known rows, t={t}: {len(diff)} ids differ within 2 ulp of a tie, of {S * Q}")
 
 
 def test_nar_uniforms_equal_torch_rand(dev):

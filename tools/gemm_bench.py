@@ -117,6 +117,7 @@ CASES = [
     ("nar l0 qkv", 1408, 3072, 1024, L.EPI_QKV, True, 1408),        # layer 0's shared self-attention block: one branch
     ("nar out_proj", 2816, 1024, 1024, L.EPI_RESIDUAL, True, None),
     ("nar cross q", 2816, 1024, 1024, L.EPI_QKV, True, 1408),
+    ("nar p.b", 2816, 1024, 768, L.EPI_RESIDUAL, True, None),            # absorbed cross-attention: P . B with the residual epilogue
     ("nar swiglu", 2816, 6144, 1024, L.EPI_SWIGLU, False, None),
     ("nar linear2", 2816, 1024, 3072, L.EPI_RESIDUAL, True, None),
     ("nar head (1 of 7)", 1798, 1025, 1024, L.EPI_F32, True, None),
