@@ -155,6 +155,12 @@ def parse():
     ap.add_argument("--check-bundle", action="store_true", help="with --launch-check: also build the (tiny) synthetic checkpoint on rank 0 and "
                     "map it on the other ranks, as the N-rank runs do with the full one")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend (nccl = RCCL on the GPU box)")
+    ap.add_argument("--same-device", action="store_true", help="--launch-check with more ranks than visible GPUs: rank r uses device r %% device_count "
+                    "(two RCCL ranks on one GPU, if the library accepts that; tests only)")
+    ap.add_argument("--collective-at-1", action="store_true",
+                    help="c4 under a launcher with WORLD_SIZE=1: still initialise the process group and send the requests / results through the "
+                         "scatter / gather / census collectives (RCCL init, device-tensor scatter and gather, /dev/shm bundle path on ONE GPU: what "
+                         "a 1-GPU box can prove about the multi-GPU path; tests/test_gpu_e2e.py)")
     return ap.parse_args()
 
 
@@ -166,7 +172,7 @@ def self_launch(args) -> int:
     import subprocess
     if args.backend == "nccl":
         n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if n_dev < args.gpus:
+        if n_dev < args.gpus and not (args.same_device and args.launch_check and n_dev >= 1):
             print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible on this node; refusing to run", file=sys.stderr, flush=True)
             return 2
     with socket.socket() as sk:
@@ -184,7 +190,8 @@ def launch_check(args, world: int, rank: int) -> None:
     import torch.distributed as dist
     from mars5_tts_amd import sharding as sh
     if args.backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(lr % max(torch.cuda.device_count(), 1) if args.same_device else lr)
     if world > 1:
         dist.init_process_group(backend=args.backend)
         census = sh.rank_census()
@@ -482,8 +489,10 @@ def main_c4(args, m, dev, world, rank, barrier):
     work = request_worker(m, cfg)
     bwork = None if args.c4_per_request else request_batch_worker(m, cfg, args.nar_batch, args.nar_in_flight)
 
+    coll = world > 1 or bool(getattr(args, "coll", False))       # --collective-at-1: one rank, the collectives still run
+
     def step():
-        if world > 1:
+        if coll:
             return sh.run_sharded(reqs if rank == 0 else None, n_total, work, src=0, batch_worker=bwork)
         if bwork is not None:
             return bwork(reqs)
@@ -501,14 +510,15 @@ def main_c4(args, m, dev, world, rank, barrier):
     frames = float(sum(int(o.shape[0]) for o in outs)) * args.steps if rank == 0 else 0.0
     collective = None
     checked_local = None
-    if world == 1 and bwork is not None:          # one rank: the group results against lone seeded calls of two requests
+    if world == 1 and bwork is not None and not coll:          # one rank: the group results against lone seeded calls of two requests
         checked_local = verify_remote(m, cfg, reqs, set(), outs, k=2)
-    if world > 1:
+    if coll:
         elapsed, frames = sh.reduce_timing(elapsed, frames)
         census = sh.rank_census()
         parts = sh.lpt_partition([sh.estimate_cost(r) for r in reqs], world)
         if rank == 0:
-            checked = verify_remote(m, cfg, reqs, set(parts[0]), outs, k=2)
+            # (one rank: nothing ran elsewhere -- re-run two of its own requests alone instead)
+            checked = verify_remote(m, cfg, reqs, set(parts[0]) if world > 1 else set(), outs, k=2)
             collective = dict(backend=sh.LAST_STATS.get("backend"), ranks_seen=sh.LAST_STATS.get("ranks_seen"), census=census,
                               scatter_bytes=sh.LAST_STATS.get("scatter_bytes"), gather_bytes=sh.LAST_STATS.get("gather_bytes"),
                               remote_results_rechecked_equal=checked, requests_per_rank=[len(p) for p in parts])
@@ -525,7 +535,7 @@ def main_c4(args, m, dev, world, rank, barrier):
                                + ", results gathered on rank 0; "
                                f"reference 150-900 frames, {args.n_gen} generated frames each, temperature=0.7 top_k=100, 200 DDPM steps x CFG",
                    "requests_per_step": n_total, "reference_frames_min_mean_max": [min(ref_frames), round(sum(ref_frames) / len(ref_frames), 1), max(ref_frames)],
-                   "parallelism": f"replicas x{world}, request scatter + result gather over {'RCCL' if world > 1 else 'nothing (single rank)'}"},
+                   "parallelism": f"replicas x{world}, request scatter + result gather over {('RCCL' if args.backend == 'nccl' else args.backend) if coll else 'nothing (single rank)'}"},
         "collective": collective, "group_results_rechecked_against_lone_calls": checked_local,
     }
     print(json.dumps(out), flush=True)
@@ -1030,7 +1040,9 @@ def main():
             sys.exit(3)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    coll = world > 1 or (args.collective_at_1 and args.workload == "c4" and "WORLD_SIZE" in os.environ)
+    args.coll = coll
+    if coll:
         import torch.distributed as dist
         dist.init_process_group(backend=args.backend, device_id=dev)
     from mars5_tts_amd import synth
@@ -1056,13 +1068,13 @@ def main():
         ne.NARSession.run = lambda self, uniform, use_graph=True, n_steps=None: _r(self, uniform, False, n_steps)
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize()
 
     if args.workload in ("c3", "c4"):
         (main_c3 if args.workload == "c3" else main_c4)(args, m, dev, world, rank, barrier)
-        if world > 1:
+        if coll:
             dist.destroy_process_group()
         return
 

@@ -13,7 +13,7 @@
  * dtype codes select the GEMM/attention OPERAND type; accumulation is always fp32 and the
  * residual stream is always fp32:  M5_F32 = exact-fp32 parity mode (reference CPU/NAR
  * numerics), M5_F16 = reference GPU autocast numerics (ar_generate.py:67), M5_BF16 =
- * BASELINE.json config.  M5_F32X3 (m5_gemm only): fp32 operands in memory exactly as for
+ * BASELINE.json config.  M5_F32X3 (m5_gemm, m5_attention): fp32 operands in memory exactly as for
  * M5_F32, products on the f16 matrix pipe as three split-operand terms (x = hi + lo 2^-11):
  * operand error 2^-22 relative, i.e. fp32-grade results at several times the fp32 matrix
  * rate, NOT bitwise an fmaf chain; |A| < 4094, |W| < 255 or the result is inf / NaN

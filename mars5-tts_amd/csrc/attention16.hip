@@ -59,8 +59,8 @@ constexpr int STAGE_B = 2 * TILE_B;              // K tile + V^T tile
 constexpr int NST = 3;
 
 // VARIANT: 0 = product kernel; 1..3 = timing ablations (WRONG results; M5_ATTN_VARIANT, tools only):
-// 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.  4 (round 6 probe, correct results): s_setprio 1 around the
-// two MFMA clusters of a tile (cdna_hip_programming.md T5: arbitration between the co-resident waves of a SIMD).
+// 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax VALU.  4 (round-6 probe, correct results): s_setprio 1 around the
+// two MFMA clusters of a tile (cdna_hip_programming.md T5) -- measured 1.5-4 % SLOWER (profiles/r6a_attn_setprio_negative.txt).
 template <typename T, int NWAVE, int VARIANT, int KH = 1>
 __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(M5AttnArgs p) {
     using st = typename T::storage;

@@ -71,81 +71,88 @@ __device__ inline void x3_split(const uint4& v, float scale, uint2& hi, uint2& l
     lo = *reinterpret_cast<const uint2*>(l);
 }
 
-template <typename T, int EPI, bool X3 = false>
-__global__ __launch_bounds__(256, X3 ? 2 : 1) void gemm_kernel(GemmParams p) {
+// TMW = 16-row MFMA tiles per wave along M: 4 (tile 128 x 128) or -- X3 only -- 2 (tile 64 x 128, three workgroups per CU: the
+// N = 1024 GEMMs of a 2816-row NAR step are 176 tiles of 128 x 128 on 256 CUs, 352 of 64 x 128).
+template <typename T, int EPI, bool X3 = false, int TMW = 4>
+__global__ __launch_bounds__(256, X3 ? (TMW == 2 ? 3 : 2) : 1) void gemm_kernel(GemmParams p) {
     using st = typename T::storage;
     constexpr int ES = sizeof(st);
     constexpr int BK = 128 / ES;
+    constexpr int BMK = 2 * TMW * 16;             // rows of the workgroup tile (2 waves along M)
+    constexpr int NPA = BMK / 32;                 // staging passes over the A rows (32 rows per pass)
     static_assert(!X3 || ES == 4, "X3: fp32 operands");
+    static_assert(TMW == 4 || (X3 && TMW == 2), "64-row tiles: X3 only");
     if constexpr (X3) __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11) /* hwreg(HW_REG_MODE, offset 6, width 2): FP_DENORM of f16 / f64 */, 0);   // flush f16 denormals in the conversions
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 128 * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[(BMK + 128) * ROWB];
     unsigned char* As = lds;
-    unsigned char* Ws = lds + 128 * ROWB;
+    unsigned char* Ws = lds + BMK * ROWB;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, lg = lane >> 4;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int m0 = blockIdx.y * BMK, n0 = blockIdx.x * BN;
     const int64_t bz = blockIdx.z;
     const unsigned char* A = p.A + bz * p.sA * ES;
     const unsigned char* W = p.W + bz * p.sW * ES;
 
-    // staging assignment: 8 threads cover one 128-byte row slab, 32 rows per pass, 4 passes
+    // staging assignment: 8 threads cover one 128-byte row slab, 32 rows per pass
     const int chunk = tid & 7, r0 = tid >> 3;
-    const unsigned char* ga[4];
+    const unsigned char* ga[NPA];
     const unsigned char* gw[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        int ra = min(m0 + r0 + 32 * j, p.M - 1);
-        int rw = min(n0 + r0 + 32 * j, p.N - 1);
-        ga[j] = A + (int64_t)ra * p.lda * ES + chunk * 16;
-        gw[j] = W + (int64_t)rw * p.ldw * ES + chunk * 16;
-    }
+    for (int j = 0; j < NPA; ++j) ga[j] = A + (int64_t)min(m0 + r0 + 32 * j, p.M - 1) * p.lda * ES + chunk * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) gw[j] = W + (int64_t)min(n0 + r0 + 32 * j, p.N - 1) * p.ldw * ES + chunk * 16;
     const int lds_st = r0 * ROWB + chunk * 16;
 
-    f4_t acc[4][4];
+    f4_t acc[TMW][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    f4_t accc[X3 ? 4 : 1][X3 ? 4 : 1];                 // X3: the cross terms hi lo + lo hi (scaled by 2^-11 at the end)
+    f4_t accc[X3 ? TMW : 1][X3 ? 4 : 1];               // X3: the cross terms hi lo + lo hi (scaled by 2^-11 at the end)
     if constexpr (X3) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) accc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
     }
     // stage one register slab into LDS.  X3: a row's 32 floats become 32 hi halves (bytes 0..63) + 32 lo halves (64..127)
-    auto stage_write = [&](const uint4 (&qa)[4], const uint4 (&qw)[4]) {
+    auto stage_write = [&](const uint4 (&qa)[NPA], const uint4 (&qw)[4]) {
+        if constexpr (X3) {
+            uint2 h, l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (X3) {
-                uint2 h, l;
+            for (int j = 0; j < NPA; ++j) {
                 x3_split(qa[j], X3_SA, h, l);
                 *reinterpret_cast<uint2*>(As + (r0 + 32 * j) * ROWB + chunk * 8) = h;
                 *reinterpret_cast<uint2*>(As + (r0 + 32 * j) * ROWB + 64 + chunk * 8) = l;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 x3_split(qw[j], X3_SW, h, l);
                 *reinterpret_cast<uint2*>(Ws + (r0 + 32 * j) * ROWB + chunk * 8) = h;
                 *reinterpret_cast<uint2*>(Ws + (r0 + 32 * j) * ROWB + 64 + chunk * 8) = l;
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
                 *reinterpret_cast<uint4*>(As + lds_st + 32 * j * ROWB) = qa[j];
                 *reinterpret_cast<uint4*>(Ws + lds_st + 32 * j * ROWB) = qw[j];
             }
         }
     };
 
-    uint4 ra[4], rw[4];
+    uint4 ra[NPA], rw[4];
     const int nk = p.K / BK;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        ra[j] = *reinterpret_cast<const uint4*>(ga[j]);
-        rw[j] = *reinterpret_cast<const uint4*>(gw[j]);
-    }
+    for (int j = 0; j < NPA; ++j) ra[j] = *reinterpret_cast<const uint4*>(ga[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const uint4*>(gw[j]);
     stage_write(ra, rw);
     __syncthreads();
 
-    const unsigned char* a_base = As + (wm * 64 + l15) * ROWB;
+    const unsigned char* a_base = As + (wm * TMW * 16 + l15) * ROWB;
     const unsigned char* w_base = Ws + (wn * 64 + l15) * ROWB;
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -153,22 +160,24 @@ __global__ __launch_bounds__(256, X3 ? 2 : 1) void gemm_kernel(GemmParams p) {
         if (more) {
             const int64_t koff = (int64_t)(kt + 1) * 128;   // bytes
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ra[j] = *reinterpret_cast<const uint4*>(ga[j] + koff);
-                rw[j] = *reinterpret_cast<const uint4*>(gw[j] + koff);
-            }
+            for (int j = 0; j < NPA; ++j) ra[j] = *reinterpret_cast<const uint4*>(ga[j] + koff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rw[j] = *reinterpret_cast<const uint4*>(gw[j] + koff);
         }
         if constexpr (X3) {
-            uint4 ahi[4], alo[4], whi[4], wlo[4];
+            uint4 ahi[TMW], alo[TMW], whi[4], wlo[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < TMW; ++i) {
                 ahi[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * ROWB + lg * 16);
                 alo[i] = *reinterpret_cast<const uint4*>(a_base + i * 16 * ROWB + 64 + lg * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
                 whi[i] = *reinterpret_cast<const uint4*>(w_base + i * 16 * ROWB + lg * 16);
                 wlo[i] = *reinterpret_cast<const uint4*>(w_base + i * 16 * ROWB + 64 + lg * 16);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     acc[i][j] = mfma16<F16T>(ahi[i], whi[j], acc[i][j]);
@@ -215,14 +224,14 @@ __global__ __launch_bounds__(256, X3 ? 2 : 1) void gemm_kernel(GemmParams p) {
     }
     if constexpr (X3) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TMW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = (acc[i][j][r] + accc[i][j][r] * (1.0f / 2048.0f)) * (1.0f / (X3_SA * X3_SW));
     }
 
-    // ---- epilogue: acc[i][j][r] is C[row = m0+wm*64+i*16+lg*4+r][col = n0+wn*64+j*16+l15]
+    // ---- epilogue: acc[i][j][r] is C[row = m0+wm*TMW*16+i*16+lg*4+r][col = n0+wn*64+j*16+l15]
     const float* bias = p.bias ? p.bias + bz * p.sBias : nullptr;
     unsigned char* Cb = p.C + bz * p.sC * ((EPI == M5_EPI_F32 || EPI == M5_EPI_RESIDUAL) ? 4 : ES);
     const int Dm = p.sc.n_heads * p.sc.head_dim;
@@ -241,10 +250,10 @@ __global__ __launch_bounds__(256, X3 ? 2 : 1) void gemm_kernel(GemmParams p) {
             dd = c % p.sc.head_dim;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TMW; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
+                const int row = m0 + wm * TMW * 16 + i * 16 + lg * 4 + r;
                 const bool ok = cok && row < p.M;
                 const float v = acc[i][j][r] + bv;
                 if constexpr (EPI == M5_EPI_F32) {
@@ -279,15 +288,15 @@ __global__ __launch_bounds__(256, X3 ? 2 : 1) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <typename T, bool X3 = false>
+template <typename T, bool X3 = false, int TMW = 4>
 int launch_gemm(int epi, const GemmParams& p, dim3 grid, hipStream_t s) {
     switch (epi) {
-        case M5_EPI_F32: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_F32, X3>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_DT, X3>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_RESIDUAL, X3>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_SWIGLU: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SWIGLU, X3>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_QKV, X3>), grid, dim3(256), 0, s, p); break;
-        case M5_EPI_SILU_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SILU_DT, X3>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_F32: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_F32, X3, TMW>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_DT, X3, TMW>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_RESIDUAL, X3, TMW>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_SWIGLU: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SWIGLU, X3, TMW>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_QKV, X3, TMW>), grid, dim3(256), 0, s, p); break;
+        case M5_EPI_SILU_DT: hipLaunchKernelGGL((gemm_kernel<T, M5_EPI_SILU_DT, X3, TMW>), grid, dim3(256), 0, s, p); break;
         default: return M5_ERR_ARG;
     }
     M5_CHECK_LAUNCH();
@@ -344,7 +353,13 @@ extern "C" int m5_gemm(int dtype, const void* A, int64_t lda, const void* W, int
     dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, batch);
     switch (dtype) {
         case M5_F32: return launch_gemm<F32T>(epi, p, grid, s);
-        case M5_F32X3: return launch_gemm<F32T, true>(epi, p, grid, s);
+        case M5_F32X3: {
+            // 64-row tiles (three workgroups per CU) when 128-row tiles would leave the machine short of two full rounds of workgroups
+            int bm = ((int64_t)grid.x * grid.y * grid.z < 2 * 512) ? 64 : 128;
+            if (const char* e = m5_tool_env("M5_X3_BM")) bm = atoi(e);                  // same-process A/B (tools build)
+            if (bm == 64) return launch_gemm<F32T, true, 2>(epi, p, dim3((N + BN - 1) / BN, (M + 63) / 64, batch), s);
+            return launch_gemm<F32T, true>(epi, p, grid, s);
+        }
         case M5_F16: return launch_gemm<F16T>(epi, p, grid, s);
         case M5_BF16: return launch_gemm<BF16T>(epi, p, grid, s);
         default: return M5_ERR_ARG;

@@ -1198,6 +1198,16 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                         acc[i][j] = f4_t{xc[0], xc[1], xc[2], xc[3]};             // the deferred LayerNorm's operand, before rounding
                     }
                 }
+#ifdef M5_DLN_STORE_FIRST      // round-6 probe (tools/r6b.sh): the fp32 tile leaves FIRST, the LDS staging of the centred copy runs under its drain
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = mw + i * 16 + l15;
+                    float* rp = Cf + (int64_t)row * p.ldc;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        if (row < p.M) *reinterpret_cast<float4*>(rp + nw + j * 16 + lg * 4) = oldpre[i][j];
+                }
+#endif
                 // the centred copy leaves through the (dead) stage buffers as whole 16-byte row chunks (straight from the
                 // accumulator layout a store instruction writes 16 rows x 32 bytes: measured +4 us per launch)
                 constexpr int RBX = TN * 32 + 16;                                 // padded LDS row: TN*16 columns of 2 bytes
@@ -1252,6 +1262,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                         if (row < p.M) p.dl_cen_out[bz * p.dl_rows_bs + row] = dl_cen[i];
                     }
                 }
+#ifndef M5_DLN_STORE_FIRST
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = mw + i * 16 + l15;
@@ -1260,6 +1271,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     for (int j = 0; j < TN; ++j)
                         if (row < p.M) *reinterpret_cast<float4*>(rp + nw + j * 16 + lg * 4) = oldpre[i][j];
                 }
+#endif
                 return;
             }
 #pragma unroll
@@ -1487,8 +1499,9 @@ static const CfgInfo kCfg[] = {
     {192, 384, 6, 1, 8.f, 2.10f, -2},             // 9 (tools build, round-4 probe): = 5 with 32-deep K-steps and 4 stages (same 144 KB: three
                                                   //    half-steps of DMA in flight instead of one whole step)
     {192, 192, 4, 1, 7.f, 1.20f, -2},             // 10 (tools build): = 2 with 32-deep K-steps and 6 stages
-    { 96, 128, 2, 1, 8.f, 0.48f, -2},             // 11 (round 6): region 96x128 with EIGHT waves (2x4 of 48x32), 4 stages, one workgroup per CU:
-                                                  //    two waves per SIMD for the residual class (K loop overlap + twice the waves in the C burst)
+    { 96, 128, 2, 1, 8.f, 0.48f, -2},             // 11 (tools build, round-6 probe): region 96x128 with EIGHT waves (2x4 of 48x32), 4 stages, one workgroup
+                                                  //    per CU -- two waves per SIMD for the residual class.  Measured SLOWER than cfg 7 on every shape
+                                                  //    (profiles/r6a_gemm_8wave_residual_region_negative.txt): 16.8 -> 18.4, 14.6 -> 16.0, 31.3 -> 37.1 us
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -1504,8 +1517,8 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool
         case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s, fast, dln);
         case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true, 1>(epi, p, batch, s, fast, dln);
         case 8: return launch16<T, 2, 2, 3, 4, 128, 5, 1, true>(epi, p, batch, s, fast, dln);
-        case 11: return launch16<T, 2, 4, 3, 2, 128, 4, 1, false, 1, M5_EPI_RESIDUAL>(epi, p, batch, s, fast, dln);
 #ifdef M5_TOOLS
+        case 11: return launch16<T, 2, 4, 3, 2, 128, 4, 1, false, 1, M5_EPI_RESIDUAL>(epi, p, batch, s, fast, dln);
         case 9: return launch16<T, 4, 4, 3, 6, 64, 4, 1>(epi, p, batch, s, fast, dln);
         case 10: return launch16<T, 4, 3, 3, 4, 64, 6, 1>(epi, p, batch, s, fast, dln);
 #endif

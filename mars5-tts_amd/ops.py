@@ -183,7 +183,7 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: torch.Tensor, str
 
 
 def attention(dtype: torch.dtype, args: L.AttnArgs, stream: Optional[int] = None) -> None:
-    check(lib.m5_attention(DT_CODE[dtype], C.byref(args), _s(stream)), "m5_attention")
+    check(lib.m5_attention(_gemm_code(dtype), C.byref(args), _s(stream)), "m5_attention")
 
 
 def gather_rows(out: torch.Tensor, table: torch.Tensor, idx: torch.Tensor, alpha: Optional[torch.Tensor] = None,

@@ -2,6 +2,7 @@
 (``ar_generate`` / ``perform_simple_inference``): HIP path vs golden fixtures produced by the
 unmodified reference, and vs the CPU oracle on the same seeded inputs."""
 import io
+import json
 import os
 
 import numpy as np
@@ -871,3 +872,51 @@ def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle)
             assert wav.shape[-1] == fx[f"wav_{i}"].shape[-1]
             d = wav.cpu() - torch.from_numpy(fx[f"wav_{i}"])        # the stand-in vocoder's sin() runs on the GPU here, on the CPU there
             assert float(d.pow(2).mean().sqrt()) < 1e-4 and float(d.abs().max()) < 1e-4      # BASELINE: waveform RMS within 1e-4
+
+
+# ------------------------------------------------------------------ the multi-GPU path on ONE GPU
+def _bench_cmd(extra, nproc):
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py")] + extra
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+
+
+def test_c4_request_scatter_and_gather_run_over_rccl_with_one_rank(dev):
+    """What a 1-GPU box can prove about BASELINE configs[3]: `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1
+    --workload c4 --batch 4 --backend nccl --collective-at-1` -- RCCL communicator init, the request scatter and result gather
+    on DEVICE tensors (sharding.scatter_requests / gather_results), the timing all-reduces, the rank census, and rank 0's
+    re-computation of two gathered results, all through bench.py's own c4 path with the real engines."""
+    r = _bench_cmd(["--gpus", "1", "--workload", "c4", "--batch", "4", "--backend", "nccl", "--collective-at-1", "--steps", "1", "--warmup", "0",
+                    "--n-gen", "90", "--no-preflight"], 1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    c = j["collective"]
+    print("c4 over RCCL, one rank:", {k: c[k] for k in ("backend", "ranks_seen", "scatter_bytes", "gather_bytes", "remote_results_rechecked_equal")}, j["value"])
+    assert c["backend"] == "nccl" and c["ranks_seen"] == 1 and c["requests_per_rank"] == [4]
+    assert c["scatter_bytes"] > 4 * 8 * 150 and c["gather_bytes"] > 4 * 8 * 90 and c["remote_results_rechecked_equal"] == 2
+    assert j["n_gpus"] == 1 and j["value"] > 0
+
+
+def test_two_rccl_ranks_on_the_one_visible_gpu_if_the_library_allows(dev):
+    """`bench.py --gpus 2 --launch-check --same-device --backend nccl`: two ranks, both on device 0 -- rendezvous, communicator
+    init, the all-gather census and the /dev/shm checkpoint sharing over RCCL.  RCCL may refuse two ranks on one device
+    ("Duplicate GPU detected"): then this is a skip, not a failure (the CPU suite covers the same flow over gloo)."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the driver's own multi-GPU run covers this")
+    r = _bench_cmd(["--gpus", "2", "--launch-check", "--check-bundle", "--same-device", "--backend", "nccl"], 2)
+    if r.returncode != 0:
+        tail = (r.stderr + r.stdout)[-4000:]
+        if "uplicate GPU" in tail or "invalid usage" in tail.lower() or "ncclInvalidUsage" in tail or "NCCL error" in tail or "ncclUnhandledCudaError" in tail:
+            pytest.skip("RCCL refuses two ranks on one device: " + tail.strip().splitlines()[-1][:200])
+        assert False, tail
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["collective"]["ranks_seen"] == 2 and j["shared_bundle"]["checksums_equal"]

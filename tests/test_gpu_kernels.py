@@ -61,12 +61,13 @@ def test_gemm_epilogues(dev, dt, M, N, K):
     assert _rel(out3.float().cpu(), torch.nn.functional.silu(ref)) < max(TOL[dt], 8e-3 if dt != torch.float32 else 0)
 
 
-@pytest.mark.parametrize("M,N,K,scale", [(300, 260, 1024, 1.0), (129, 200, 3072, 1.0), (257, 129, 64, 1.0), (200, 256, 1024, 3e-5), (130, 140, 512, 900.0)])
+@pytest.mark.parametrize("M,N,K,scale", [(300, 260, 1024, 1.0), (129, 200, 3072, 1.0), (257, 129, 64, 1.0), (200, 256, 1024, 1e-3), (130, 140, 512, 900.0),
+                                         (2816, 1024, 1024, 1.0)])
 def test_gemm_f32_split_f16_products(dev, M, N, K, scale):
     """M5_F32X3 (csrc/gemm.hip "X3"): fp32 operands multiplied as three split-f16 MFMA terms.  Against a float64 product of
     the same fp32 operands its error must stay at fp32 level -- within 4x the exact fp32-MFMA kernel's own error (which is
-    accumulation-order noise) and below 2e-6 of max |ref| -- over every epilogue the fp32 engines use; small (3e-5)
-    and large (900) activations included (the operands are pre-scaled into f16's normal range, csrc/gemm.hip)."""
+    accumulation-order noise) and below 2e-6 of max |ref| -- over every epilogue the fp32 engines use; small (1e-3)
+    and large (900) activations included; the last shape takes the 64-row tiling (the operands are pre-scaled into f16's normal range, csrc/gemm.hip)."""
     from mars5_tts_amd import _lib as L, ops
     a, w, b = _rand((M, K), 11) * scale, _rand((N, K), 12), _rand((N,), 13) * scale
     ref = (a.double() @ w.double().T + b.double())
@@ -600,6 +601,20 @@ def test_attention(dev, dt, B, H, Sq, Sk, kls, causal):
     torch.cuda.synchronize()
     r = _rel(o.float().cpu(), ref)
     assert r < max(TOL[dt], 1e-2 if dt != torch.float32 else 1e-4), f"attention rel err {r}"
+    if dt == torch.float32:
+        # the split-f16 product mode of the fp32 engines (csrc/attention.hip attn_x3_kernel): same masks, key order and softmax
+        # arithmetic, both products as three f16 MFMA terms -- within 4x the exact kernel's own distance from the fp32 reference
+        prev = ops.set_f32_products("f16x3")
+        try:
+            o3 = torch.zeros_like(o)
+            a.o = o3.data_ptr()
+            ops.attention(dt, a)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_f32_products(prev)
+        r3 = _rel(o3.cpu(), ref)
+        print(f"fp32 attention rel err: exact {r:.2e}, split-f16 {r3:.2e}")
+        assert r3 < max(4 * r, 2e-6), f"split-f16 attention rel err {r3} (exact {r})"
 
 
 def test_attention_kv_index(dev):

@@ -5,6 +5,7 @@ step in both modes, same process, alternating (ms per step and the largest logit
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("M5_HIP_TOOLS", "1")      # tools library: M5_X3_BM forces the tile height of the split-f16 kernel
 import torch
 import bench
 from mars5_tts_amd import synth, ops, _lib as L
@@ -22,7 +23,10 @@ def gemm_case(name, M, N, K, epi):
     ref = a.double() @ w.double().T + b.double()
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
-    for mode in ("exact", "f16x3"):
+    for mode, bm in (("exact", None), ("f16x3", "128"), ("f16x3", "64"), ("f16x3", None)):
+        os.environ.pop("M5_X3_BM", None)
+        if bm:
+            os.environ["M5_X3_BM"] = bm
         prev = ops.set_f32_products(mode)
         out = torch.zeros(M, N, device=dev)
         with torch.cuda.stream(stream):
@@ -43,7 +47,7 @@ def gemm_case(name, M, N, K, epi):
             stream.synchronize()
         ops.set_f32_products(prev)
         us = e0.elapsed_ms(e1) * 1e3 / (3 * REP)
-        print(f"{name:16s} M={M} N={N} K={K} {mode:6s} {us:9.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF  rel err vs float64 {err:.2e}", flush=True)
+        print(f"{name:16s} M={M} N={N} K={K} {mode:6s} bm={bm or 'auto':4s} {us:9.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF  rel err vs float64 {err:.2e}", flush=True)
 
 
 def step_bench():
@@ -83,7 +87,9 @@ def step_bench():
 
 
 if __name__ == "__main__":
-    for c in [("qkv", 2816, 3072, 1024), ("out_proj", 2816, 1024, 1024), ("swiglu-shape", 2816, 6144, 1024), ("linear2", 2816, 1024, 3072)]:
+    for c in [("qkv", 2816, 3072, 1024), ("out_proj", 2816, 1024, 1024), ("swiglu-shape", 2816, 6144, 1024), ("linear2", 2816, 1024, 3072),
+              ("heads", 1798, 1025, 1024)]:
         gemm_case(*c, L.EPI_F32)
+    os.environ.pop("M5_X3_BM", None)
     if os.environ.get("STEP", "1") == "1":
         step_bench()

@@ -121,6 +121,7 @@ CASES = [
     ("nar swiglu", 2816, 6144, 1024, L.EPI_SWIGLU, False, None),
     ("nar linear2", 2816, 1024, 3072, L.EPI_RESIDUAL, True, None),
     ("nar head (1 of 7)", 1798, 1025, 1024, L.EPI_F32, True, None),
+    ("nar heads folded", 1798, 7196, 1024, L.EPI_F32, True, None),     # round 4: the seven heads as ONE GEMM (rows padded 1025 -> 1028)
     ("enc qkv (hoisted)", 15600, 3072, 1024, L.EPI_QKV, True, 39),
     ("enc swiglu (hoisted)", 15600, 6144, 1024, L.EPI_SWIGLU, False, None),
     ("ar prefill qkv", 489, 4608, 1536, L.EPI_DT, False, None),
