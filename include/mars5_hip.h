@@ -395,6 +395,44 @@ M5_API int m5_trim_bounds(const float* y, int n, int frame_length, int hop, floa
 
 M5_API int m5_add_int(int32_t* p, int32_t delta, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Stage-level entry points: one call enqueues a whole stage from a caller-filled plan (csrc/stage_plan.hip).
+ *   m5_nar_step        one NAR reverse step = forward of both guidance branches + the step's uniforms + posterior / sample +
+ *                      step counter (reference mars5/diffuser.py:345-394, :451-468 loop body; model.py:264-343): ~190 launches
+ *   m5_ar_decode_step  one AR decode step = the 26 layers + final norm / head + sampler (nn_future.py:369-398,
+ *                      ar_generate.py:74-121): 3 launches with the persistent layer kernel, 132 in the per-launch form
+ *   m5_stage_run       any op list (conditioning, prefill)
+ * A plan is an array of ops in launch order; op.fn names an entry point of THIS header and op.a[] holds its arguments except
+ * the trailing stream: integers by value, device pointers by address, floats as IEEE bits in the low 32, pointers to argument
+ * structures (M5QkvScatter, M5DeferredLN, M5RowTiles, M5AttnArgs, M5GemvArgs, M5AttnDecodeArgs, M5ArMegaArgs, M5SampleArgs,
+ * M5NarSampleArgs, M5NarUniformArgs) as (byte offset into `arena` + 1; 8-byte aligned), 0 = NULL.  Every argument of a step is a
+ * pointer, stride or size (the step index, positions and RNG state live in device memory), so a session's plan is filled once
+ * and serves every step; the caller owns ops / arena / all buffers and may capture the call in a hipGraph.  Returns the first
+ * non-zero status of an op (the ops before it are already enqueued; *failed_op = its index, -1 on success, may be NULL);
+ * M5_ERR_ARG for an unknown fn, a wrong argument count, an op that does not belong to the stage kind or an arena offset out of
+ * range. */
+#define M5_PLAN_MAX_ARGS 24
+enum {
+    M5_FN_GEMM = 1, M5_FN_GEMM_EX, M5_FN_LAYERNORM, M5_FN_LAYERNORM_TWICE, M5_FN_LAYERNORM_MEAN, M5_FN_RMSNORM, M5_FN_ATTENTION,
+    M5_FN_GATHER_ROWS, M5_FN_CHUNKED_EMBED, M5_FN_XATTN_ABSORB, M5_FN_XATTN_SCORES, M5_FN_XATTN_SCORES_EX, M5_FN_NAR_UNIFORMS,
+    M5_FN_NAR_SAMPLE, M5_FN_ADD_INT, M5_FN_COPY_D2D, M5_FN_AR_GEMV, M5_FN_AR_ATTN_DECODE, M5_FN_AR_LAYERS_PERSISTENT, M5_FN_AR_SAMPLE,
+    M5_FN_AR_ROPE_CACHE_BATCH, M5_FN_AR_QKV_ROPE_BATCH, M5_FN_AR_ATTN_COMBINE_BATCH
+};
+typedef struct {
+    int32_t fn, n_args;                 /* M5_FN_*, number of slots used (= the entry point's parameters without the stream) */
+    int64_t a[M5_PLAN_MAX_ARGS];
+} M5PlanOp;
+typedef struct {
+    const M5PlanOp* ops; int32_t n_ops;
+    const unsigned char* arena; int64_t arena_bytes;      /* copies of the argument structures the ops point to */
+    int32_t* failed_op;                                    /* host int32, may be NULL */
+} M5StagePlan;
+M5_API int m5_nar_step(const M5StagePlan* plan, void* stream);
+M5_API int m5_ar_decode_step(const M5StagePlan* plan, void* stream);
+M5_API int m5_stage_run(const M5StagePlan* plan, void* stream);
+/* dst[0 .. bytes) = src[0 .. bytes), device to device, stream-ordered (capturable) */
+M5_API int m5_copy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
+
 /* hipGraph helpers (capture the launches issued between begin/end on `stream`). */
 M5_API int m5_graph_begin(void* stream);
 M5_API int m5_graph_end(void* stream, void** graph_exec);

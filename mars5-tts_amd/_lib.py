@@ -145,6 +145,26 @@ class DeferredLN(C.Structure):
                 ("s", vp), ("s_bs", i64), ("eps", f32), ("n_feat", i32), ("rows_bs", i32)]
 
 
+PLAN_MAX_ARGS = 24
+
+
+class PlanOp(C.Structure):
+    """M5PlanOp (include/mars5_hip.h): one launch of a stage plan -- entry point code + argument slots (stream excluded)."""
+    _fields_ = [("fn", i32), ("n_args", i32), ("a", i64 * PLAN_MAX_ARGS)]
+
+
+class StagePlanC(C.Structure):
+    """M5StagePlan: ops in launch order + the arena holding copies of the argument structures they point to."""
+    _fields_ = [("ops", C.POINTER(PlanOp)), ("n_ops", i32), ("arena", vp), ("arena_bytes", i64), ("failed_op", C.POINTER(i32))]
+
+
+# entry points a stage plan may hold -> M5_FN_* code (the enum of include/mars5_hip.h, in order)
+PLAN_FN = {name: i + 1 for i, name in enumerate([
+    "m5_gemm", "m5_gemm_ex", "m5_layernorm", "m5_layernorm_twice", "m5_layernorm_mean", "m5_rmsnorm", "m5_attention", "m5_gather_rows",
+    "m5_chunked_embed", "m5_xattn_absorb", "m5_xattn_scores", "m5_xattn_scores_ex", "m5_nar_uniforms", "m5_nar_sample", "m5_add_int",
+    "m5_copy_d2d", "m5_ar_gemv", "m5_ar_attn_decode", "m5_ar_layers_persistent", "m5_ar_sample", "m5_ar_rope_cache_batch",
+    "m5_ar_qkv_rope_batch", "m5_ar_attn_combine_batch"])}
+
 # name -> (restype, argtypes); also the list the symbol-export test checks against the header
 PROTOTYPES = {
     "m5_version": (C.c_int, []),
@@ -178,6 +198,10 @@ PROTOTYPES = {
     "m5_expand_tokens": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
     "m5_trim_bounds": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, f32, vp, C.c_int, vp, vp]),
     "m5_add_int": (C.c_int, [vp, i32, vp]),
+    "m5_copy_d2d": (C.c_int, [vp, vp, i64, vp]),
+    "m5_nar_step": (C.c_int, [C.POINTER(StagePlanC), vp]),
+    "m5_ar_decode_step": (C.c_int, [C.POINTER(StagePlanC), vp]),
+    "m5_stage_run": (C.c_int, [C.POINTER(StagePlanC), vp]),
     "m5_graph_begin": (C.c_int, [vp]),
     "m5_graph_end": (C.c_int, [vp, C.POINTER(vp)]),
     "m5_graph_launch": (C.c_int, [vp, vp]),
@@ -224,4 +248,68 @@ def _load() -> C.CDLL:
     return lib
 
 
-lib = _load()
+_cdll = _load()
+
+
+class PlanRecorder:
+    """Collects the launches issued through ``lib`` on this thread instead of enqueuing them (ops.StagePlan.recording)."""
+
+    def __init__(self):
+        self.ops = []                 # (fn code, [slots])
+        self.arena = bytearray()
+
+    def add(self, name: str, argtypes, args) -> int:
+        if name not in PLAN_FN:
+            raise Mars5HipError(f"{name} cannot be part of a stage plan (include/mars5_hip.h, M5_FN_*)")
+        assert len(args) == len(argtypes) and len(args) - 1 <= PLAN_MAX_ARGS, name
+        slots = []
+        for t, v in zip(argtypes[:-1], args[:-1]):          # the trailing stream is supplied when the plan runs
+            if t is vp:
+                slots.append(int(v) if v else 0)
+            elif t is f32:
+                slots.append(int.from_bytes(C.c_float(v), "little"))
+            elif isinstance(t, type) and issubclass(t, C._Pointer):     # POINTER(Struct): copy the structure into the arena
+                if v is None:
+                    slots.append(0)
+                else:
+                    obj = v._obj if hasattr(v, "_obj") else v.contents
+                    while len(self.arena) % 16:
+                        self.arena.append(0)
+                    slots.append(len(self.arena) + 1)
+                    self.arena += bytes(obj)
+            else:
+                slots.append(int(v))
+        self.ops.append((PLAN_FN[name], slots))
+        return M5_OK
+
+
+import threading as _threading
+
+_REC = _threading.local()
+
+
+class _LibProxy:
+    """The loaded library.  A call is enqueued at once -- unless this thread is recording a stage plan, in which case the
+    plannable launch entry points are appended to the plan instead (everything else still executes)."""
+
+    def __init__(self, cdll):
+        object.__setattr__(self, "_cdll", cdll)
+        object.__setattr__(self, "_cache", {})
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if name not in PLAN_FN:
+            return fn
+        w = self._cache.get(name)
+        if w is None:
+            def w(*args, _fn=fn, _name=name):
+                rec = getattr(_REC, "plan", None)
+                if rec is not None:
+                    return rec.add(_name, _fn.argtypes, args)
+                return _fn(*args)
+            w.argtypes, w.restype = fn.argtypes, fn.restype
+            self._cache[name] = w
+        return w
+
+
+lib = _LibProxy(_cdll)

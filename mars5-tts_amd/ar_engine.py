@@ -152,6 +152,8 @@ class ARSession:
         self.mega_dbg: Optional[torch.Tensor] = None           # tools/ar_mega_clock.py: (32, 16, 8) int64 phase stamps
         self.mega = _mega_default() and model.dt != torch.float32 and (D, F, H) == (1536, 3584, 24) and not buffers
         self.graph: Optional[ops.Graph] = None
+        self.step_plan: Optional[ops.StagePlan] = None         # the recorded decode step (enqueue_step)
+        self.use_c_plan = True                                 # False: the step's launches are composed in this file (tests compare the two)
         self._sample_args: Optional[L.SampleArgs] = None
         self._keep: List[torch.Tensor] = []
         self.ended_on_eos = False
@@ -305,15 +307,39 @@ class ARSession:
                          rng=self._rng.data_ptr() if self._rng is not None else None, rng_bs=0,
                          noise_inc=int(rng[2]) if noise is None else 0, noise_grid=int(rng[3]) if noise is None else 0)
         self._sample_args = a
+        self.step_plan = None                                    # (the recorded step holds a copy of the sampler arguments)
         self.n_noise = noise.shape[0] if noise is not None else int(n_steps)
+
+    def enqueue_step(self, st: int) -> None:
+        """One decode step (layers + head + sampler) through ONE C call (include/mars5_hip.h m5_ar_decode_step): the launches
+        are recorded once per session and sampler configuration into a stage plan (positions, counters and RNG state live in
+        device memory) and composed by the library from then on.  (M5_AR_CPLAN=0: tools A/B knob, composition stays here.)"""
+        if not self.use_c_plan or L.tool_knob("M5_AR_CPLAN", "1") == "0":
+            self.enqueue_layers(st)
+            self.enqueue_head_and_sample(st)
+            return
+        for _ in range(2):
+            if self.step_plan is None:
+                pl = ops.StagePlan("ar_decode_step")
+                with pl.recording():
+                    self.enqueue_layers(0)
+                    self.enqueue_head_and_sample(0)
+                self.step_plan = pl
+            rc = self.step_plan.run(st, raise_on_error=False)
+            if rc == L.M5_OK:
+                return
+            if rc == L.M5_ERR_UNSUPPORTED and self.mega and int(self.step_plan._failed.value) == 0:
+                # the persistent layer kernel declined (device / geometry): nothing was enqueued; per-launch form from here on
+                self.mega, self.step_plan = False, None
+                continue
+            L.check(rc, f"m5_ar_decode_step (op {int(self.step_plan._failed.value)})")
 
     def capture(self) -> None:
         """Capture one decode step (layers + head + sampler) as a hipGraph."""
         st = self.stream.cuda_stream
         self.stream.synchronize()
         ops.Graph.begin(st)
-        self.enqueue_layers(st)
-        self.enqueue_head_and_sample(st)
+        self.enqueue_step(st)
         self.graph = ops.Graph().end(st)
 
     def _launch_steps(self, n: int, use_graph: bool, st: int) -> None:
@@ -323,8 +349,7 @@ class ARSession:
                 if use_graph:
                     self.graph.launch(st)
                 else:
-                    self.enqueue_layers(st)
-                    self.enqueue_head_and_sample(st)
+                    self.enqueue_step(st)
 
     def decode(self, use_graph: bool = True, poll: int = 32, noise_fill=None) -> torch.Tensor:
         """Run sampler for the prefill logits, then decode steps until EOS / max_len.
@@ -389,7 +414,7 @@ class ARSession:
                     if kv_snap is not None:
                         self.kc.index_copy_(2, kv_snap[0], kv_snap[1])
                         self.vc.index_copy_(2, kv_snap[0], kv_snap[2])
-                self.mega = False
+                self.mega, self.step_plan = False, None       # (the recorded step held the persistent launch)
                 self.mega_recovered += 1
                 if use_graph:
                     self.capture()                             # the per-launch form of the step

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wno-unused-result"
-SRCS="gemm gemm16 gemm_skinny attention attention16 xattn_absorb rowops ar_decode ar_mega ar_batch nar_sample util"
+SRCS="gemm gemm16 gemm_skinny attention attention16 xattn_absorb rowops ar_decode ar_mega ar_batch nar_sample util stage_plan"
 build_one() {   # $1 = object dir, $2 = extra flags, $3 = output library
   mkdir -p $1
   pids=()

@@ -1198,16 +1198,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                         acc[i][j] = f4_t{xc[0], xc[1], xc[2], xc[3]};             // the deferred LayerNorm's operand, before rounding
                     }
                 }
-#ifdef M5_DLN_STORE_FIRST      // round-6 probe (tools/r6b.sh): the fp32 tile leaves FIRST, the LDS staging of the centred copy runs under its drain
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = mw + i * 16 + l15;
-                    float* rp = Cf + (int64_t)row * p.ldc;
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        if (row < p.M) *reinterpret_cast<float4*>(rp + nw + j * 16 + lg * 4) = oldpre[i][j];
-                }
-#endif
                 // the centred copy leaves through the (dead) stage buffers as whole 16-byte row chunks (straight from the
                 // accumulator layout a store instruction writes 16 rows x 32 bytes: measured +4 us per launch)
                 constexpr int RBX = TN * 32 + 16;                                 // padded LDS row: TN*16 columns of 2 bytes
@@ -1262,7 +1252,8 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                         if (row < p.M) p.dl_cen_out[bz * p.dl_rows_bs + row] = dl_cen[i];
                     }
                 }
-#ifndef M5_DLN_STORE_FIRST
+                // (round 6: the fp32 tile FIRST and the LDS staging of the centred copy under its drain measured 1 % SLOWER per
+                // step, 2.89 -> 2.92 ms, profiles/r6b_dln_store_first_ab_negative.txt: the tile goes last)
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int row = mw + i * 16 + l15;
@@ -1271,7 +1262,6 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                     for (int j = 0; j < TN; ++j)
                         if (row < p.M) *reinterpret_cast<float4*>(rp + nw + j * 16 + lg * 4) = oldpre[i][j];
                 }
-#endif
                 return;
             }
 #pragma unroll

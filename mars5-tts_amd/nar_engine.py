@@ -403,6 +403,8 @@ class NARSession:
             self.hn = torch.empty(1 if self.fold_heads else Q - 1, nb * self.s_out, D, dtype=dt, device=dev)
         self.graph = None
         self.graph_step, self._ph = None, None      # whole-step graph and in-graph uniform generator (made at the first run that can use them)
+        self.step_plan = None                       # (ops.StagePlan of one reverse step, the PhiloxDraws it was recorded with)
+        self.use_c_plan = True                      # False: the step's launches are composed here (tests compare the two)
 
     # ----------------------------------------------------------------------------- step
     def _last_layer_compact(self, lw, mem, normed: bool, st: int) -> None:
@@ -445,9 +447,8 @@ class NARSession:
             ops.chunked_embed(self.h[:1], mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
                               rows=S, stream=st)
             self_attn_block(hx[:Sr], mdl.dec[0], self.ws0, None, st)
-            ops.mark("torch copy: branch 0 -> branch 1", st)
-            with torch.cuda.stream(self.stream):
-                self.h[1].copy_(self.h[0])
+            ops.mark("copy: branch 0 -> branch 1", st)
+            ops.copy_d2d(self.h[1], self.h[0], stream=st)         # (a library copy: capturable AND visible to a stage plan)
             skip0 = True
         else:
             ops.chunked_embed(self.h, mdl.res_tables, self.x, None, mdl.pos_alpha, mdl.pe, add=self.t_dec, add_index=self.step_ptr,
@@ -473,9 +474,8 @@ class NARSession:
                               rows=S, stream=st)
             lw, mem = layers[0]
             self_attn_block(hx[:Sr], lw, self.ws0, None, st)
-            ops.mark("torch copy: branch 0 -> branch 1", st)
-            with torch.cuda.stream(self.stream):
-                self.h[1].copy_(self.h[0])                     # same stream (captured into the step graph)
+            ops.mark("copy: branch 0 -> branch 1", st)
+            ops.copy_d2d(self.h[1], self.h[0], stream=st)         # same stream (captured into the step graph)
             nxt = (mdl.dec[1].n1_w, mdl.dec[1].n1_b) if len(mdl.dec) > 1 else None
             normed = cross_attn_block(hx, lw, self.ws, mem, self.step_ptr, st, next_ln=(lw.n3_w, lw.n3_b), xa=self.xa[0], plan=self.plan, layer=0)
             normed = ff_block(hx, lw, self.ws, lw.n3_w, lw.n3_b, st, normed=normed, next_ln=nxt)
@@ -552,10 +552,24 @@ class NARSession:
         posterior / sample, step counter -- replayed as one hipGraph from the second step on."""
         st = self.stream.cuda_stream
 
+        def compose(s_):
+            self.enqueue_forward(s_)
+            ph.enqueue(s_)
+            self.enqueue_sample(ph.buf, ph.buf, s_)
+
         def body():
-            self.enqueue_forward(st)
-            ph.enqueue(st)
-            self.enqueue_sample(ph.buf, ph.buf, st)
+            # The whole reverse step through ONE C call (include/mars5_hip.h m5_nar_step): the ~190 launches are recorded once
+            # per session into a stage plan -- all their arguments are pointers / strides / sizes, the step index lives in
+            # device memory -- and composed by the library from then on.  (Deferred-LayerNorm engines; M5_NAR_CPLAN=0 is the
+            # tools A/B knob that keeps the composition in this file.)
+            if self.dl is None or not self.use_c_plan or L.tool_knob("M5_NAR_CPLAN", "1") == "0":
+                return compose(st)
+            if self.step_plan is None or self.step_plan[1] is not ph:
+                pl = ops.StagePlan("nar_step")
+                with pl.recording():
+                    compose(0)
+                self.step_plan = (pl, ph)
+            self.step_plan[0].run(st)
         if not use_graph or (self.graph_step is None and self.step_i == 0 and len(self.times) > 1):
             body()                                  # first step launch by launch: the capture below runs while the GPU works on it
         else:
@@ -652,6 +666,8 @@ class NARBatchSession:
         self.graph: Optional[ops.Graph] = None
         self.graph_step: Optional[ops.Graph] = None
         self._phs: Optional[List[PhiloxDraws]] = None
+        self.step_plan = None
+        self.use_c_plan = True
         self.subs: List[NARSession] = []
         self.diff_tables = diff_tables
 
@@ -803,12 +819,22 @@ class NARBatchSession:
         (its own generator's stream) and its posterior / sample launch, then the step counter."""
         st = self.stream.cuda_stream
 
-        def body():
-            self.enqueue_forward(st)
+        def compose(s_):
+            self.enqueue_forward(s_)
             for u, (sub, ph) in enumerate(zip(self.subs, phs)):
-                ph.enqueue(st)
-                ops.nar_sample(self._sample_args(u, sub, ph.buf, ph.buf), stream=st)
-            ops.add_int(self.step_ptr, 1, stream=st)
+                ph.enqueue(s_)
+                ops.nar_sample(self._sample_args(u, sub, ph.buf, ph.buf), stream=s_)
+            ops.add_int(self.step_ptr, 1, stream=s_)
+
+        def body():          # the group's step as one m5_nar_step call (NARSession._step_philox)
+            if self.dl is None or not self.use_c_plan or L.tool_knob("M5_NAR_CPLAN", "1") == "0":
+                return compose(st)
+            if self.step_plan is None or self.step_plan[1] is not phs:
+                pl = ops.StagePlan("nar_step")
+                with pl.recording():
+                    compose(0)
+                self.step_plan = (pl, phs)
+            self.step_plan[0].run(st)
         if not use_graph or (self.graph_step is None and self.step_i == 0 and len(self.times) > 1):
             body()
         else:

@@ -302,6 +302,64 @@ def trim_bounds(y: torch.Tensor, top_db: float, frame_length: int = 2048, hop_le
     return bounds
 
 
+def copy_d2d(dst: torch.Tensor, src: torch.Tensor, stream: Optional[int] = None) -> None:
+    """dst = src (contiguous device tensors of the same size and dtype) as a stream-ordered device copy of this library --
+    capturable, and plannable (a torch ``copy_`` is neither visible to a stage plan nor free of an ATen launch)."""
+    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.numel() == src.numel()
+    check(lib.m5_copy_d2d(_p(dst), _p(src), dst.numel() * dst.element_size(), _s(stream)), "m5_copy_d2d")
+
+
+class StagePlan:
+    """A stage of the hot path as ONE C call (include/mars5_hip.h: m5_nar_step / m5_ar_decode_step / m5_stage_run).  The
+    host engine runs its enqueue code once under ``recording()`` -- every launch that would have gone to the library is
+    appended to the plan instead -- and from then on ``run(stream)`` enqueues the whole stage from C.  The tensors the
+    recorded launches point to must stay alive and in place (the engines' sessions own them); `keep` holds extra references."""
+
+    KINDS = {"nar_step": "m5_nar_step", "ar_decode_step": "m5_ar_decode_step", "stage": "m5_stage_run"}
+
+    def __init__(self, kind: str):
+        assert kind in self.KINDS, kind
+        self.kind, self._rec, self._c, self.keep = kind, None, None, []
+
+    def recording(self):
+        plan = self
+
+        class _Ctx:
+            def __enter__(self_c):
+                assert getattr(L._REC, "plan", None) is None, "a stage plan is already being recorded on this thread"
+                plan._rec = L.PlanRecorder()
+                L._REC.plan = plan._rec
+                return plan
+
+            def __exit__(self_c, *exc):
+                L._REC.plan = None
+                if exc[0] is None:
+                    plan._finish()
+                return False
+        return _Ctx()
+
+    def _finish(self) -> None:
+        rec = self._rec
+        n = len(rec.ops)
+        arr = (L.PlanOp * max(n, 1))()
+        for i, (fn, slots) in enumerate(rec.ops):
+            arr[i].fn, arr[i].n_args = fn, len(slots)
+            for j, v in enumerate(slots):
+                arr[i].a[j] = v if v < (1 << 63) else v - (1 << 64)
+        arena = (C.c_ubyte * max(len(rec.arena), 1)).from_buffer_copy(bytes(rec.arena) or b"\0")
+        self._failed = L.i32(-1)
+        self._arr, self._arena = arr, arena
+        self._c = L.StagePlanC(ops=arr, n_ops=n, arena=C.cast(arena, C.c_void_p), arena_bytes=len(rec.arena), failed_op=C.pointer(self._failed))
+        self.n_ops = n
+
+    def run(self, stream: Optional[int] = None, raise_on_error: bool = True) -> int:
+        assert self._c is not None, "record the plan first"
+        rc = getattr(lib, self.KINDS[self.kind])(C.byref(self._c), _s(stream))
+        if rc != L.M5_OK and raise_on_error:
+            check(rc, f"{self.KINDS[self.kind]} (op {int(self._failed.value)} of {self.n_ops})")
+        return rc
+
+
 def add_int(p: torch.Tensor, delta: int, stream: Optional[int] = None) -> None:
     assert p.dtype == torch.int32
     check(lib.m5_add_int(_p(p), delta, _s(stream)), "m5_add_int")

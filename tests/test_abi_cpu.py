@@ -76,6 +76,75 @@ def test_every_compute_entry_point_rejects_null_arguments():
     assert swept >= 27
 
 
+def test_stage_plans_are_validated_before_anything_is_launched():
+    """m5_nar_step / m5_ar_decode_step / m5_stage_run (csrc/stage_plan.hip): a plan is checked op by op -- entry point code,
+    argument count against the real prototype, stage kind, arena offsets of the argument structures -- and the first bad op
+    returns M5_ERR_ARG with its index in *failed_op.  The ops used here fail their OWN argument validation (null buffers), so
+    nothing reaches a device: the whole test runs without a GPU.  Also: the Python recorder (ops.StagePlan.recording) turns the
+    library calls of a thread into exactly such a plan, fn codes in the header's enum order."""
+    from mars5_tts_amd import _lib as L, ops
+    hdr = open(os.path.join(ROOT, "include", "mars5_hip.h")).read()
+    enum = re.search(r"enum \{\s*(M5_FN_GEMM = 1.*?)\};", hdr, flags=re.S).group(1)
+    names = [n.strip().split(" ")[0] for n in enum.replace("\n", " ").split(",") if n.strip()]
+    assert ["m5_" + n[len("M5_FN_"):].lower() for n in names] == sorted(L.PLAN_FN, key=L.PLAN_FN.get), "M5_FN_* enum and _lib.PLAN_FN disagree"
+    assert int(re.search(r"#define M5_PLAN_MAX_ARGS (\d+)", hdr).group(1)) == L.PLAN_MAX_ARGS
+    for name in L.PLAN_FN:
+        assert len(L.PROTOTYPES[name][1]) - 1 <= L.PLAN_MAX_ARGS, name
+    lib = L.lib
+    failed = L.i32(123)
+
+    def plan(ops_, arena=b""):
+        arr = (L.PlanOp * max(len(ops_), 1))()
+        for i, (fn, slots) in enumerate(ops_):
+            arr[i].fn, arr[i].n_args = fn, len(slots)
+            for j, v in enumerate(slots):
+                arr[i].a[j] = v
+        ar = (C.c_ubyte * max(len(arena), 1)).from_buffer_copy(arena or b"\0")
+        return L.StagePlanC(ops=arr, n_ops=len(ops_), arena=C.cast(ar, C.c_void_p), arena_bytes=len(arena), failed_op=C.pointer(failed)), (arr, ar)
+
+    for entry in (lib.m5_nar_step, lib.m5_ar_decode_step, lib.m5_stage_run):
+        assert entry(None, None) == L.M5_ERR_ARG
+        p, keep = plan([])
+        assert entry(C.byref(p), None) == L.M5_OK and failed.value == -1          # an empty stage
+    p, keep = plan([(999, [])])
+    assert lib.m5_stage_run(C.byref(p), None) == L.M5_ERR_ARG and failed.value == 0     # unknown entry point
+    add_int = L.PLAN_FN["m5_add_int"]
+    p, keep = plan([(add_int, [0, 1, 2])])
+    assert lib.m5_nar_step(C.byref(p), None) == L.M5_ERR_ARG                           # m5_add_int takes 2 arguments + stream
+    p, keep = plan([(add_int, [0, 1])])
+    assert lib.m5_nar_step(C.byref(p), None) == L.M5_ERR_ARG and failed.value == 0     # right shape, null pointer: the op's own check
+    p, keep = plan([(L.PLAN_FN["m5_ar_sample"], [0])])
+    assert lib.m5_nar_step(C.byref(p), None) == L.M5_ERR_ARG                           # an AR launch is not part of a NAR step
+    assert lib.m5_ar_decode_step(C.byref(p), None) == L.M5_ERR_ARG                     # (as an AR step: null argument structure)
+    p, keep = plan([(L.PLAN_FN["m5_nar_sample"], [0])])
+    assert lib.m5_ar_decode_step(C.byref(p), None) == L.M5_ERR_ARG
+    att = L.PLAN_FN["m5_attention"]
+    p, keep = plan([(att, [L.BF16, 1 + 64])], arena=bytes(64))
+    assert lib.m5_nar_step(C.byref(p), None) == L.M5_ERR_ARG                           # structure offset past the arena
+    p, keep = plan([(att, [L.BF16, 1 + 4])], arena=bytes(C.sizeof(L.AttnArgs) + 16))
+    assert lib.m5_nar_step(C.byref(p), None) == L.M5_ERR_ARG                           # misaligned structure offset
+    p, keep = plan([(att, [L.BF16, 1 + 8])], arena=bytes(C.sizeof(L.AttnArgs) + 16))
+    assert lib.m5_nar_step(C.byref(p), None) == L.M5_ERR_ARG and failed.value == 0     # in range: m5_attention refuses the zeroed args
+    # the recorder
+    sp = ops.StagePlan("nar_step")
+    a = L.AttnArgs(B=1, H=2, Sq=3, Sk=4, scale=0.5)
+    with sp.recording():
+        assert lib.m5_add_int(None, 7, None) == L.M5_OK                                # recorded, not run (run directly: M5_ERR_ARG)
+        assert lib.m5_layernorm(L.BF16, 4096, 1024, 8192, 12288, 1e-5, 16384, 1024, 10, 1024, 1, 0, 0, None) == L.M5_OK
+        assert lib.m5_attention(L.BF16, C.byref(a), None) == L.M5_OK
+        with pytest.raises(L.Mars5HipError):
+            pass_through = lib.m5_version()                                           # (not a launch: executes)
+            assert pass_through == 1
+            raise L.Mars5HipError("sentinel")
+    assert sp.n_ops == 3 and [o.fn for o in sp._arr[:3]] == [add_int, L.PLAN_FN["m5_layernorm"], att]
+    assert list(sp._arr[0].a[:2]) == [0, 7] and sp._arr[1].n_args == 13
+    assert sp._arr[1].a[5] == int.from_bytes(C.c_float(1e-5), "little")               # floats travel as their bits
+    off = sp._arr[2].a[1] - 1
+    got = L.AttnArgs.from_buffer_copy(bytes(sp._arena)[off:off + C.sizeof(L.AttnArgs)])
+    assert (got.B, got.H, got.Sq, got.Sk, got.scale) == (1, 2, 3, 4, 0.5)             # the structure was copied into the arena
+    assert sp.run(0, raise_on_error=False) == L.M5_ERR_ARG and sp._failed.value == 0         # (stream 0) op 0's null pointer is refused when the plan RUNS
+
+
 def test_persistent_decode_step_refuses_what_it_cannot_run():
     """m5_ar_layers_persistent validates before it touches the device: missing pointers are an argument error, any geometry
     but the CodecLM one (dim 1536, hidden 3584, 24 heads), fp32 operands or more than 31 layers are 'unsupported' -- the
@@ -284,7 +353,8 @@ def test_ctypes_structs_match_the_header_layout(tmp_path):
     hdr = os.path.join(ROOT, "include", "mars5_hip.h")
     pairs = {"M5QkvScatter": L.QkvScatter, "M5AttnArgs": L.AttnArgs, "M5Prefetch": L.Prefetch, "M5GemvArgs": L.GemvArgs,
              "M5AttnDecodeArgs": L.AttnDecodeArgs, "M5SampleArgs": L.SampleArgs, "M5NarSampleArgs": L.NarSampleArgs,
-             "M5ArMegaArgs": L.ArMegaArgs, "M5DeferredLN": L.DeferredLN, "M5RowTiles": L.RowTiles, "M5NarUniformArgs": L.NarUniformArgs}
+             "M5ArMegaArgs": L.ArMegaArgs, "M5DeferredLN": L.DeferredLN, "M5RowTiles": L.RowTiles, "M5NarUniformArgs": L.NarUniformArgs,
+             "M5PlanOp": L.PlanOp, "M5StagePlan": L.StagePlanC}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{hdr}"', 'int main(void) {']
     for cname, cls in pairs.items():
         lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')

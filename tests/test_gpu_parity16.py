@@ -716,3 +716,64 @@ def test_nar_long_form_forward_vs_oracle(dev, full_bundle, dt):
                   f"argmax agreement {am:.4f}")
             assert max(ec, eu) <= tol
             del lc, lu
+
+
+# ------------------------------------------------------------------ stage-level C entry points
+def test_c_composed_stages_equal_the_host_composed_ones_bit_for_bit(dev, full_bundle):
+    """The product enqueues a NAR reverse step and an AR decode step through ONE C call each (m5_nar_step / m5_ar_decode_step
+    over a stage plan recorded once per session, csrc/stage_plan.hip).  Same launches, same arguments: the results must be
+    bit-identical to the steps composed launch by launch in Python -- lone NAR session (12 reverse steps, both guidance
+    branches, in-graph uniforms), a batched NAR group of three utterances, and 96 AR decode steps on the persistent and on
+    the per-launch form, each under a hipGraph and eagerly."""
+    from mars5_tts_amd import _lib as L
+    from mars5_tts_amd.diffuser import _generator_uniform
+    from mars5_tts_amd.nar_engine import NARBatchSession, NARConfig, NARSession
+    b = full_bundle
+    eng = _nar_engine(b, torch.bfloat16, dev)
+    cfg = NARConfig(T=200, x_0_temp=0.7, guidance_w=3.0, deep_clone=True, q0_override_steps=20)
+    times = list(range(199, 187, -1))
+    it = _nar_item(b.nar_shape, 38, 450, 449, 5)
+    outs = {}
+    for mode in ("c", "host", "c-eager"):
+        sess = NARSession(eng, cfg)
+        sess.use_c_plan = mode != "host"
+        sess.prepare(it["c_text"], it["c_codes"], it["x"], it["x_known"], it["m_mask"], it["row_offset"], times)
+        assert sess.dl is not None, "the bench engine runs the deferred-LayerNorm schedule"
+        gen = torch.Generator(device=dev).manual_seed(77)
+        x = sess.run(_generator_uniform(dev, gen), use_graph=mode != "c-eager").clone()
+        outs[mode] = (x.cpu(), int(gen.get_offset()))
+        if mode != "host":
+            assert sess.step_plan is not None and sess.step_plan[0].n_ops > 100, "the C-composed path did not run"
+            n_ops = sess.step_plan[0].n_ops
+        else:
+            assert sess.step_plan is None
+    assert torch.equal(outs["c"][0], outs["host"][0]) and torch.equal(outs["c-eager"][0], outs["host"][0])
+    assert outs["c"][1] == outs["host"][1]
+    print(f"NAR reverse step: {n_ops} launches per m5_nar_step call; 12 steps bit-identical to the host-composed step (graph and eager)")
+    # a batched group (row-tile lists, per-utterance uniforms)
+    items = [_nar_item(b.nar_shape, 30, 300, 200, 11), _nar_item(b.nar_shape, 52, 450, 260, 12), _nar_item(b.nar_shape, 41, 180, 120, 13)]
+    res = {}
+    for mode in ("c", "host"):
+        bs = NARBatchSession(eng, cfg)
+        bs.use_c_plan = mode == "c"
+        bs.prepare(items, times[:6])
+        gens = [torch.Generator(device=dev).manual_seed(500 + i) for i in range(len(items))]
+        res[mode] = [t.cpu() for t in bs.run([_generator_uniform(dev, g) for g in gens])]
+        assert (bs.step_plan is not None) == (mode == "c")
+    assert all(torch.equal(a, c) for a, c in zip(res["c"], res["host"]))
+    # AR decode: persistent and per-launch forms
+    N = 96
+    for persistent in (True, False):
+        toks = {}
+        for mode, graph in (("c", True), ("host", True), ("c", False)):
+            s, _ = _bench_session(dev, b, N, persistent=persistent)
+            s.use_c_plan = mode == "c"
+            toks[(mode, graph)] = s.decode(use_graph=graph).cpu().tolist()
+            assert s.mega == persistent
+            if mode == "c":
+                assert s.step_plan is not None and s.step_plan.n_ops == (3 if persistent else 26 * 5 + 2), s.step_plan.n_ops
+            else:
+                assert s.step_plan is None
+        assert toks[("c", True)] == toks[("host", True)] == toks[("c", False)]
+        assert len(toks[("c", True)]) > 60
+    print("AR decode step: 3 launches (persistent) / 132 (per-launch) per m5_ar_decode_step call; tokens identical to the host-composed step")
