@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
     const bool known = a.m[row] != 0;
     int64_t result;
 
-    if (known) {
+    if (q == 0 && t > a.q0_override_steps) {
+        result = xk;             // L0 override (diffuser.py:467-468): whatever this row would draw is replaced, so it draws nothing
+    } else if (known) {
         if (t == 0) {
             result = xk;                                          // diffuser.py:387-388
         } else {
@@ -107,6 +109,11 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
         const float invT = 1.0f / a.temperature;
         float z[MAXC];
         float mx = -INFINITY;
+        // the row's uniforms are requested with the logits (they are consumed four reductions later: requested there, the wave
+        // sat through a dependent HBM round trip in the middle of the chain)
+        float uu[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) uu[i] = (lane + 64 * i < K) ? u1[lane + 64 * i] : 0.5f;
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int k = lane + 64 * i;
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(256) void nar_sample_kernel(M5NarSampleArgs a) {
         for (int i = 0; i < MAXC; ++i) {
             const int k = lane + 64 * i;
             if (k < K) {
-                const float v = gumbel(u1[k]) + (z[i] - lse);       // log_sample_categorical (:219-228)
+                const float v = gumbel(uu[i]) + (z[i] - lse);       // log_sample_categorical (:219-228)
                 if (v > best) { best = v; bi = k; }
             }
         }

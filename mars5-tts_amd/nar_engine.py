@@ -241,6 +241,8 @@ class NARSession:
         self.graph_step: Optional[ops.Graph] = None
         self._ph: Optional[PhiloxDraws] = None
         self.diff_tables = diff_tables
+        self.step_plan = None
+        self.use_c_plan = True                      # False: the step's launches are composed in this file (tests compare the two)
 
     def _enter(self) -> None:
         """Order this session's stream behind whatever the caller has already enqueued on its current stream (inputs
@@ -404,7 +406,6 @@ class NARSession:
         self.graph = None
         self.graph_step, self._ph = None, None      # whole-step graph and in-graph uniform generator (made at the first run that can use them)
         self.step_plan = None                       # (ops.StagePlan of one reverse step, the PhiloxDraws it was recorded with)
-        self.use_c_plan = True                      # False: the step's launches are composed here (tests compare the two)
 
     # ----------------------------------------------------------------------------- step
     def _last_layer_compact(self, lw, mem, normed: bool, st: int) -> None:
