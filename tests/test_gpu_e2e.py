@@ -309,9 +309,11 @@ def test_nar_tiny_reduced_precision_logits(dev, dt):
     assert ece < tol / 2 and eue < tol / 2
 
 
-def test_full_size_goldens_f32(dev, gold_dir, full_bundle):
+@pytest.mark.parametrize("f32_products", ["exact", "f16x3"], indirect=True)
+def test_full_size_goldens_f32(dev, gold_dir, full_bundle, f32_products):
     """The real MARS5 geometry (1536-d x 26 layers AR, 1024-d 8+16 layers NAR) with seeded
-    weights regenerated on this host: fp32 engine vs tokens produced by the reference."""
+    weights regenerated on this host: fp32 engine vs tokens produced by the reference -- with exact fp32-MFMA products and
+    with split-f16 products (csrc/gemm.hip X3: the prefill GEMMs / attention of the AR stage and the whole NAR forward)."""
     from mars5_tts_amd import synth
     from mars5_tts_amd.diffuser import DSH, MultinomialDiffusion, perform_simple_inference
     b = full_bundle
@@ -811,8 +813,10 @@ def test_ar_batch_full_size_vs_single(dev, dt, full_bundle):
     print(f"batched vs batch-1: worst rel logit diff {worst:.2e}; greedy tokens agree for the first {agree} of {n_gen} steps")
 
 
-def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle):
-    """The public ``Mars5TTS.tts()`` against the reference's OWN ``inference.py`` (fixture: the unmodified reference on
+@pytest.mark.parametrize("f32_products", ["exact", "f16x3"], indirect=True)
+def test_tts_entry_point_matches_reference_inference(dev, gold_dir, full_bundle, f32_products):
+    """(Both fp32 product modes: exact fp32-MFMA and split-f16, ops.set_f32_products.)
+    The public ``Mars5TTS.tts()`` against the reference's OWN ``inference.py`` (fixture: the unmodified reference on
     CPU, full-size seeded weights, deep and shallow clone, README sampling settings; Encodec / Vocos replaced on both
     sides by the deterministic stand-ins of oracle/fakes.py).  fp32 engine, the reference's CPU random stream replayed
     draw by draw: the AR frames must be identical and so must the final codes -- unless a step of the engine's own
