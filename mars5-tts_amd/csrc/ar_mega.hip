@@ -272,7 +272,6 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
     const unsigned char* Wo = (const unsigned char*)a.wo;
     if (loader) {
         dma_flat(lds_base + OFF_A, Wq + ((int64_t)a.layer0 * 3 * MD + (int64_t)b * 18) * MD * 2, 54, lane);
-        dma_flat(lds_base + OFF_B, Wo + ((int64_t)a.layer0 * MD + (int64_t)b * 6) * MD * 2, 18, lane);
     }
 
     for (int l = a.layer0; l < a.layer1; ++l) {
@@ -293,6 +292,10 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         bar();
         if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
         mstamp(a.dbg, l, 1);
+        // loader: this layer's Wo rows -> region B (the previous layer's W2 rows were consumed before its last barrier).  Requested HERE,
+        // behind the x gather, not at the end of the previous layer: 18 pieces fewer in flight while the CU polls the x edge
+        // (round 6, same box, alternated builds: 503.5 -> 495 us per token, profiles/r6f_ar_dma_placement_ab.txt)
+        if (loader) dma_flat(lds_base + OFF_B, Wo + ((int64_t)l * MD + (int64_t)b * 6) * MD * 2, 18, lane);
         rms_to_xs<T, 3>(graw, nws, a.eps, xs, red[0], tid, lane, wave);
         mstamp(a.dbg, l, 11);
         if (loader) wait_dma<18>();                           // the Wqkv rows have landed (the 18 Wo pieces are younger)
@@ -368,7 +371,9 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
             if (wave == 4 && !gather<T, 3, 1>(g + G_QKV + ah * 32, MD / 2, 32, tl + E_QKV, graw, lane)) fail = 1;
             bar();
             if (fail) { if (tid == 0) atomicAdd(a.err, 1u); return; }
-            if (loader) dma_flat(lds_base + OFF_A, W13, 42, lane);            // drains under the scan's arithmetic
+            // all 84 W1 | W3 pieces in ONE request: drains under the scan's arithmetic and the O edge (round 6: two requests of 42,
+            // the second behind the scan, were 1.5 us per token slower -- profiles/r6f_ar_dma_placement_ab.txt)
+            if (loader) dma_flat(lds_base + OFF_A, W13, 84, lane);
             mstamp(a.dbg, l, 3);
             float m = -INFINITY, lsum = 0.f, o[8];
             if (wave < 4) {
@@ -442,7 +447,6 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
                 }
             }
             bar();
-            if (loader) dma_flat(lds_base + OFF_A + 42 * 1024, W13 + 42 * 1024, 42, lane);      // drains before the O edge completes
             if (wave == 0) {
                 // merge of the 4 waves (attn_decode_kernel's 8-thread tail, one (d-group, element) per lane: the same sums in
                 // the same order), then two store instructions publish the 66 words
@@ -554,6 +558,7 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
         mstamp(a.dbg, l, 9);
         // loader: next layer's Wqkv rows -> region A (the W1 | W3 rows were consumed in P4), while the others run their products
         const bool more = l + 1 < a.layer1;
+        // (requested one barrier earlier, in front of the h gather: neutral, 503.3 vs 503.7 us per token, same file)
         if (loader && more) dma_flat(lds_base + OFF_A, Wq + ((int64_t)(l + 1) * 3 * MD + (int64_t)b * 18) * MD * 2, 54, lane);
         if (wave < 6) {
             float acc[1];
@@ -568,8 +573,6 @@ __global__ __launch_bounds__(512) void ar_mega_kernel(M5ArMegaArgs a) {
             if (more) publish(g + G_X2, b * 6 + lane, xloc[lane], tl + E_X2);
             else a.xres[b * 6 + lane] = xloc[lane];
         }
-        // loader: next layer's Wo rows -> region B (the W2 rows were consumed before this barrier)
-        if (loader && more) dma_flat(lds_base + OFF_B, Wo + ((int64_t)(l + 1) * MD + (int64_t)b * 6) * MD * 2, 18, lane);
         mstamp(a.dbg, l, 10);
     }
 }

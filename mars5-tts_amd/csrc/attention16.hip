@@ -336,6 +336,364 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// attn16s_kernel (round 6): the SAME arithmetic as attn16_kernel<T, 4, 0, 1> -- same fragments, same fma / exp2 / sum order,
+// bit-identical output -- with the instruction stream of a key tile laid out by hand (sched_barrier between small groups)
+// instead of leaving three big blocks to the scheduler.  What the compiler made of the kernel above: the 8 S^T MFMAs of tile
+// t+1 back to back (the wave sits at each until the matrix pipe frees: ~256 cycles in which it issues nothing else), then the
+// 17-deep max chain, then exp / PV, then a 16-deep dependent v_pk_add chain with s_nops AFTER the last PV MFMA, then the
+// barrier and ~45 instructions of DMA issue in front of the next S^T block -- ~500 cycles per tile with the matrix pipe idle
+// and nothing overlapping the VALU.  Here: one MFMA every 4-8 other instructions through the whole tile --
+//   phase 1: the 8 S^T MFMAs of tile t+1 interleaved with tile t's max chain, the lane^32 exchange, alpha, the DMA issue of
+//            tile t+2 and the V^T fragment reads of tile t;
+//   phase 2: per 8-key block {8 fma, 8 exp2, 8 row-sum adds, 4 cvt_pk} then its 2 PV MFMAs (the row sums ride with the exps:
+//            no dependent chain at the end of the tile);
+// the DMA of all tiles but the last takes a path without the per-row clamp, m0 is saved once per four pieces.
+// FM = 1: the fma / add of the softmax as single v_fma_f32 / v_add_f32 (asm) -- MI355X_MICROARCH.md prices packed f32 VALU
+// beside MFMAs at +22..26 cycles per instruction over the two scalar ones; FM = 0 leaves the choice to the compiler.
+__device__ inline void glds16x4(const unsigned char* g0, const unsigned char* g1, const unsigned char* g2, const unsigned char* g3,
+                                uint32_t lds_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_base) : "memory", "scc");
+}
+template <int FM>
+__device__ inline float sm_fma(float a, float b, float c) {
+    if constexpr (FM == 1) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
+    else return __builtin_fmaf(a, b, c);
+}
+template <int FM>
+__device__ inline float sm_add(float a, float b) {
+    if constexpr (FM == 1) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+    else return a + b;
+}
+#define M5_SB() __builtin_amdgcn_sched_barrier(0)
+// two fp32 values -> one dword of two operand-type values, round to nearest even (one v_cvt_pk_*: the same values as two T::from_f32)
+template <typename T>
+__device__ inline uint32_t pack2(float a, float b);
+template <>
+__device__ inline uint32_t pack2<BF16T>(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    const f2_t v = {a, b};
+    const bf2 r = __builtin_convertvector(v, bf2);
+    return *reinterpret_cast<const uint32_t*>(&r);
+}
+template <>
+__device__ inline uint32_t pack2<F16T>(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
+    const f2_t v = {a, b};
+    const hf2 r = __builtin_convertvector(v, hf2);
+    return *reinterpret_cast<const uint32_t*>(&r);
+}
+
+// ABL (tools, timing only, WRONG results unless noted): 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax fma / exp / sum, 4 no S^T MFMAs,
+// 5 no PV MFMAs, 6 (correct) the four DMA pieces of a tile issued one per 8-key block of phase 2, 7 = 1 + 2
+template <typename T, int FM, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
+    using st = typename T::storage;
+    constexpr int NJ = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_B];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+    if (p.q_len && q0 >= p.q_len[b]) return;
+    int kl = p.key_len ? p.key_len[b] : p.Sk;
+    kl = min(kl, p.Sk);
+    int64_t koff = 0, voff = 0;
+    if (p.kv_index) {
+        const int64_t ix = *p.kv_index;
+        koff = ix * p.kv_index_stride_k;
+        voff = ix * p.kv_index_stride_v;
+    }
+    const unsigned char* Kg = (const unsigned char*)p.k + (koff + b * p.k_bs + h * p.k_hs) * 2;
+    const unsigned char* Vg = (const unsigned char*)p.vt + (voff + b * p.vt_bs + h * p.vt_hs) * 2;
+    const unsigned char* Qg = (const unsigned char*)p.q + (b * p.q_bs + h * p.q_hs) * 2;
+
+    int ntiles = (kl + KT - 1) / KT;
+    if (p.causal) ntiles = min(ntiles, (min(q0 + 128, p.Sq) - 1) / KT + 1);
+
+    const int qpos = q0 + wave * 32 + l31;
+    const int qrow = min(qpos, p.Sq - 1);
+    uint4 qf[4];
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+        qf[ds] = *reinterpret_cast<const uint4*>(Qg + ((int64_t)qrow * p.q_rs + ds * 16 + hh * 8) * 2);
+
+    // DMA assignment: as attn16_kernel (instruction q = 4 wave + j: waves 0, 1 bring the K rows, waves 2, 3 the V^T rows)
+    const int srow = lane >> 3;
+    const unsigned char* gcur[NJ];
+    const unsigned char* klast[NJ];
+    int krow_of[NJ];
+    const bool kwave = wave < 2;                                  // wave-uniform
+    const int64_t gstep = kwave ? (int64_t)KT * p.k_rs * 2 : (int64_t)KT * 2;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = wave * NJ + j;
+        const int row = (q & 7) * 8 + srow;
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        if (kwave) {
+            gcur[j] = Kg + (int64_t)row * p.k_rs * 2 + chunk * 16;
+            klast[j] = Kg + (int64_t)(p.Sk - 1) * p.k_rs * 2 + chunk * 16;
+            krow_of[j] = row;
+        } else {
+            gcur[j] = Vg + (int64_t)row * p.vt_ds * 2 + chunk * 16;
+            klast[j] = gcur[j];
+            krow_of[j] = -(1 << 30);
+        }
+    }
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    auto stage_load = [&](int stage, int kt) {                   // called with kt = 0, 1, 2, ... in order
+        const uint32_t sb = lds_base + stage * STAGE_B + wave * NJ * 1024;
+        if ((kt + 1) * KT <= p.Sk) {                              // no row of this tile is past the end (wave-uniform)
+            glds16x4(gcur[0], gcur[1], gcur[2], gcur[3], sb);
+        } else {
+            const int over = kt * KT - p.Sk;
+            glds16x4((krow_of[0] + over >= 0) ? klast[0] : gcur[0], (krow_of[1] + over >= 0) ? klast[1] : gcur[1],
+                     (krow_of[2] + over >= 0) ? klast[2] : gcur[2], (krow_of[3] + over >= 0) ? klast[3] : gcur[3], sb);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) gcur[j] += gstep;
+    };
+
+    const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    int koffs[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+            const int row = krow + 32 * kb;
+            koffs[kb][ds] = row * 128 + (((2 * ds + hh) ^ ((row >> 1) & 7)) << 4);
+        }
+    int voffs[2][4];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = l31 + 32 * db;
+            voffs[db][c] = TILE_B + row * 128 + (((2 * c + hh) ^ ((row >> 1) & 7)) << 4);
+        }
+
+    f16_t oacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float sc2 = p.scale * 1.4426950408889634f;
+
+    auto ld = [&](const unsigned char* sb, int off) { return *reinterpret_cast<const uint4*>(sb + off); };
+    auto qk = [&](const uint4& a, const uint4& bq, f16_t c) -> f16_t {
+        if constexpr (ABL == 4) { c[0] += __uint_as_float(a.x); return c; }
+        else return mfma32<T>(a, bq, c);
+    };
+    auto mask_tile = [&](int kt, f16_t (&s)[2]) {
+        const int kbase = kt * KT;
+        const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);
+        if (need_mask) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kidx = kbase + 32 * kb + 16 * (r >> 3) + 8 * hh + (r & 7);
+                    const bool vis = kidx < kl && (!p.causal || kidx <= qpos);
+                    s[kb][r] = vis ? s[kb][r] : -INFINITY;
+                }
+        }
+    };
+    // tile statistics once the 32 scores' maximum `mx` of this lane is known: m_new, alpha, -m_use
+    float alpha, mneg, m_new;
+    auto stats = [&](float mx) {
+        mx = fmaxf(mx, lane_xor32(mx)) * sc2;
+        m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        mneg = -m_use;
+    };
+    auto rescale = [&]() {
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        }
+    };
+    float ps0, ps1;                                               // row-sum partials (even / odd registers, attn16_kernel's order)
+    // one 8-key block of P^T: scores -> probabilities (kept in s for nothing: only the packed operand is used)
+    auto p_block = [&](f16_t (&s)[2], int kb, int m) -> uint4 {
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (ABL == 3) { w[j] = pack2<T>(s[kb][8 * m + 2 * j], s[kb][8 * m + 2 * j + 1]); continue; }
+            const float e0 = __builtin_amdgcn_exp2f(sm_fma<FM>(s[kb][8 * m + 2 * j], sc2, mneg));
+            const float e1 = __builtin_amdgcn_exp2f(sm_fma<FM>(s[kb][8 * m + 2 * j + 1], sc2, mneg));
+            ps0 = sm_add<FM>(ps0, e0);
+            ps1 = sm_add<FM>(ps1, e1);
+            w[j] = pack2<T>(e0, e1);
+        }
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    };
+    uint32_t dma_sb = 0;                                          // ABL 6: LDS base of the tile being fetched (0 = none)
+    bool dma_slow = false;
+    int dma_over = 0;
+    auto pv_phase = [&](const unsigned char* sbc, f16_t (&cur)[2], uint4 (&va)[2][4]) {
+        ps0 = 0.f;
+        ps1 = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            const uint4 pb = p_block(cur, blk >> 1, blk & 1);
+            M5_SB();
+            if constexpr (ABL == 6) {
+                if (dma_sb) {
+                    glds16((dma_slow && krow_of[blk] + dma_over >= 0) ? klast[blk] : gcur[blk], dma_sb + blk * 1024);
+                    gcur[blk] += gstep;
+                }
+                M5_SB();
+            }
+            if constexpr (ABL != 5) {
+                oacc[0] = mfma32<T>(va[0][blk], pb, oacc[0]);
+                oacc[1] = mfma32<T>(va[1][blk], pb, oacc[1]);
+            } else {
+                oacc[0][blk] += __uint_as_float(pb.x);
+            }
+            M5_SB();
+        }
+        l_run = l_run * alpha + (ps0 + ps1);
+        m_run = m_new;
+    };
+
+    if (ntiles > 0) stage_load(0, 0);
+    if (ntiles > 1) stage_load(1, 1);
+    f16_t sA[2], sB[2];
+    if (ntiles > 0) {
+        if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NJ) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sA[kb][r] = 0.f;
+#pragma unroll
+            for (int ds = 0; ds < 4; ++ds) sA[kb] = mfma32<T>(ld(lds, koffs[kb][ds]), qf[ds], sA[kb]);
+        }
+    }
+    int slot = 0;
+    // tile kt (scores in cur) with a tile kt+1 behind it
+    auto full = [&](int kt, f16_t (&cur)[2], f16_t (&nxt)[2]) {
+        const int s1 = (slot == 2) ? 0 : slot + 1;
+        const unsigned char* sbc = lds + slot * STAGE_B;
+        const unsigned char* sbn = lds + s1 * STAGE_B;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile kt+1 (the only DMA in flight) landed
+        if constexpr (ABL != 2 && ABL != 7) __builtin_amdgcn_s_barrier();       // ... for every wave; tile kt-1 fully consumed
+        M5_SB();
+        uint4 ka[2][4], va[2][4];
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) ka[kb][ds] = ld(sbn, koffs[kb][ds]);
+        M5_SB();
+        mask_tile(kt, cur);
+        float mx = fmaxf(cur[0][0], cur[1][0]);
+#pragma unroll
+        for (int r = 1; r < 8; ++r) mx = fmaxf(fmaxf(mx, cur[0][r]), cur[1][r]);
+        M5_SB();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { nxt[0][r] = 0.f; nxt[1][r] = 0.f; }
+        nxt[0] = qk(ka[0][0], qf[0], nxt[0]);
+        M5_SB();
+#pragma unroll
+        for (int r = 8; r < 12; ++r) mx = fmaxf(fmaxf(mx, cur[0][r]), cur[1][r]);
+        M5_SB();
+        nxt[1] = qk(ka[1][0], qf[0], nxt[1]);
+        M5_SB();
+#pragma unroll
+        for (int r = 12; r < 16; ++r) mx = fmaxf(fmaxf(mx, cur[0][r]), cur[1][r]);
+        M5_SB();
+        nxt[0] = qk(ka[0][1], qf[1], nxt[0]);
+        M5_SB();
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { va[0][c] = ld(sbc, voffs[0][c]); va[1][c] = ld(sbc, voffs[1][c]); }
+        M5_SB();
+        nxt[1] = qk(ka[1][1], qf[1], nxt[1]);
+        M5_SB();
+        stats(mx);
+        M5_SB();
+        nxt[0] = qk(ka[0][2], qf[2], nxt[0]);
+        M5_SB();
+        if constexpr (ABL == 6) {
+            dma_sb = (kt + 2 < ntiles) ? lds_base + (slot == 0 ? 2 : slot - 1) * STAGE_B + wave * NJ * 1024 : 0;
+            dma_slow = (kt + 3) * KT > p.Sk;
+            dma_over = (kt + 2) * KT - p.Sk;
+        } else if constexpr (ABL != 1 && ABL != 7) {
+            if (kt + 2 < ntiles) stage_load(slot == 0 ? 2 : slot - 1, kt + 2);       // into the slot tile kt-1 used
+        }
+        M5_SB();
+        nxt[1] = qk(ka[1][2], qf[2], nxt[1]);
+        M5_SB();
+#pragma unroll
+        for (int c = 2; c < 4; ++c) { va[0][c] = ld(sbc, voffs[0][c]); va[1][c] = ld(sbc, voffs[1][c]); }
+        M5_SB();
+        nxt[0] = qk(ka[0][3], qf[3], nxt[0]);
+        M5_SB();
+        rescale();
+        M5_SB();
+        nxt[1] = qk(ka[1][3], qf[3], nxt[1]);
+        M5_SB();
+        pv_phase(sbc, cur, va);
+        slot = s1;
+    };
+    // the last tile
+    auto last = [&](int kt, f16_t (&cur)[2]) {
+        const unsigned char* sbc = lds + slot * STAGE_B;
+        dma_sb = 0;
+        uint4 va[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { va[0][c] = ld(sbc, voffs[0][c]); va[1][c] = ld(sbc, voffs[1][c]); }
+        mask_tile(kt, cur);
+        float mx = fmaxf(cur[0][0], cur[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, cur[0][r]), cur[1][r]);
+        stats(mx);
+        rescale();
+        pv_phase(sbc, cur, va);
+    };
+    if (ntiles > 0) {
+        int kt = 0;
+        for (; kt + 2 < ntiles; kt += 2) {
+            full(kt, sA, sB);
+            full(kt + 1, sB, sA);
+        }
+        if (kt + 1 < ntiles) {
+            full(kt, sA, sB);
+            last(kt + 1, sB);
+        } else {
+            last(kt, sA);
+        }
+    }
+
+    const float l_tot = l_run + lane_xor32(l_run);
+    if (qpos < p.Sq) {
+        const float inv = 1.0f / l_tot;
+        st* Og = reinterpret_cast<st*>(p.o) + b * p.o_bs + (int64_t)qpos * p.o_rs + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                st t4[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) t4[r] = T::from_f32(oacc[db][4 * g + r] * inv);
+                *reinterpret_cast<uint2*>(Og + 32 * db + 8 * g + 4 * hh) = *reinterpret_cast<const uint2*>(t4);
+            }
+    }
+}
+
 }  // namespace
 
 // Called by m5_attention (attention.hip) for F16 / BF16 operands after argument validation.
@@ -351,7 +709,26 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     // -2 % at the NAR shape of one utterance, -25 % on the small one-off problems (AR prefill, speaker encoder: 3 us each),
     // +16 % at a batched group's 16 x 2240 rows and +10 % at the 5399-row long form -- so the product keeps one form.
 #ifdef M5_TOOLS
+    static const int sched = [] { const char* e = m5_tool_env("M5_ATTN_SCHED"); return e ? atoi(e) : 0; }();
     static const int khe = [] { const char* e = m5_tool_env("M5_ATTN_KH"); return e ? atoi(e) : 0; }();
+#define M5_A16S(TT, FMV) hipLaunchKernelGGL((attn16s_kernel<TT, FMV>), dim3((a->Sq + 127) / 128, a->H, a->B), dim3(256), 0, s, *a)
+#define M5_A16SA(AB) hipLaunchKernelGGL((attn16s_kernel<BF16T, 1, AB>), dim3((a->Sq + 127) / 128, a->H, a->B), dim3(256), 0, s, *a)
+    static const int abl = [] { const char* e = m5_tool_env("M5_ATTN_ABL"); return e ? atoi(e) : 0; }();
+    if (sched == 2 && abl >= 1 && abl <= 7 && dtype == M5_BF16) {
+        switch (abl) {
+            case 1: M5_A16SA(1); break;
+            case 2: M5_A16SA(2); break;
+            case 3: M5_A16SA(3); break;
+            case 4: M5_A16SA(4); break;
+            case 5: M5_A16SA(5); break;
+            case 6: M5_A16SA(6); break;
+            default: M5_A16SA(7); break;
+        }
+    } else
+    if (sched >= 1 && sched <= 2 && nw == 4 && var == 0) {
+        if (dtype == M5_F16) { if (sched == 2) M5_A16S(F16T, 1); else M5_A16S(F16T, 0); }
+        else { if (sched == 2) M5_A16S(BF16T, 1); else M5_A16S(BF16T, 0); }
+    } else
     if (khe == 2 && nw == 4 && var == 0) {
         if (dtype == M5_F16) M5_A16K(F16T);
         else M5_A16K(BF16T);

@@ -41,6 +41,7 @@ def case(name, B, H, Sq, Sk, causal=False, key_len=None):
     ref = torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, -1), v[:, :, :Sk].float())
     got = o[:, :Sq].view(B, Sq, H, 64).permute(0, 2, 1, 3).float()
     err = (got - ref).abs().max().item()
+    csum = int(o[:, :Sq].contiguous().view(torch.int16).to(torch.int64).mul(torch.arange(1, B * Sq * D + 1, device=dev).view(B, Sq, D) % 8191 + 1).sum().item())
     with torch.cuda.stream(stream):
         ops.Graph.begin(st)
         for _ in range(REP):
@@ -56,7 +57,7 @@ def case(name, B, H, Sq, Sk, causal=False, key_len=None):
         stream.synchronize()
     us = e0.elapsed_ms(e1) * 1e3 / (5 * REP)
     fl = 4.0 * B * H * Sq * Sk * 64 * (0.5 if causal else 1.0)
-    print(f"{name:28s} B={B} H={H} Sq={Sq} Sk={Sk}  {us:8.2f} us  {fl / us / 1e6:7.1f} TF  maxerr={err:.4g}", flush=True)
+    print(f"{name:28s} B={B} H={H} Sq={Sq} Sk={Sk}  {us:8.2f} us  {fl / us / 1e6:7.1f} TF  maxerr={err:.4g} csum={csum}", flush=True)
 
 if __name__ == "__main__":
     if os.environ.get("CASES"):            # CASES="B,H,Sq,Sk;B,H,Sq,Sk;..." : grid-shape experiments
