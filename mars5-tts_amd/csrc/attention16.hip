@@ -337,42 +337,6 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE <= 4 ? 2 : 1) void attn16_kernel(
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// attn16s_kernel (round 6): the SAME arithmetic as attn16_kernel<T, 4, 0, 1> -- same fragments, same fma / exp2 / sum order,
-// bit-identical output -- with the instruction stream of a key tile laid out by hand (sched_barrier between small groups)
-// instead of leaving three big blocks to the scheduler.  What the compiler made of the kernel above: the 8 S^T MFMAs of tile
-// t+1 back to back (the wave sits at each until the matrix pipe frees: ~256 cycles in which it issues nothing else), then the
-// 17-deep max chain, then exp / PV, then a 16-deep dependent v_pk_add chain with s_nops AFTER the last PV MFMA, then the
-// barrier and ~45 instructions of DMA issue in front of the next S^T block -- ~500 cycles per tile with the matrix pipe idle
-// and nothing overlapping the VALU.  Here: one MFMA every 4-8 other instructions through the whole tile --
-//   phase 1: the 8 S^T MFMAs of tile t+1 interleaved with tile t's max chain, the lane^32 exchange, alpha, the DMA issue of
-//            tile t+2 and the V^T fragment reads of tile t;
-//   phase 2: per 8-key block {8 fma, 8 exp2, 8 row-sum adds, 4 cvt_pk} then its 2 PV MFMAs (the row sums ride with the exps:
-//            no dependent chain at the end of the tile);
-// the DMA of all tiles but the last takes a path without the per-row clamp, m0 is saved once per four pieces.
-// FM = 1: the fma / add of the softmax as single v_fma_f32 / v_add_f32 (asm) -- MI355X_MICROARCH.md prices packed f32 VALU
-// beside MFMAs at +22..26 cycles per instruction over the two scalar ones; FM = 0 leaves the choice to the compiler.
-__device__ inline void glds16x4(const unsigned char* g0, const unsigned char* g1, const unsigned char* g2, const unsigned char* g3,
-                                uint32_t lds_base) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
-                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g0), "v"(g1), "v"(g2), "v"(g3), "s"(lds_base) : "memory", "scc");
-}
-template <int FM>
-__device__ inline float sm_fma(float a, float b, float c) {
-    if constexpr (FM == 1) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
-    else return __builtin_fmaf(a, b, c);
-}
-template <int FM>
-__device__ inline float sm_add(float a, float b) {
-    if constexpr (FM == 1) { float d; asm("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-    else return a + b;
-}
 #define M5_SB() __builtin_amdgcn_sched_barrier(0)
 // two fp32 values -> one dword of two operand-type values, round to nearest even (one v_cvt_pk_*: the same values as two T::from_f32)
 template <typename T>
@@ -392,18 +356,72 @@ __device__ inline uint32_t pack2<F16T>(float a, float b) {
     return *reinterpret_cast<const uint32_t*>(&r);
 }
 
-// ABL (tools, timing only, WRONG results unless noted): 1 no per-tile DMA, 2 no per-tile barrier, 3 no softmax fma / exp / sum, 4 no S^T MFMAs,
-// 5 no PV MFMAs, 6 (correct) the four DMA pieces of a tile issued one per 8-key block of phase 2, 7 = 1 + 2
-template <typename T, int FM, int ABL = 0>
-__global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
-    using st = typename T::storage;
-    constexpr int NJ = 4;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NST * STAGE_B];
+// ---------------------------------------------------------------------------------------------------------------------
+// attn16w_kernel (round 6): attn16_kernel<T, 4, 0, 1>'s arithmetic -- same fragments, same fma / exp2 / row-sum order, bit-identical
+// output (tools/attn_bench.py csum) -- with the operand traffic taken off the computing waves and the tile loop laid out by hand.
+//
+// Why.  Ablations of the tile loop (profiles/r6k_attn_tile_loop_ablation.txt): dropping the four LDS-DMA instructions a wave issues
+// per key tile -- 4 KB of the 16 -- buys as much as dropping the whole softmax (-17 % at the NAR shape, -22 % at a batched one): a
+// `global_load_lds_dwordx4` holds the issuing wave for 60-185 cycles wherever it is placed (MI355X_MICROARCH.md, "LDS-DMA piece issue
+// cost"; moving the pieces into the softmax phase was slower still), and the per-tile barrier makes every wave pay the slowest one's.
+// Instruction rates (tools/probes/valu_rate.hip, profiles/r6j_valu_instruction_rates.txt): v_exp_f32 occupies the VALU 8.6 cycles,
+// v_max3 / v_cvt_pk / v_pk_* 4.7, v_fma / v_add 2.5; a lone wave issues one instruction per ~5.3 cycles -- the loop is issue-bound
+// per wave and the matrix pipe (512 of ~1900 cycles per tile) idles unless MFMAs are spread between the VALU work.
+//
+// What.  * A loader wave (the AR decode step's wave 7, csrc/ar_mega.hip): wave NCW alone requests K and V^T tiles -- scalar bases + two
+// lane-constant 32-bit offsets (saddr form: no per-piece VALU), m0 saved once per tile -- K three tiles and V^T two tiles ahead of
+// their use into two 3-slot rings (the same 48 KB), and joins the tile barrier once the next step's operands have landed (counted
+// vmcnt: the newest group stays in flight).  Waves 0..NCW-1 never touch the VM counter inside the loop.
+// * The tile loop as one hand-ordered stream (sched_barrier between small groups): the 8 S^T MFMAs of tile t+1 spread between tile
+// t's max chain, lane^32 exchange, alpha and the first 8-key block's exponentials; each PV MFMA followed by half of the next block's
+// {fma, exp2, row-sum add, cvt_pk} -- no MFMA waits on the matrix pipe behind another, no dependent add chain at the end of the tile
+// (what the compiler made of attn16_kernel: 8 S^T MFMAs back to back, then the max chain, then exp / PV, then 16 dependent v_pk_add
+// with s_nops, then barrier + 45 instructions of DMA issue: ~500 cycles per tile with the matrix pipe idle).
+// * The softmax's fma / add stay compiler-visible instructions: an inline-asm v_add_f32 that consumes a v_exp_f32 result does NOT
+// get the s_nop the hazard recogniser inserts between a transcendental and its VALU user on gfx950 (found the hard way: wrong row
+// sums in one of three inlined copies of the step).
+// the 8 pieces of one tile: scalar bases b0..b7 (rows 8q ..), lane offsets `ve` / `vo` for even / odd q, m0 saved once
+__device__ inline void glds16_tile(uint32_t ve, uint32_t vo, const unsigned char* b0, const unsigned char* b1, const unsigned char* b2,
+                                   const unsigned char* b3, const unsigned char* b4, const unsigned char* b5, const unsigned char* b6,
+                                   const unsigned char* b7, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %11\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %4\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %6\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %7\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %8\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %9\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %10\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(ve), "v"(vo), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(b4), "s"(b5), "s"(b6), "s"(b7), "s"(lds_addr)
+                 : "memory", "scc");
+}
+// s_barrier between compiler-level memory barriers (the builtin alone does not keep LDS reads on their side of it)
+__device__ inline void tile_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+constexpr int RING_B = 3 * TILE_B;               // K ring at 0, V^T ring behind it
+
+// NCW computing waves (32 query rows each) + the loader = wave NCW.  NCW = 3: 4-wave workgroups of 96 rows, two per CU at two waves
+// per SIMD (256 VGPRs each).  NCW = 4: 5-wave workgroups of 128 rows; two per CU need three waves on a SIMD = 168 VGPRs.
+template <typename T, int NCW, int DBG = 0>
+__device__ __forceinline__ void attn16w_body(const M5AttnArgs& p);
+template <typename T, int NCW, int WPE>
+__global__ __launch_bounds__((NCW + 1) * 64) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void attn16w_kernel(M5AttnArgs p) { attn16w_body<T, NCW>(p); }
+template <typename T, int NCW, int DBG>
+__device__ __forceinline__ void attn16w_body(const M5AttnArgs& p) {
+    constexpr int QB = 32 * NCW;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * RING_B];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hh = lane >> 5;
-    const int q0 = blockIdx.x * 128, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * QB, h = blockIdx.y, b = blockIdx.z;
     if (p.q_len && q0 >= p.q_len[b]) return;
     int kl = p.key_len ? p.key_len[b] : p.Sk;
     kl = min(kl, p.Sk);
@@ -415,53 +433,78 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
     }
     const unsigned char* Kg = (const unsigned char*)p.k + (koff + b * p.k_bs + h * p.k_hs) * 2;
     const unsigned char* Vg = (const unsigned char*)p.vt + (voff + b * p.vt_bs + h * p.vt_hs) * 2;
-    const unsigned char* Qg = (const unsigned char*)p.q + (b * p.q_bs + h * p.q_hs) * 2;
-
     int ntiles = (kl + KT - 1) / KT;
-    if (p.causal) ntiles = min(ntiles, (min(q0 + 128, p.Sq) - 1) / KT + 1);
+    if (p.causal) ntiles = min(ntiles, (min(q0 + QB, p.Sq) - 1) / KT + 1);
+    if (ntiles <= 0) ntiles = 0;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 
+    if (wave == NCW) {
+        // ---------------- loader ----------------
+        // piece q (0..7) of a tile = its rows 8q .. 8q+7: lane -> row 8q + (lane >> 3), 16-byte chunk (lane & 7) ^ ((row >> 1) & 7);
+        // (row >> 1) & 7 = (4 (q & 1) + (lane >> 4)) & 7: two lane-constant offsets per operand (q even / odd)
+        const int srow = lane >> 3;
+        uint32_t kvo[2], vvo[2];
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int chunk = (lane & 7) ^ ((4 * par + (srow >> 1)) & 7);
+            kvo[par] = (uint32_t)(srow * p.k_rs * 2 + chunk * 16);
+            vvo[par] = (uint32_t)((int64_t)srow * p.vt_ds * 2 + chunk * 16);
+        }
+        const int64_t k8 = (int64_t)8 * p.k_rs * 2, v8 = (int64_t)8 * p.vt_ds * 2;
+        auto load_k = [&](int t) {
+            const uint32_t sb = lds_base + (t % 3) * TILE_B;
+            if ((t + 1) * KT <= p.Sk) {
+                const unsigned char* base = Kg + (int64_t)t * KT * p.k_rs * 2;
+                glds16_tile(kvo[0], kvo[1], base, base + k8, base + 2 * k8, base + 3 * k8, base + 4 * k8, base + 5 * k8, base + 6 * k8,
+                            base + 7 * k8, sb);
+            } else {                                              // rows past Sk - 1 read row Sk - 1 (valid memory; masked by index)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int row = min(t * KT + 8 * q + srow, p.Sk - 1);
+                    const int chunk = (lane & 7) ^ ((4 * (q & 1) + (srow >> 1)) & 7);
+                    glds16(Kg + (int64_t)row * p.k_rs * 2 + chunk * 16, sb + q * 1024);
+                }
+            }
+        };
+        auto load_v = [&](int t) {
+            const uint32_t sb = lds_base + RING_B + (t % 3) * TILE_B;
+            const unsigned char* base = Vg + (int64_t)t * KT * 2;
+            glds16_tile(vvo[0], vvo[1], base, base + v8, base + 2 * v8, base + 3 * v8, base + 4 * v8, base + 5 * v8, base + 6 * v8,
+                        base + 7 * v8, sb);
+        };
+        if (ntiles == 0) return;
+        // prologue groups: {K0} {K1, V0} {K2, V1}; step kt then issues {K(kt+3), V(kt+2)}
+        load_k(0);
+        if (ntiles > 1) load_k(1);
+        load_v(0);
+        if (ntiles > 2) load_k(2);
+        if (ntiles > 1) load_v(1);
+        // K0 landed (everything younger may stay in flight when all three groups are whole)
+        if (ntiles > 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tile_barrier();
+        for (int kt = 0; kt + 1 < ntiles; ++kt) {
+            // top of step kt: K(kt+1) and V(kt) landed; the group issued during step kt-1 ({K(kt+2), V(kt+1)}, whole iff kt+2 < ntiles)
+            // may stay in flight
+            if (kt + 2 < ntiles) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tile_barrier();
+            if (kt + 3 < ntiles) load_k(kt + 3);                 // into the slot of K(kt): consumed in step kt-1
+            if (kt + 2 < ntiles) load_v(kt + 2);                 // into the slot of V(kt-1)
+        }
+        // the last tile's step has no barrier; its V^T tile was waited for above when ntiles > 1 ...
+        return;
+    }
+
+    // ---------------- compute waves ----------------
+    using st = typename T::storage;
+    const unsigned char* Qg = (const unsigned char*)p.q + (b * p.q_bs + h * p.q_hs) * 2;
     const int qpos = q0 + wave * 32 + l31;
     const int qrow = min(qpos, p.Sq - 1);
     uint4 qf[4];
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds)
         qf[ds] = *reinterpret_cast<const uint4*>(Qg + ((int64_t)qrow * p.q_rs + ds * 16 + hh * 8) * 2);
-
-    // DMA assignment: as attn16_kernel (instruction q = 4 wave + j: waves 0, 1 bring the K rows, waves 2, 3 the V^T rows)
-    const int srow = lane >> 3;
-    const unsigned char* gcur[NJ];
-    const unsigned char* klast[NJ];
-    int krow_of[NJ];
-    const bool kwave = wave < 2;                                  // wave-uniform
-    const int64_t gstep = kwave ? (int64_t)KT * p.k_rs * 2 : (int64_t)KT * 2;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int q = wave * NJ + j;
-        const int row = (q & 7) * 8 + srow;
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        if (kwave) {
-            gcur[j] = Kg + (int64_t)row * p.k_rs * 2 + chunk * 16;
-            klast[j] = Kg + (int64_t)(p.Sk - 1) * p.k_rs * 2 + chunk * 16;
-            krow_of[j] = row;
-        } else {
-            gcur[j] = Vg + (int64_t)row * p.vt_ds * 2 + chunk * 16;
-            klast[j] = gcur[j];
-            krow_of[j] = -(1 << 30);
-        }
-    }
-    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    auto stage_load = [&](int stage, int kt) {                   // called with kt = 0, 1, 2, ... in order
-        const uint32_t sb = lds_base + stage * STAGE_B + wave * NJ * 1024;
-        if ((kt + 1) * KT <= p.Sk) {                              // no row of this tile is past the end (wave-uniform)
-            glds16x4(gcur[0], gcur[1], gcur[2], gcur[3], sb);
-        } else {
-            const int over = kt * KT - p.Sk;
-            glds16x4((krow_of[0] + over >= 0) ? klast[0] : gcur[0], (krow_of[1] + over >= 0) ? klast[1] : gcur[1],
-                     (krow_of[2] + over >= 0) ? klast[2] : gcur[2], (krow_of[3] + over >= 0) ? klast[3] : gcur[3], sb);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) gcur[j] += gstep;
-    };
 
     const int krow = (l31 & 0x13) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
     int koffs[2][4];
@@ -478,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int row = l31 + 32 * db;
-            voffs[db][c] = TILE_B + row * 128 + (((2 * c + hh) ^ ((row >> 1) & 7)) << 4);
+            voffs[db][c] = RING_B + row * 128 + (((2 * c + hh) ^ ((row >> 1) & 7)) << 4);
         }
 
     f16_t oacc[2];
@@ -490,10 +533,6 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
     const float sc2 = p.scale * 1.4426950408889634f;
 
     auto ld = [&](const unsigned char* sb, int off) { return *reinterpret_cast<const uint4*>(sb + off); };
-    auto qk = [&](const uint4& a, const uint4& bq, f16_t c) -> f16_t {
-        if constexpr (ABL == 4) { c[0] += __uint_as_float(a.x); return c; }
-        else return mfma32<T>(a, bq, c);
-    };
     auto mask_tile = [&](int kt, f16_t (&s)[2]) {
         const int kbase = kt * KT;
         const bool need_mask = (kbase + KT > kl) || (p.causal && kbase + KT - 1 > q0 + wave * 32);
@@ -508,7 +547,6 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
                 }
         }
     };
-    // tile statistics once the 32 scores' maximum `mx` of this lane is known: m_new, alpha, -m_use
     float alpha, mneg, m_new;
     auto stats = [&](float mx) {
         mx = fmaxf(mx, lane_xor32(mx)) * sc2;
@@ -525,57 +563,46 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
                 for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         }
     };
-    float ps0, ps1;                                               // row-sum partials (even / odd registers, attn16_kernel's order)
-    // one 8-key block of P^T: scores -> probabilities (kept in s for nothing: only the packed operand is used)
-    auto p_block = [&](f16_t (&s)[2], int kb, int m) -> uint4 {
-        uint32_t w[4];
+    float ps0, ps1;
+    // half (two dwords = four keys) of one 8-key block of P^T
+    auto p_half = [&](f16_t (&s)[2], int blk, int half, uint32_t (&w)[4]) {
+        const int kb = blk >> 1, m = blk & 1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (ABL == 3) { w[j] = pack2<T>(s[kb][8 * m + 2 * j], s[kb][8 * m + 2 * j + 1]); continue; }
-            const float e0 = __builtin_amdgcn_exp2f(sm_fma<FM>(s[kb][8 * m + 2 * j], sc2, mneg));
-            const float e1 = __builtin_amdgcn_exp2f(sm_fma<FM>(s[kb][8 * m + 2 * j + 1], sc2, mneg));
-            ps0 = sm_add<FM>(ps0, e0);
-            ps1 = sm_add<FM>(ps1, e1);
+        for (int j = 2 * half; j < 2 * half + 2; ++j) {
+            const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * m + 2 * j], sc2, mneg));
+            const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][8 * m + 2 * j + 1], sc2, mneg));
+            ps0 += e0;
+            ps1 += e1;
             w[j] = pack2<T>(e0, e1);
         }
-        return make_uint4(w[0], w[1], w[2], w[3]);
     };
-    uint32_t dma_sb = 0;                                          // ABL 6: LDS base of the tile being fetched (0 = none)
-    bool dma_slow = false;
-    int dma_over = 0;
-    auto pv_phase = [&](const unsigned char* sbc, f16_t (&cur)[2], uint4 (&va)[2][4]) {
-        ps0 = 0.f;
-        ps1 = 0.f;
+    // blocks 1..3 and the PV MFMAs of all four; block 0's operand arrives in w0 (built under the S^T MFMAs)
+    auto pv_phase = [&](f16_t (&cur)[2], uint4 (&va)[2][4], uint32_t (&w0)[4]) {
+        uint32_t wa[4], wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wa[j] = w0[j];
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
-            const uint4 pb = p_block(cur, blk >> 1, blk & 1);
+            uint32_t (&wc)[4] = (blk & 1) ? wb : wa;
+            uint32_t (&wn)[4] = (blk & 1) ? wa : wb;
+            const uint4 pb = make_uint4(wc[0], wc[1], wc[2], wc[3]);
+            oacc[0] = mfma32<T>(va[0][blk], pb, oacc[0]);
             M5_SB();
-            if constexpr (ABL == 6) {
-                if (dma_sb) {
-                    glds16((dma_slow && krow_of[blk] + dma_over >= 0) ? klast[blk] : gcur[blk], dma_sb + blk * 1024);
-                    gcur[blk] += gstep;
-                }
-                M5_SB();
-            }
-            if constexpr (ABL != 5) {
-                oacc[0] = mfma32<T>(va[0][blk], pb, oacc[0]);
-                oacc[1] = mfma32<T>(va[1][blk], pb, oacc[1]);
-            } else {
-                oacc[0][blk] += __uint_as_float(pb.x);
-            }
+            if (blk < 3) p_half(cur, blk + 1, 0, wn);
+            M5_SB();
+            oacc[1] = mfma32<T>(va[1][blk], pb, oacc[1]);
+            M5_SB();
+            if (blk < 3) p_half(cur, blk + 1, 1, wn);
             M5_SB();
         }
         l_run = l_run * alpha + (ps0 + ps1);
         m_run = m_new;
     };
 
-    if (ntiles > 0) stage_load(0, 0);
-    if (ntiles > 1) stage_load(1, 1);
     f16_t sA[2], sB[2];
     if (ntiles > 0) {
-        if (ntiles > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NJ) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the Q fragments (the only VM operations of a computing wave)
+        tile_barrier();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -584,20 +611,19 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
             for (int ds = 0; ds < 4; ++ds) sA[kb] = mfma32<T>(ld(lds, koffs[kb][ds]), qf[ds], sA[kb]);
         }
     }
-    int slot = 0;
-    // tile kt (scores in cur) with a tile kt+1 behind it
+    int slot = 0;                                                // ring slot of tile kt (both rings)
     auto full = [&](int kt, f16_t (&cur)[2], f16_t (&nxt)[2]) {
         const int s1 = (slot == 2) ? 0 : slot + 1;
-        const unsigned char* sbc = lds + slot * STAGE_B;
-        const unsigned char* sbn = lds + s1 * STAGE_B;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // tile kt+1 (the only DMA in flight) landed
-        if constexpr (ABL != 2 && ABL != 7) __builtin_amdgcn_s_barrier();       // ... for every wave; tile kt-1 fully consumed
+        const unsigned char* sbc = lds + slot * TILE_B;          // + voffs: V^T(kt)
+        const unsigned char* sbn = lds + s1 * TILE_B;            // + koffs: K(kt+1)
+        tile_barrier();                            // K(kt+1), V^T(kt) landed (the loader waited); tile kt-1 fully consumed
         M5_SB();
+        // fragment registers: at most two quads (32 VGPRs) live at a time -- K d-slices 0, 1 -> K d-slices 2, 3 -> V^T keys 0..31 -> 32..63
+        // (the whole kernel has to fit 168 VGPRs: three waves per SIMD = two 5-wave workgroups per CU)
         uint4 ka[2][4], va[2][4];
+        uint32_t w0[4];
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds)
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) ka[kb][ds] = ld(sbn, koffs[kb][ds]);
+        for (int ds = 0; ds < 2; ++ds) { ka[0][ds] = ld(sbn, koffs[0][ds]); ka[1][ds] = ld(sbn, koffs[1][ds]); }
         M5_SB();
         mask_tile(kt, cur);
         float mx = fmaxf(cur[0][0], cur[1][0]);
@@ -606,54 +632,54 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
         M5_SB();
 #pragma unroll
         for (int r = 0; r < 16; ++r) { nxt[0][r] = 0.f; nxt[1][r] = 0.f; }
-        nxt[0] = qk(ka[0][0], qf[0], nxt[0]);
+        nxt[0] = mfma32<T>(ka[0][0], qf[0], nxt[0]);
         M5_SB();
+#pragma unroll
+        for (int ds = 2; ds < 4; ++ds) { ka[0][ds] = ld(sbn, koffs[0][ds]); ka[1][ds] = ld(sbn, koffs[1][ds]); }
 #pragma unroll
         for (int r = 8; r < 12; ++r) mx = fmaxf(fmaxf(mx, cur[0][r]), cur[1][r]);
         M5_SB();
-        nxt[1] = qk(ka[1][0], qf[0], nxt[1]);
+        nxt[1] = mfma32<T>(ka[1][0], qf[0], nxt[1]);
         M5_SB();
 #pragma unroll
         for (int r = 12; r < 16; ++r) mx = fmaxf(fmaxf(mx, cur[0][r]), cur[1][r]);
         M5_SB();
-        nxt[0] = qk(ka[0][1], qf[1], nxt[0]);
-        M5_SB();
-#pragma unroll
-        for (int c = 0; c < 2; ++c) { va[0][c] = ld(sbc, voffs[0][c]); va[1][c] = ld(sbc, voffs[1][c]); }
-        M5_SB();
-        nxt[1] = qk(ka[1][1], qf[1], nxt[1]);
+        nxt[0] = mfma32<T>(ka[0][1], qf[1], nxt[0]);
         M5_SB();
         stats(mx);
         M5_SB();
-        nxt[0] = qk(ka[0][2], qf[2], nxt[0]);
+        nxt[1] = mfma32<T>(ka[1][1], qf[1], nxt[1]);
         M5_SB();
-        if constexpr (ABL == 6) {
-            dma_sb = (kt + 2 < ntiles) ? lds_base + (slot == 0 ? 2 : slot - 1) * STAGE_B + wave * NJ * 1024 : 0;
-            dma_slow = (kt + 3) * KT > p.Sk;
-            dma_over = (kt + 2) * KT - p.Sk;
-        } else if constexpr (ABL != 1 && ABL != 7) {
-            if (kt + 2 < ntiles) stage_load(slot == 0 ? 2 : slot - 1, kt + 2);       // into the slot tile kt-1 used
-        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) { va[0][c] = ld(sbc, voffs[0][c]); va[1][c] = ld(sbc, voffs[1][c]); }
+        ps0 = 0.f;
+        ps1 = 0.f;
+        p_half(cur, 0, 0, w0);
         M5_SB();
-        nxt[1] = qk(ka[1][2], qf[2], nxt[1]);
+        nxt[0] = mfma32<T>(ka[0][2], qf[2], nxt[0]);
+        M5_SB();
+        p_half(cur, 0, 1, w0);
+        M5_SB();
+        nxt[1] = mfma32<T>(ka[1][2], qf[2], nxt[1]);
+        M5_SB();
+        rescale();
+        M5_SB();
+        nxt[0] = mfma32<T>(ka[0][3], qf[3], nxt[0]);
+        nxt[1] = mfma32<T>(ka[1][3], qf[3], nxt[1]);
         M5_SB();
 #pragma unroll
         for (int c = 2; c < 4; ++c) { va[0][c] = ld(sbc, voffs[0][c]); va[1][c] = ld(sbc, voffs[1][c]); }
         M5_SB();
-        nxt[0] = qk(ka[0][3], qf[3], nxt[0]);
-        M5_SB();
-        rescale();
-        M5_SB();
-        nxt[1] = qk(ka[1][3], qf[3], nxt[1]);
-        M5_SB();
-        pv_phase(sbc, cur, va);
+        pv_phase(cur, va, w0);
         slot = s1;
     };
-    // the last tile
     auto last = [&](int kt, f16_t (&cur)[2]) {
-        const unsigned char* sbc = lds + slot * STAGE_B;
-        dma_sb = 0;
+        const unsigned char* sbc = lds + slot * TILE_B;
         uint4 va[2][4];
+        uint32_t w0[4];
+        if (kt == 0) {                                           // a single tile: its V^T was not waited for by any step barrier
+            // (the loader waited vmcnt(0) before the prologue barrier when ntiles <= 2)
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) { va[0][c] = ld(sbc, voffs[0][c]); va[1][c] = ld(sbc, voffs[1][c]); }
         mask_tile(kt, cur);
@@ -662,7 +688,11 @@ __global__ __launch_bounds__(256, 2) void attn16s_kernel(M5AttnArgs p) {
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, cur[0][r]), cur[1][r]);
         stats(mx);
         rescale();
-        pv_phase(sbc, cur, va);
+        ps0 = 0.f;
+        ps1 = 0.f;
+        p_half(cur, 0, 0, w0);
+        p_half(cur, 0, 1, w0);
+        pv_phase(cur, va, w0);
     };
     if (ntiles > 0) {
         int kt = 0;
@@ -708,27 +738,28 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     // Key-half split (KH = 2, see the header): tools only (M5_ATTN_KH=2).  Measured (profiles/r3x_attn_key_half_split_ab.txt):
     // -2 % at the NAR shape of one utterance, -25 % on the small one-off problems (AR prefill, speaker encoder: 3 us each),
     // +16 % at a batched group's 16 x 2240 rows and +10 % at the 5399-row long form -- so the product keeps one form.
+    // Which form (the two produce the same bits -- tools/attn_bench.py csum, tests/test_gpu_kernels.py::test_attention_forms_bit_identical --
+    // so this is a scheduling decision only): the loader-wave kernel with 96-row workgroups while attn16_kernel's grid would leave
+    // the chip at <= 2 workgroups per CU (one utterance's NAR step: 352 workgroups -> 38.6 vs 33.4 us; speaker encoder / prefill
+    // shapes -13 %), attn16_kernel's 128-row workgroups, three per CU, beyond (16 x 2240 rows: 433 vs 472 us;
+    // profiles/r6o_attn_loader_wave.txt).
+    const int64_t wgs128 = (int64_t)((a->Sq + 127) / 128) * a->H * a->B;
+    bool loader_form = wgs128 <= 512;
+#define M5_A16W(TT, NCWV, WPEV) hipLaunchKernelGGL((attn16w_kernel<TT, NCWV, WPEV>), dim3((a->Sq + 32 * NCWV - 1) / (32 * NCWV), a->H, a->B), dim3(64 * (NCWV + 1)), 0, s, *a)
 #ifdef M5_TOOLS
-    static const int sched = [] { const char* e = m5_tool_env("M5_ATTN_SCHED"); return e ? atoi(e) : 0; }();
+    // M5_ATTN_SCHED: 0 = attn16_kernel always, 3 = loader form always, 5 = 4 computing waves + loader (one workgroup per CU), unset = product rule
+    static const int sched = [] { const char* e = m5_tool_env("M5_ATTN_SCHED"); return e ? atoi(e) : -1; }();
     static const int khe = [] { const char* e = m5_tool_env("M5_ATTN_KH"); return e ? atoi(e) : 0; }();
-#define M5_A16S(TT, FMV) hipLaunchKernelGGL((attn16s_kernel<TT, FMV>), dim3((a->Sq + 127) / 128, a->H, a->B), dim3(256), 0, s, *a)
-#define M5_A16SA(AB) hipLaunchKernelGGL((attn16s_kernel<BF16T, 1, AB>), dim3((a->Sq + 127) / 128, a->H, a->B), dim3(256), 0, s, *a)
-    static const int abl = [] { const char* e = m5_tool_env("M5_ATTN_ABL"); return e ? atoi(e) : 0; }();
-    if (sched == 2 && abl >= 1 && abl <= 7 && dtype == M5_BF16) {
-        switch (abl) {
-            case 1: M5_A16SA(1); break;
-            case 2: M5_A16SA(2); break;
-            case 3: M5_A16SA(3); break;
-            case 4: M5_A16SA(4); break;
-            case 5: M5_A16SA(5); break;
-            case 6: M5_A16SA(6); break;
-            default: M5_A16SA(7); break;
-        }
+    if (sched == 0 || nw != 4 || var != 0 || khe == 2) loader_form = false;
+    if (sched == 3) loader_form = true;
+    if (sched == 5 && nw == 4 && var == 0) {
+        if (dtype == M5_F16) M5_A16W(F16T, 4, 2); else M5_A16W(BF16T, 4, 2);
     } else
-    if (sched >= 1 && sched <= 2 && nw == 4 && var == 0) {
-        if (dtype == M5_F16) { if (sched == 2) M5_A16S(F16T, 1); else M5_A16S(F16T, 0); }
-        else { if (sched == 2) M5_A16S(BF16T, 1); else M5_A16S(BF16T, 0); }
+#endif
+    if (loader_form) {
+        if (dtype == M5_F16) M5_A16W(F16T, 3, 2); else M5_A16W(BF16T, 3, 2);
     } else
+#ifdef M5_TOOLS
     if (khe == 2 && nw == 4 && var == 0) {
         if (dtype == M5_F16) M5_A16K(F16T);
         else M5_A16K(BF16T);
@@ -755,6 +786,7 @@ int m5_attention16_dispatch(int dtype, const M5AttnArgs* a, hipStream_t s) {
     }
 #undef M5_A16
 #undef M5_A16K
+#undef M5_A16W
     M5_CHECK_LAUNCH();
     return M5_OK;
 }

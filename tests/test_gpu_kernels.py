@@ -617,6 +617,40 @@ def test_attention(dev, dt, B, H, Sq, Sk, kls, causal):
         assert r3 < max(4 * r, 2e-6), f"split-f16 attention rel err {r3} (exact {r})"
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("Sq,Sk,kl,causal", [(300, 1349, 1349, False), (333, 333, 333, True), (200, 700, 530, False), (97, 64, 64, False),
+                                             (130, 200, 129, False)])
+def test_attention_forms_bit_identical(dev, dt, Sq, Sk, kl, causal):
+    """The two 16-bit attention kernels (csrc/attention16.hip: attn16_kernel, 128-row workgroups that bring their own operands;
+    attn16w_kernel, 96-row workgroups with a loader wave and the hand-ordered tile loop) compute the same arithmetic in the same
+    order: the library picks by grid size only, so ONE problem (small grid: loader form) and the same problem as every sequence of
+    a 36-sequence batch (large grid: attn16_kernel) must agree bit for bit -- which is also what keeps a batched NAR group equal to
+    its lone calls whichever side of the rule each lands on."""
+    from mars5_tts_amd import _lib as L, ops
+    H, NB = 16, 36
+    assert (Sq + 127) // 128 * H * 1 <= 512 < (Sq + 127) // 128 * H * NB
+    q, k, v = _rand((1, H, Sq, 64), 11, 2.0), _rand((1, H, Sk, 64), 12, 2.0), _rand((1, H, Sk, 64), 13)
+    Skp = (Sk + 63) // 64 * 64
+    vt = torch.zeros(1, H, 64, Skp)
+    vt[..., :Sk] = v.transpose(-1, -2)
+    outs = []
+    for B in (1, NB):
+        qd, kd, vtd = (t.to(dev, dt).expand(B, *t.shape[1:]).contiguous() for t in (q, k, vt))
+        o = torch.zeros(B, Sq, H * 64, device=dev, dtype=dt)
+        kls = torch.full((B,), kl, dtype=torch.int32, device=dev)
+        a = L.AttnArgs(q=qd.data_ptr(), q_bs=H * Sq * 64, q_hs=Sq * 64, q_rs=64, k=kd.data_ptr(), k_bs=H * Sk * 64, k_hs=Sk * 64, k_rs=64,
+                       vt=vtd.data_ptr(), vt_bs=H * 64 * Skp, vt_hs=64 * Skp, vt_ds=Skp, o=o.data_ptr(), o_bs=Sq * H * 64, o_rs=H * 64,
+                       B=B, H=H, Sq=Sq, Sk=Sk, key_len=kls.data_ptr(), causal=1 if causal else 0, scale=0.125, kv_index=None,
+                       kv_index_stride_k=0, kv_index_stride_v=0)
+        ops.attention(dt, a)
+        torch.cuda.synchronize()
+        outs.append(o.cpu())
+    ref = _ref_attention(_q(q, dt), _q(k, dt), _q(v, dt), [kl], causal).permute(0, 2, 1, 3).reshape(1, Sq, H * 64)
+    assert _rel(outs[0].float(), ref) < 1e-2
+    for b in range(NB):
+        assert torch.equal(outs[1][b], outs[0][0]), f"sequence {b} of the batch differs from the lone call"
+
+
 def test_attention_kv_index(dev):
     from mars5_tts_amd import _lib as L, ops
     dt = torch.float32

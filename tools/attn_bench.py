@@ -27,6 +27,7 @@ def case(name, B, H, Sq, Sk, causal=False, key_len=None):
                    vt=vt.data_ptr(), vt_bs=H * 64 * Skr, vt_hs=64 * Skr, vt_ds=Skr, o=o.data_ptr(), o_bs=Sr * D, o_rs=D,
                    B=B, H=H, Sq=Sq, Sk=Sk, key_len=kl.data_ptr() if kl is not None else None, causal=1 if causal else 0,
                    scale=0.125, kv_index=None, kv_index_stride_k=0, kv_index_stride_v=0)
+    torch.cuda.synchronize()          # q / k / vt / the zero fill of o were enqueued on the default stream: without this the fill can land AFTER the kernel's stores
     stream = torch.cuda.Stream()
     st = stream.cuda_stream
     with torch.cuda.stream(stream):
@@ -42,6 +43,18 @@ def case(name, B, H, Sq, Sk, causal=False, key_len=None):
     got = o[:, :Sq].view(B, Sq, H, 64).permute(0, 2, 1, 3).float()
     err = (got - ref).abs().max().item()
     csum = int(o[:, :Sq].contiguous().view(torch.int16).to(torch.int64).mul(torch.arange(1, B * Sq * D + 1, device=dev).view(B, Sq, D) % 8191 + 1).sum().item())
+    if os.environ.get("STRESS"):          # the same launch N times: how many outputs differ from the first one's?
+        bad = 0
+        first = o.clone()
+        with torch.cuda.stream(stream):
+            for i in range(int(os.environ["STRESS"])):
+                o.zero_()
+                ops.attention(dt, a, stream=st)
+                stream.synchronize()
+                if not torch.equal(o, first):
+                    bad += 1
+        print(f"{name:28s} stress: {bad} of {os.environ['STRESS']} launches differ from the first (first maxerr {err:.4g})", flush=True)
+        return
     with torch.cuda.stream(stream):
         ops.Graph.begin(st)
         for _ in range(REP):
