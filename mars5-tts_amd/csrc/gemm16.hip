@@ -186,10 +186,20 @@ __device__ inline void wait_younger(int y, bool full_share) {
 // when the kernel merely grew from 2100 to 2500 instructions, and the "fixed" cost of a launch is ~10 us against 3.6 us for
 // hipBLASLt's kernels (profiles/r3m_*).  FAST compiles the fallbacks out: straight-line code, a fraction of the size.
 constexpr int DL_MAX_NP = 8;                      // deferred LayerNorm: at most 8 column tiles of partials per row (D <= 8 x 128)
-template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, bool FAST = false, int DLN = 0>
-__global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_kernel(Gemm16Params p) {
+// LW (round 6, "loader waves"): the workgroup carries NW extra waves -- wave NW + w issues compute wave w's share of the LDS-DMA
+// pieces (and nothing else), waits for them with the counted vmcnt and joins the K loop's barriers; the computing waves only
+// read fragments and issue MFMAs (their VM counter holds the epilogue's preloads alone).  Why: a `global_load_lds_dwordx4`
+// costs the wave that issues it 60-185 cycles among MFMAs and LDS reads (MI355X_MICROARCH.md; tools/probes/lds_dma_rate.hip:
+// a wave that does nothing else issues one per 45 cycles, a CU takes 59 B/clk from L2 with >= 4 waves issuing), the 96x128
+// region kernel stages 7 pieces per wave and K-step beside 24 MFMAs (384 cycles of matrix pipe): its K-step takes ~1040
+// cycles = 27 B/clk/CU, ~775 with the DMA removed (profiles/r3a_gemm_ablation.txt).  A loader wave beside each computing
+// wave on its SIMD issues them in parallel (different instruction class, different wave).
+template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, bool FAST = false, int DLN = 0,
+          bool LW = false>
+__global__ __launch_bounds__(WM * WN * 64 * (LW ? 2 : 1), (OCC * WM * WN * (LW ? 2 : 1) + 3) / 4) void gemm16_kernel(Gemm16Params p) {
     using st = typename T::storage;
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NW = WM * WN;
+    static_assert(!LW || (PF && DLN != 2), "loader waves: prefetched-fragment loop, no consumer-side LDS-DMA prologue");
     constexpr int STAGE = (BM + BN) * BKB;
     // DLN = 2 (consumer): behind the stages, the tile's BM x np partial pairs (LDS-DMA'd in front of the operand stages) and
     // the per-row {d, r} derived from them.  DLN = 1 (producer): the per-wave row sums that the WN waves of a row exchange.
@@ -209,7 +219,9 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
     unsigned char* const dl_lds = lds + NSTAGE * STAGE;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_raw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW && wave_raw >= NW;          // wave-uniform; a loader wave takes computing wave (wave_raw - NW)'s DMA share
+    const int wave = loader ? wave_raw - NW : wave_raw;
     const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, lg = lane >> 4;
 #ifdef M5_TOOLS
@@ -532,18 +544,53 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const uint4*>(sb + w_row0 + j * 16 * BKB + foff[ks]);
         };
+        if (!LW || loader) {
 #pragma unroll
         for (int sgi = 0; sgi < NSTAGE; ++sgi)
             if (sgi < nk) {
 #pragma unroll
                 for (int j = 0; j < JN; ++j) piece(j, Au + (int64_t)sgi * BKB, Wu + (int64_t)sgi * BKB, lds_base + sgi * STAGE + wave * 1024);
             }
+        }
+        if constexpr (LW) {
+            if (loader) {
+                // the loader's K loop: the computing waves' barriers, one for one (kstep below), the counted waits and the refills
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * JN) : "memory");       // K-step 0 has landed (all NSTAGE stages are whole
+                if (nk < NSTAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // ... unless the problem is shorter)
+                __syncthreads();
+                int slot = 0, kt = 0;
+                auto lstep = [&](int kt_, auto y_tag, auto refill_tag) {
+                    constexpr int Y = decltype(y_tag)::value;
+                    constexpr bool REFILL = decltype(refill_tag)::value;
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Y * JN) : "memory");
+                    __syncthreads();
+                    if constexpr (REFILL) {
+                        const unsigned char* sA = Au + (int64_t)(kt_ + NSTAGE) * BKB;
+                        const unsigned char* sW = Wu + (int64_t)(kt_ + NSTAGE) * BKB;
+                        const uint32_t sbase = lds_base + slot * STAGE + wave * 1024;
+#pragma unroll
+                        for (int j = 0; j < JN; ++j) piece(j, sA, sW, sbase);
+                    }
+                    slot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
+                };
+                for (; kt + NSTAGE < nk; ++kt) lstep(kt, std::integral_constant<int, NSTAGE - 2>{}, std::true_type{});
+                auto ltail = [&](auto r_tag) {
+                    constexpr int R = decltype(r_tag)::value;
+                    if (nk - 1 - kt == R) { lstep(kt, std::integral_constant<int, (R - 1 < NSTAGE - 2 ? R - 1 : NSTAGE - 2)>{}, std::false_type{}); ++kt; }
+                };
+                if constexpr (NSTAGE >= 5) ltail(std::integral_constant<int, 4>{});
+                if constexpr (NSTAGE >= 4) ltail(std::integral_constant<int, 3>{});
+                if constexpr (NSTAGE >= 3) ltail(std::integral_constant<int, 2>{});
+                ltail(std::integral_constant<int, 1>{});
+                return;
+            }
+        }
         // old C and bias are requested BEHIND the operand stages (the VM counter retires in order: in front of them, the first
         // MFMA would wait for 11.5 MB of cold fp32 residual).  These loads are younger than K-step 0, so the counted wait
         // below over-waits a little on the first K-step only -- never under-waits.
         preload_c();
         if constexpr (HOIST_B && DLN != 2) load_bias();
-        wait_younger<NSTAGE - 1, JN>(min(NSTAGE - 1, nk - 1), true);             // K-step 0 has landed
+        if constexpr (!LW) wait_younger<NSTAGE - 1, JN>(min(NSTAGE - 1, nk - 1), true);             // K-step 0 has landed
         __syncthreads();
         uint4 af0[TM], bf0[TN], af1[TM], bf1[TN];
         read_frags(lds, 0, af0, bf0);
@@ -563,7 +610,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
             mfma_block(af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
             const int nslot = (slot + 1 == NSTAGE) ? 0 : slot + 1;
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Y * JN) : "memory");
+            if constexpr (!LW) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Y * JN) : "memory");
             __syncthreads();
             read_frags(lds + nslot * STAGE, 0, af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
@@ -576,7 +623,7 @@ __global__ __launch_bounds__(WM * WN * 64, (OCC * WM * WN + 3) / 4) void gemm16_
                 for (int j = 0; j < TN; ++j) {
                     if (EPI == M5_EPI_QKV && vblock) acc[i][j] = mfma16<T>(af1[i], bf1[j], acc[i][j]);
                     else acc[i][j] = mfma16<T>(bf1[j], af1[i], acc[i][j]);
-                    if constexpr (REFILL) {
+                    if constexpr (REFILL && !LW) {
                         if (i * TN + j < JN) {
                             piece(i * TN + j, sA, sW, sbase);
                             __builtin_amdgcn_sched_barrier(0);
@@ -1402,9 +1449,11 @@ constexpr bool fast_ok(int E, int WM, int WN, int TM, int TN, int BKB, int NSTAG
 
 // Deferred-LayerNorm instantiations (DLN = 1: residual producer; DLN = 2: QKV / SwiGLU consumers) exist for the tilings the
 // engines' shapes use (DLNC: bit 0 = producer, bit 1 = consumers); anything else answers M5_ERR_UNSUPPORTED.
-template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, int DLNC = 0, int ONLY = -1>
+template <typename T, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, int DLNC = 0, int ONLY = -1, bool LW = false>
 int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = false, int dln = 0) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    static_assert(!LW || ONLY == M5_EPI_RESIDUAL, "loader waves: instantiated for the residual epilogue only");
+    if (LW && !fast) return M5_ERR_UNSUPPORTED;
     if (ONLY >= 0 && epi != ONLY) return M5_ERR_UNSUPPORTED;        // a tiling instantiated for one epilogue only (compile time)
     if (dln) {
         if (!fast) return M5_ERR_UNSUPPORTED;
@@ -1414,11 +1463,11 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = fal
         if (nb > 0x7fffffff) return M5_ERR_UNSUPPORTED;
         p.nblk = (int)nb;
         p.group_m = max(1, GROUP_M * 128 / BM);
-        const dim3 grid(p.nblk), blk(WM * WN * 64);
+        const dim3 grid(p.nblk), blk(WM * WN * 64 * (LW ? 2 : 1));
         if constexpr ((DLNC & 1) != 0 && fast_ok(M5_EPI_RESIDUAL, WM, WN, TM, TN, BKB, NSTAGE)) {
             if (dln == 1 && epi == M5_EPI_RESIDUAL) {
                 if (p.N % BN || p.dl_np != p.tilesN) return M5_ERR_UNSUPPORTED;       // one partial pair per (row, column tile)
-                hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_RESIDUAL, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, true, 1>), grid, blk, 0, s, p);
+                hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_RESIDUAL, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, true, 1, LW>), grid, blk, 0, s, p);
                 M5_CHECK_LAUNCH();
                 return M5_OK;
             }
@@ -1447,7 +1496,15 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = fal
     if (nblk > 0x7fffffff) return M5_ERR_UNSUPPORTED;
     p.nblk = (int)nblk;
     p.group_m = max(1, GROUP_M * 128 / BM);
-    const dim3 grid(p.nblk), blk(WM * WN * 64);
+    const dim3 grid(p.nblk), blk(WM * WN * 64 * (LW ? 2 : 1));
+    if constexpr (LW) {
+        if constexpr (fast_ok(M5_EPI_RESIDUAL, WM, WN, TM, TN, BKB, NSTAGE)) {
+            hipLaunchKernelGGL((gemm16_kernel<T, M5_EPI_RESIDUAL, WM, WN, TM, TN, BKB, NSTAGE, OCC, PF, true, 0, true>), grid, blk, 0, s, p);
+            M5_CHECK_LAUNCH();
+            return M5_OK;
+        }
+        return M5_ERR_UNSUPPORTED;
+    } else {
 #define M5_G16(E)                                                                                                          \
     do {                                                                                                                   \
         if constexpr (fast_ok(E, WM, WN, TM, TN, BKB, NSTAGE)) {                                                           \
@@ -1471,6 +1528,7 @@ int launch16(int epi, Gemm16Params& p, int batch, hipStream_t s, bool fast = fal
 #undef M5_G16
     M5_CHECK_LAUNCH();
     return M5_OK;
+    }
 }
 
 // Tile configurations.  M5_GEMM_CFG=<n> forces one (tuning sweeps); otherwise pick_config().
@@ -1492,6 +1550,7 @@ static const CfgInfo kCfg[] = {
     { 96, 128, 2, 1, 8.f, 0.48f, -2},             // 11 (tools build, round-6 probe): region 96x128 with EIGHT waves (2x4 of 48x32), 4 stages, one workgroup
                                                   //    per CU -- two waves per SIMD for the residual class.  Measured SLOWER than cfg 7 on every shape
                                                   //    (profiles/r6a_gemm_8wave_residual_region_negative.txt): 16.8 -> 18.4, 14.6 -> 16.0, 31.3 -> 37.1 us
+    { 96, 128, 4, 1, 8.f, 0.40f, -2},             // 12 (round 6): = 7 with LOADER WAVES (gemm16_kernel LW): 4 computing + 4 loader waves, residual epilogue only
 };
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
@@ -1507,6 +1566,7 @@ int launch_cfg(int cfg, int epi, Gemm16Params& p, int batch, hipStream_t s, bool
         case 6: return launch16<T, 2, 3, 6, 4, 128, 3, 1>(epi, p, batch, s, fast, dln);
         case 7: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true, 1>(epi, p, batch, s, fast, dln);
         case 8: return launch16<T, 2, 2, 3, 4, 128, 5, 1, true>(epi, p, batch, s, fast, dln);
+        case 12: return launch16<T, 2, 2, 3, 4, 128, 4, 1, true, 1, M5_EPI_RESIDUAL, true>(epi, p, batch, s, fast, dln);
 #ifdef M5_TOOLS
         case 11: return launch16<T, 2, 4, 3, 2, 128, 4, 1, false, 1, M5_EPI_RESIDUAL>(epi, p, batch, s, fast, dln);
         case 9: return launch16<T, 4, 4, 3, 6, 64, 4, 1>(epi, p, batch, s, fast, dln);
@@ -1802,6 +1862,9 @@ int m5_gemm16_dispatch(int dtype, const void* A, int64_t lda, const void* W, int
     else fast = fast && p.vec16;
     if (const char* fk = m5_tool_env("M5_GEMM_FAST")) { if (atoi(fk) == 0) fast = false; }      // same-process A/B (tools build)
     if (dln && !fast) return M5_ERR_UNSUPPORTED;
+    // the residual class on its 96x128 region: loader waves (cfg 12 = cfg 7 + 4 DMA-only waves; same MFMA order, same bits) whenever
+    // the FAST instantiation applies -- linear2 31.3 -> 28.8 us, out-proj 16.6 -> 16.2, M = 35,840 linear2 341 -> 330 (profiles/r6u_*)
+    if (cfg == 7 && forced < 0 && fast && epi == M5_EPI_RESIDUAL && dln != 2) cfg = 12;
     if (dtype == M5_F16) return launch_cfg<F16T>(cfg, epi, p, batch, s, fast, dln);
     return launch_cfg<BF16T>(cfg, epi, p, batch, s, fast, dln);
 }

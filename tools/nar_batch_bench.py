@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """NAR reverse-step cost against the number of utterances refined together (BASELINE config 3).
 usage: python tools/nar_batch_bench.py [U ...]   (default 1 2 4 8; all utterances S = 1349 unless MIXED=1)
+GRAPH=0: launches go out one by one (rocprofv3 cannot trace the 310-node batched graph).
 CONC=1: for every U also TWO sessions of U utterances each on two streams, steps enqueued alternately (two groups in flight)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -30,6 +31,7 @@ def main():
     Us = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
     mixed = os.environ.get("MIXED", "0") == "1"
     times = list(range(199, 179, -1))
+    use_graph = os.environ.get("GRAPH", "1") != "0"
     for U in Us:
         g = torch.Generator().manual_seed(11)
         items = []
@@ -44,12 +46,12 @@ def main():
         sess.prepare(items, times)
         gens = [torch.Generator(device=dev).manual_seed(u) for u in range(U)]
         unis = [(lambda shp, g=g_: torch.rand(shp, generator=g, device=dev)) for g_ in gens]
-        sess.run(unis, True, n_steps=3)
+        sess.run(unis, use_graph, n_steps=3)
         st = sess.stream.cuda_stream
         e0, e1 = ops.Event(), ops.Event()
         e0.record(st)
         n = 10
-        sess.run(unis, True, n_steps=n)
+        sess.run(unis, use_graph, n_steps=n)
         e1.record(st)
         sess.stream.synchronize()
         ms = e0.elapsed_ms(e1) / n
