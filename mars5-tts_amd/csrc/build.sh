@@ -10,7 +10,9 @@ build_one() {   # $1 = object dir, $2 = extra flags, $3 = output library
   mkdir -p $1
   pids=()
   for f in $SRCS; do
-    if [ ! -f $1/$f.o ] || [ $f.hip -nt $1/$f.o ] || [ common.h -nt $1/$f.o ] || [ philox.h -nt $1/$f.o ] || [ ../../include/mars5_hip.h -nt $1/$f.o ]; then
+    stale=0
+    for h in *.h ../../include/mars5_hip.h; do [ $h -nt $1/$f.o ] && stale=1; done
+    if [ ! -f $1/$f.o ] || [ $f.hip -nt $1/$f.o ] || [ $stale = 1 ]; then
       hipcc $FLAGS $2 -c $f.hip -o $1/$f.o &
       pids+=($!)
     fi
