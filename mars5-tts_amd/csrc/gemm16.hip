@@ -193,7 +193,8 @@ constexpr int DL_MAX_NP = 8;                      // deferred LayerNorm: at most
 // a wave that does nothing else issues one per 45 cycles, a CU takes 59 B/clk from L2 with >= 4 waves issuing), the 96x128
 // region kernel stages 7 pieces per wave and K-step beside 24 MFMAs (384 cycles of matrix pipe): its K-step takes ~1040
 // cycles = 27 B/clk/CU, ~775 with the DMA removed (profiles/r3a_gemm_ablation.txt).  A loader wave beside each computing
-// wave on its SIMD issues them in parallel (different instruction class, different wave).
+// wave on its SIMD issues them in parallel (different instruction class, different wave).  (Five stages behind the loader
+// waves change nothing, profiles/r6x_*: at ~31 B/clk/CU the K loop runs at the rate the L2s deliver 240 different tile pairs.)
 template <typename T, int EPI, int WM, int WN, int TM, int TN, int BKB, int NSTAGE, int OCC, bool PF = false, bool FAST = false, int DLN = 0,
           bool LW = false>
 __global__ __launch_bounds__(WM * WN * 64 * (LW ? 2 : 1), (OCC * WM * WN * (LW ? 2 : 1) + 3) / 4) void gemm16_kernel(Gemm16Params p) {
