@@ -775,14 +775,17 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     # the dominant kernel = the kernel NAME with the largest total, as rocprofv3 --stats groups them (all shapes of one epilogue)
     dom = max(cls.items(), key=lambda kv: kv[1]["ms"])
     mfma_bound = dom[1]["flops"] > 0
-    traffic = None
+    traffic, traffic_source = None, None
     try:        # HBM bytes per launch from the committed PMC passes (profiles/traffic.json), same shapes
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
         for k, v in tj.items():
             if isinstance(v, dict) and v.get("class") == dom[0] and dtype_name == "bf16":
                 traffic = v["bytes_per_launch"]
+                # counters cannot be read inside this run (rocprofv3 --pmc is its own process): the value is the committed PMC
+                # pass over this kernel class, and the line says so
+                traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.sh): " + str(v.get("measured", ""))[:160]
     except Exception:
-        traffic = None
+        traffic, traffic_source = None, None
     # Which roof bounds the class: its arithmetic intensity (algorithmic flops / algorithmic bytes, summed over the class's launches)
     # against the machine balance peak_flops / peak_bytes.  The residual-epilogue class reads and rewrites an fp32 C tile set (8 bytes
     # per output element, + 2 for the deferred LayerNorm's centred copy): K = 768 / 1024 launches sit at 125-160 flop/B, under the
@@ -801,7 +804,7 @@ def roofline_leg(m, ref_codes, cfg, dtype_name):
     mfma_bound = roof["bound"] == "mfma"
     sum_us = 1e3 * sum(ms for _, _, _, ms in per)
     fwd_flops = sum(fl for _, fl, _, _ in per)
-    roof.update(traffic=traffic, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_per_step=dom[1]["n"], timing=timing,
+    roof.update(traffic=traffic, traffic_source=traffic_source, avg_launch_us=round(1e3 * dom[1]["ms"] / dom[1]["n"], 2), launches_per_step=dom[1]["n"], timing=timing,
                 alg_per_launch=(dom[1]["flops"] if mfma_bound else dom[1]["bytes"]) / dom[1]["n"],
                 shapes={k: v["avg_us"] for k, v in kernels.items() if k.startswith(dom[0])},
                 forward_sum_of_intervals_us=round(sum_us, 1), forward_graph_replay_us=round(fwd_plain_us, 1),
