@@ -57,6 +57,9 @@ _MEGA_LOCKS_GUARD = threading.Lock()
 _MEGA_LAST: Dict[int, "torch.cuda.Event"] = {}
 
 
+GRAPH_GROUP = 8          # decode steps per replayed hipGraph (ARSession.capture)
+
+
 @contextlib.contextmanager
 def _mega_exclusive(stream: "torch.cuda.Stream", dev: torch.device):
     key = dev.index if dev.index is not None else torch.cuda.current_device()
@@ -335,16 +338,29 @@ class ARSession:
             L.check(rc, f"m5_ar_decode_step (op {int(self.step_plan._failed.value)})")
 
     def capture(self) -> None:
-        """Capture one decode step (layers + head + sampler) as a hipGraph."""
+        """Capture one decode step (layers + head + sampler) as a hipGraph, and GRAPH_GROUP consecutive steps as a second one:
+        positions, counters and RNG state live in device memory, so a graph of k steps IS k replays of the one-step graph --
+        without the ~10 us the GPU idles between two graph launches (profiles/r6ae_utterance_gpu_idle_gaps.txt: 5 ms per
+        utterance).  A finished sequence's steps return at once (state[DONE]), as they do between two polls."""
         st = self.stream.cuda_stream
         self.stream.synchronize()
         ops.Graph.begin(st)
         self.enqueue_step(st)
         self.graph = ops.Graph().end(st)
+        self.graph_group, self.group = None, int(L.tool_knob("M5_AR_GROUP", str(GRAPH_GROUP)))      # A/B knob (tools/ar_step_bench.py)
+        if self.group > 1 and self.mega:                        # (the per-launch form is 133 launches per step: one step per graph)
+            ops.Graph.begin(st)
+            for _ in range(self.group):
+                self.enqueue_step(st)
+            self.graph_group = ops.Graph().end(st)
 
     def _launch_steps(self, n: int, use_graph: bool, st: int) -> None:
         """Enqueue n decode steps (persistent launches under the per-device exclusive lock)."""
         with (_mega_exclusive(self.stream, self.m.dev) if self.mega else contextlib.nullcontext()):
+            if use_graph and getattr(self, "graph_group", None) is not None:
+                while n >= self.group:
+                    self.graph_group.launch(st)
+                    n -= self.group
             for _ in range(n):
                 if use_graph:
                     self.graph.launch(st)
