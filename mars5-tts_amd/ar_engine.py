@@ -155,6 +155,8 @@ class ARSession:
         self.mega_dbg: Optional[torch.Tensor] = None           # tools/ar_mega_clock.py: (32, 16, 8) int64 phase stamps
         self.mega = _mega_default() and model.dt != torch.float32 and (D, F, H) == (1536, 3584, 24) and not buffers
         self.graph: Optional[ops.Graph] = None
+        self.graph_group: Optional[ops.Graph] = None           # GRAPH_GROUP consecutive steps as one graph (capture)
+        self.group = 1
         self.step_plan: Optional[ops.StagePlan] = None         # the recorded decode step (enqueue_step)
         self.use_c_plan = True                                 # False: the step's launches are composed in this file (tests compare the two)
         self._sample_args: Optional[L.SampleArgs] = None
@@ -357,7 +359,7 @@ class ARSession:
     def _launch_steps(self, n: int, use_graph: bool, st: int) -> None:
         """Enqueue n decode steps (persistent launches under the per-device exclusive lock)."""
         with (_mega_exclusive(self.stream, self.m.dev) if self.mega else contextlib.nullcontext()):
-            if use_graph and getattr(self, "graph_group", None) is not None:
+            if use_graph and self.graph_group is not None:
                 while n >= self.group:
                     self.graph_group.launch(st)
                     n -= self.group

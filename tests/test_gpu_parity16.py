@@ -290,6 +290,13 @@ def test_ar_persistent_step_is_bit_identical_to_the_per_launch_step(dev, full_bu
     s.prefill(prompt, ref)
     tok = s.decode(use_graph=True).cpu()
     assert s.mega and tok.tolist() == runs[False][1].tolist()
+    # the replays are graphs of ar_engine.GRAPH_GROUP steps (+ one-step graphs for the remainder of a poll interval)
+    assert s.graph_group is not None and s.group > 1
+    if window == 3000 and plen == 0:
+        s = _session(eng, b, st, P, N, noise, True)
+        s.prefill(prompt, ref)
+        tok = s.decode(use_graph=True, poll=s.group * 2 + 3).cpu()       # every poll interval = two grouped graphs + three single steps
+        assert s.mega and tok.tolist() == runs[False][1].tolist()
     print(f"AR persistent step {str(dt).split('.')[-1]} window {window} prompt {P}: {n_gen} steps bit-identical to the per-launch form")
 
 
